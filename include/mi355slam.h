@@ -1,0 +1,198 @@
+/*
+ * mi355slam.h -- C ABI of libmi355slam.so: the MI355X (gfx950) implementation of the
+ * AaltoML/SLAM-module hot path (image pyramid + ORB extraction, Hamming matching, local BA).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry point
+ * names the reference interface it replaces (file:line relative to the reference tree).
+ * Host-side C++ shims with the reference's own signatures live in slam-module_amd/host/.
+ *
+ * Conventions
+ *   - every function returns MS_OK (0) or a negative ms_status; ms_last_error() gives the text.
+ *     Nothing throws across the ABI (the reference itself has no exceptions / error codes:
+ *     assert + bool/empty returns, e.g. bundle_adjuster.cpp:239,411).
+ *   - a ms_ctx owns one HIP stream on one device; objects created from it are single-threaded
+ *     (the reference calls this path from one backend thread, mapper.cpp:229-279).  Distinct
+ *     contexts may be used concurrently from different threads.
+ *   - "device pointer" arguments must be memory of the context's device; "host pointer"
+ *     arguments are ordinary memory (pinned memory makes the copies asynchronous).
+ *   - there is NO CPU fallback: without a usable gfx950 device ms_ctx_create() fails.
+ */
+#ifndef MI355SLAM_H
+#define MI355SLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_MAX_LEVELS 16
+#define MS_ORB_PATCH_RADIUS 19       /* static_settings.hpp:14 */
+#define MS_HAMMING_THR_LOW 50        /* keyframe_matcher.hpp:10 */
+#define MS_HAMMING_THR_HIGH 100      /* keyframe_matcher.hpp:11 */
+#define MS_HAMMING_MAX 256           /* keyframe_matcher.hpp:12 */
+
+typedef enum {
+    MS_OK = 0,
+    MS_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    MS_ERR_NO_DEVICE = -2,    /* no gfx950 device, or HIP runtime failure at init */
+    MS_ERR_HIP = -3,          /* a HIP call failed; see ms_last_error */
+    MS_ERR_CAPACITY = -4,     /* a fixed capacity given at create time was exceeded */
+    MS_ERR_NUMERIC = -5       /* BA: non-finite state */
+} ms_status;
+
+typedef struct ms_ctx ms_ctx;
+typedef struct ms_orb ms_orb;
+
+/* ---------------------------------------------------------------------------------------------
+ * Context
+ * ------------------------------------------------------------------------------------------- */
+int ms_ctx_create(int device, ms_ctx **out);
+void ms_ctx_destroy(ms_ctx *ctx);
+int ms_ctx_sync(ms_ctx *ctx);                 /* hipStreamSynchronize on the context stream */
+void *ms_ctx_stream(ms_ctx *ctx);             /* the hipStream_t, for event timing by the caller */
+const char *ms_last_error(const ms_ctx *ctx); /* never NULL; valid until the next call on ctx */
+const char *ms_version(void);
+/* HIP-event timing on the context stream (bench.py measures the hot path with these). */
+int ms_timer_start(ms_ctx *ctx);
+int ms_timer_stop_ms(ms_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */
+/* plain device memory helpers so a C caller needs no HIP headers */
+int ms_dev_alloc(ms_ctx *ctx, size_t bytes, void **out);
+int ms_dev_free(ms_ctx *ctx, void *p);
+int ms_dev_upload(ms_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int ms_dev_download(ms_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * S1/S2: pyramid geometry -- replaces StaticSettings (static_settings.cpp:9-60) and the level
+ * sizing of image_pyramid.cpp:76-78.  Host-only arithmetic, exposed so callers size buffers.
+ * ------------------------------------------------------------------------------------------- */
+int ms_scale_factors(int levels, float scale_factor, float *out);
+int ms_level_sigma_sq(int levels, float scale_factor, float *out);
+int ms_level_quotas(int levels, float scale_factor, int max_kpts, int32_t *out);
+int ms_level_sizes(int levels, float scale_factor, int width, int height, int32_t *w, int32_t *h);
+
+/* ---------------------------------------------------------------------------------------------
+ * ORB extractor -- replaces OrbExtractor::build / detectAndExtract (orb_extractor.hpp:11-30,
+ * orb_extractor.cpp:73-164), ImagePyramid (image_pyramid.hpp:16-30, image_pyramid.cpp:68-86) and
+ * FeatureDetector (feature_detector.hpp:15-24, feature_detector.cpp:68-134).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t width, height;     /* frame size (fixed per extractor, like the lazily-built pyramid) */
+    int32_t levels;            /* parameters.slam.orbScaleLevels */
+    float scale_factor;        /* parameters.slam.orbScaleFactor */
+    int32_t max_kpts;          /* parameters.slam.maxKeypoints */
+    int32_t lk_track_level;    /* parameters.slam.orbLkTrackLevel */
+    int32_t fast_threshold;    /* this build's detector: FAST-9/16 threshold (score > threshold) */
+    int32_t max_tracks;        /* capacity for tracker features per frame */
+    int32_t max_batch;         /* frames per ms_orb_extract call (>= 1) */
+} ms_orb_config;
+
+/* Per-frame outputs, structure-of-arrays, `capacity` = max_tracks + max_kpts slots per frame.
+ * Frame f's keypoint i is element f*capacity + i of each array (desc: 8 words per slot).
+ * Order inside a frame: tracker features first, then detected points level-major
+ * (orb_extractor.cpp:136-162); each level ordered by (FAST score desc, y*w+x asc). */
+typedef struct {
+    int32_t capacity;
+    int32_t *count;      /* [batch] */
+    float *x, *y;        /* level-0 pixel coordinates (KeyPoint::pt, key_point.hpp:14) */
+    float *angle;        /* degrees [0,360) (KeyPoint::angle) */
+    int32_t *octave;     /* KeyPoint::octave */
+    uint32_t *desc;      /* KeyPoint::descriptor, std::array<uint32_t,8> (key_point.hpp:19-20) */
+    int32_t *track_id;   /* keyPointTrackIds: tracker id or -1 (orb_extractor.cpp:122,161) */
+} ms_keypoints;
+
+int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out);
+void ms_orb_destroy(ms_orb *orb);
+
+/* Optional camera validity mask (stand-in for tracker::Camera::isValidPixel, orb_extractor.cpp:101,
+ * :231): width*height bytes in host memory, 0 = invalid.  NULL clears it (all pixels valid). */
+int ms_orb_set_valid_mask(ms_orb *orb, const uint8_t *mask_host);
+
+/* detectAndExtract for a batch of frames.
+ *   images        : frame f starts at images + f*frame_stride, rows `row_stride` bytes apart.
+ *   images_on_device != 0: `images` is device memory and is used IN PLACE as pyramid level 0
+ *                   (needs a 16-byte aligned base and row_stride % 16 == 0, else it is copied on
+ *                   the device); it must stay valid until the call's work has completed.
+ *   track_xy      : optional [n_frames][max_tracks][2] level-0 coords (host), track_id [n_frames][max_tracks],
+ *                   n_tracks [n_frames].  NULL = no tracker features.
+ * Asynchronous on the context stream; results are read with ms_orb_download / ms_orb_device_view
+ * after ms_ctx_sync (ms_orb_download synchronises itself). */
+int ms_orb_extract(ms_orb *orb, const uint8_t *images, int images_on_device, int n_frames,
+                   size_t frame_stride, size_t row_stride,
+                   const float *track_xy, const int32_t *track_id, const int32_t *n_tracks);
+
+/* Device-resident results of the last ms_orb_extract (pointers are device memory owned by orb). */
+int ms_orb_device_view(ms_orb *orb, ms_keypoints *view);
+/* Copy frame `frame`'s keypoints to caller-owned host arrays (each sized >= capacity); returns count in *n. */
+int ms_orb_download(ms_orb *orb, int frame, float *x, float *y, float *angle, int32_t *octave,
+                    uint32_t *desc, int32_t *track_id, int32_t *n);
+int ms_orb_capacity(const ms_orb *orb);
+
+/* ImagePyramid::getLevel / getBlurredLevel (image_pyramid.hpp:24-25): copy one level of one frame
+ * of the last batch to host, tightly packed w*h bytes (debug / parity testing). */
+int ms_orb_level_size(const ms_orb *orb, int level, int32_t *w, int32_t *h);
+int ms_orb_download_level(ms_orb *orb, int frame, int level, int blurred, uint8_t *dst_host);
+/* FeatureDetector::detect (feature_detector.cpp:20-28): per-level detector output of the last batch
+ * BEFORE orientation: integer level coordinates + FAST score, `*n` points (<= quota of the level). */
+int ms_orb_download_detections(ms_orb *orb, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int32_t *n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Descriptor matching -- the scoring core of keyframe_matcher.cpp (compute_descriptor_distance_32,
+ * openvslam/match_base.h:18-39) as device primitives.
+ * ------------------------------------------------------------------------------------------- */
+/* Brute-force best / second-best of every query against every target, for `n_pairs` independent
+ * (query set, target set) pairs laid out back to back: pair p uses q + p*nq*8 and t + p*nt*8.
+ * Update rule of keyframe_matcher.cpp:106-112 (strict '<': lowest index wins ties).
+ * Optional masks (device pointers or NULL): q_bucket/t_bucket [n_pairs*nq]/[n_pairs*nt] -- only equal
+ * bucket ids are compared (DBoW2 node gate, keyframe_matcher.cpp:74); t_valid [n_pairs*nt] -- 0 skips the
+ * target (map-point gates, keyframe_matcher.cpp:94-100).
+ * Outputs (device): best_idx (-1 if none), best_dist, second_dist (256 if none). All device pointers. */
+int ms_hamming_best2(ms_ctx *ctx, const uint32_t *q, int nq, const uint32_t *t, int nt, int n_pairs,
+                     const int32_t *q_bucket, const int32_t *t_bucket, const uint8_t *t_valid,
+                     int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist);
+
+/* Accept rule of matchForLoopClosures without the greedy state (keyframe_matcher.cpp:115-122):
+ * match[i] = best_idx if best <= 50 and ratio*second >= best, else -1.  Device pointers. */
+int ms_ratio_test(ms_ctx *ctx, const int32_t *best_idx, const uint16_t *best_dist, const uint16_t *second_dist,
+                  int n, float lowe_ratio, int max_dist, int32_t *match);
+
+/* Bag-of-words buckets of one keyframe in CSR form (DBoW2::FeatureVector is an ordered std::map
+ * node id -> keypoint indices; keyframe_matcher.cpp:65-76).  Arrays are DEVICE pointers. */
+typedef struct {
+    int32_t n_nodes;
+    const int32_t *node_id;      /* [n_nodes] strictly ascending */
+    const int32_t *node_start;   /* [n_nodes+1] */
+    const int32_t *kp_idx;       /* [node_start[n_nodes]] */
+} ms_bow;
+
+/* One keyframe's matching inputs (device pointers). */
+typedef struct {
+    int32_t n;                   /* keypoints */
+    const uint32_t *desc;        /* [n*8] */
+    const float *angle;          /* [n] degrees */
+    const int32_t *octave;       /* [n] (M2 only) */
+    const double *bearing;       /* [n*3] KeyPoint::bearing (M2 only) */
+    const uint8_t *usable;       /* [n] M1: has a (triangulated) map point (keyframe_matcher.cpp:79-84,:94-96);
+                                        M2: has NO map point (keyframe_matcher.cpp:205-221) */
+    ms_bow bow;
+} ms_match_frame;
+
+/* matchForLoopClosures (keyframe_matcher.hpp:33-40, keyframe_matcher.cpp:50-158): exact greedy
+ * semantics (targets consumed in BoW-node / keypoint order), rotation histogram included.
+ * Batched: pair p matches kf1[p] against kf2[p]; matched[p] is a device array [kf1[p].n] (-1 = none);
+ * n_matches [n_pairs] device.  `pairs1/pairs2` are HOST arrays of structs holding device pointers. */
+int ms_match_loop_closure(ms_ctx *ctx, const ms_match_frame *pairs1, const ms_match_frame *pairs2, int n_pairs,
+                          float lowe_ratio, int check_orientation, int32_t *const *matched, int32_t *n_matches);
+
+/* matchForTriangulationDBoW (keyframe_matcher.hpp:53, keyframe_matcher.cpp:160-293).
+ * E12 [n_pairs*9] device, row-major essential matrices (create_E_21, essential_solver.cc:157-162);
+ * scale_factors [levels] device; residual_deg_thr = epipolarCheckThresholdDegrees. */
+int ms_match_triangulation(ms_ctx *ctx, const ms_match_frame *pairs1, const ms_match_frame *pairs2, int n_pairs,
+                           const double *E12, const float *scale_factors, float residual_deg_thr,
+                           int check_orientation, int32_t *const *matched, int32_t *n_matches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355SLAM_H */

@@ -1,0 +1,106 @@
+// ctx.cpp -- device context, stream, event timing and plain memory helpers of the C ABI.
+#include "ms_internal.h"
+#include <cstring>
+
+int ms_scratch(ms_ctx *c, size_t bytes, void **out) {
+    if (bytes > c->scratch_bytes) {
+        MS_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->scratch) MS_HIP(c, hipFree(c->scratch));
+        c->scratch = nullptr; c->scratch_bytes = 0;
+        const size_t want = ms_align_up(bytes * 2, 4096);
+        MS_HIP(c, hipMalloc(&c->scratch, want));
+        c->scratch_bytes = want;
+    }
+    *out = c->scratch;
+    return MS_OK;
+}
+
+extern "C" {
+
+const char *ms_version(void) { return "mi355slam 0.1 (gfx950)"; }
+
+int ms_ctx_create(int device, ms_ctx **out) {
+    if (!out) return MS_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MS_ERR_NO_DEVICE;   // no CPU fallback
+    if (device < 0 || device >= n) return MS_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MS_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MS_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MS_ERR_NO_DEVICE;   // kernels are gfx950-only
+    ms_ctx *c = new ms_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return MS_ERR_HIP;
+    }
+    *out = c;
+    return MS_OK;
+}
+
+void ms_ctx_destroy(ms_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+int ms_ctx_sync(ms_ctx *c) {
+    if (!c) return MS_ERR_INVALID;
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    return MS_OK;
+}
+
+void *ms_ctx_stream(ms_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+const char *ms_last_error(const ms_ctx *c) { return c ? c->err : "null context"; }
+
+int ms_timer_start(ms_ctx *c) {
+    if (!c) return MS_ERR_INVALID;
+    MS_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return MS_OK;
+}
+
+int ms_timer_stop_ms(ms_ctx *c, float *ms) {
+    if (!c || !ms) return MS_ERR_INVALID;
+    MS_HIP(c, hipEventRecord(c->ev1, c->stream));
+    MS_HIP(c, hipEventSynchronize(c->ev1));
+    MS_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MS_OK;
+}
+
+int ms_dev_alloc(ms_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return MS_ERR_INVALID;
+    MS_HIP(c, hipSetDevice(c->device));
+    MS_HIP(c, hipMalloc(out, bytes ? bytes : 1));
+    return MS_OK;
+}
+
+int ms_dev_free(ms_ctx *c, void *p) {
+    if (!c) return MS_ERR_INVALID;
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    MS_HIP(c, hipFree(p));
+    return MS_OK;
+}
+
+int ms_dev_upload(ms_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) return MS_ERR_INVALID;
+    MS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    return MS_OK;
+}
+
+int ms_dev_download(ms_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) return MS_ERR_INVALID;
+    MS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// match.hip -- descriptor matching on gfx950: Hamming best/second-best search and the two
+// BoW-bucketed greedy matchers of keyframe_matcher.cpp with their exact sequential semantics.
+//
+//   ms_hamming_best2        scoring core of every matcher (compute_descriptor_distance_32,
+//                           openvslam/match_base.h:18-39; update rule keyframe_matcher.cpp:106-112)
+//   ms_ratio_test           accept rule keyframe_matcher.cpp:115-122
+//   ms_match_loop_closure   matchForLoopClosures       keyframe_matcher.cpp:50-158
+//   ms_match_triangulation  matchForTriangulationDBoW  keyframe_matcher.cpp:160-293
+//
+// The brute-force kernel is VALU-bound, not HBM-bound (32 distance evaluations per input byte at
+// 2000x2000): each lane keeps one 256-bit query in 8 VGPRs, targets are staged through LDS in tiles
+// of 256 and read back as wave-uniform broadcasts (2 x ds_read_b128 per target), distance is 8 x
+// (v_xor, v_bcnt_u32_b32-accumulate), and best/second are tracked branch-free on packed
+// (distance<<20 | index) keys (min / max / min).
+#include "ms_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t hamming8(const uint32_t q[8], const uint4 a, const uint4 b) {
+    uint32_t d = __popc(q[0] ^ a.x);
+    d += __popc(q[1] ^ a.y); d += __popc(q[2] ^ a.z); d += __popc(q[3] ^ a.w);
+    d += __popc(q[4] ^ b.x); d += __popc(q[5] ^ b.y); d += __popc(q[6] ^ b.z); d += __popc(q[7] ^ b.w);
+    return d;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_hamming_best2(const uint32_t *__restrict__ q, int nq, const uint32_t *__restrict__ t, int nt,
+                                                       const int32_t *__restrict__ qb, const int32_t *__restrict__ tb, const uint8_t *__restrict__ tv,
+                                                       int32_t *__restrict__ best_idx, uint16_t *__restrict__ best_dist, uint16_t *__restrict__ second_dist) {
+    __shared__ uint4 s_t[256][2];
+    __shared__ int32_t s_b[256];
+    __shared__ uint8_t s_v[256];
+    const int p = blockIdx.y, tid = threadIdx.x;
+    const int qi = blockIdx.x * 256 + tid;
+    const uint32_t *Q = q + (uint64_t)p * nq * 8;
+    const uint4 *T = reinterpret_cast<const uint4 *>(t + (uint64_t)p * nt * 8);
+    uint32_t qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t my_bucket = 0;
+    if (qi < nq) {
+        const uint4 a = reinterpret_cast<const uint4 *>(Q)[2 * qi], b = reinterpret_cast<const uint4 *>(Q)[2 * qi + 1];
+        qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = b.x; qr[5] = b.y; qr[6] = b.z; qr[7] = b.w;
+        if (MASKED && qb) my_bucket = qb[(uint64_t)p * nq + qi];
+    }
+    uint32_t best = kNone, second = kNone;
+    for (int base = 0; base < nt; base += 256) {
+        __syncthreads();
+        const int j = base + tid;
+        if (j < nt) {
+            s_t[tid][0] = T[2 * j]; s_t[tid][1] = T[2 * j + 1];
+            if (MASKED) {
+                s_b[tid] = tb ? tb[(uint64_t)p * nt + j] : 0;
+                s_v[tid] = tv ? tv[(uint64_t)p * nt + j] : 1;
+            }
+        }
+        __syncthreads();
+        const int cnt = min(256, nt - base);
+        for (int k = 0; k < cnt; ++k) {
+            const uint32_t d = hamming8(qr, s_t[k][0], s_t[k][1]);
+            uint32_t key = (d << 20) | (uint32_t)(base + k);
+            if (MASKED) {
+                const bool ok = s_v[k] != 0 && (!(qb && tb) || s_b[k] == my_bucket);
+                key = ok ? key : kNone;
+            }
+            const uint32_t lo = min(best, key), hi = max(best, key);
+            second = min(second, hi);
+            best = lo;
+        }
+    }
+    if (qi < nq) {
+        const uint64_t o = (uint64_t)p * nq + qi;
+        best_idx[o] = best == kNone ? -1 : (int32_t)(best & 0xFFFFFu);
+        best_dist[o] = best == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(best >> 20);
+        second_dist[o] = second == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(second >> 20);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ratio_test(const int32_t *__restrict__ bi, const uint16_t *__restrict__ bd, const uint16_t *__restrict__ sd,
+                                                    int n, float ratio, int max_dist, int32_t *__restrict__ match) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = bd[i], s = sd[i];
+    bool ok = bi[i] >= 0 && b <= (unsigned)max_dist;                 // keyframe_matcher.cpp:115
+    if (ok && __fmul_rn(ratio, (float)s) < (float)b) ok = false;     // keyframe_matcher.cpp:120
+    match[i] = ok ? bi[i] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greedy BoW matchers: one wavefront per keyframe pair.  The walk over shared vocabulary nodes and
+// over kf1's keypoints is sequential (targets are consumed as they are matched, so query i depends on
+// the queries before it: keyframe_matcher.cpp:98-100,:128 / :224-226,:249); the 64 lanes scan the
+// node's kf2 candidates in parallel and a butterfly reduction rebuilds exactly what the sequential
+// scan would have kept (M1: first minimum + second minimum; M2: LAST minimum among epipolar inliers).
+struct GreedyArgs {
+    const ms_match_frame *f1, *f2;
+    int32_t *const *matched;
+    int32_t *n_matches;
+    const double *E12;            // M2
+    const float *scale_factors;   // M2
+    float lowe_ratio, residual_deg_thr;
+    int check_orientation;
+};
+
+__device__ __forceinline__ int angle_bin(float a1, float a2) {   // match_angle_checker.h:72-83
+    float d = __fsub_rn(a1, a2);
+    if (d < 0.0) d = (float)__dadd_rn((double)d, 360.0);
+    if (360.0 <= d) d = (float)__dsub_rn((double)d, 360.0);
+    const float inv_len = 1.0f / 30;
+    int b = __float2int_rn(__fmul_rn(d, inv_len));
+    return (b < 0 || b >= 30) ? 29 : b;
+}
+
+__device__ __forceinline__ bool epipolar_ok(const double *b1, const double *b2, const double *E, float scale1, float thr_deg) {
+    // keyframe_matcher.cpp:23-44, evaluated in the same operation order (no contraction)
+    double n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        n[i] = __dadd_rn(__dadd_rn(__dmul_rn(E[3 * i], b2[0]), __dmul_rn(E[3 * i + 1], b2[1])), __dmul_rn(E[3 * i + 2], b2[2]));
+    const double nn = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(n[0], n[0]), __dmul_rn(n[1], n[1])), __dmul_rn(n[2], n[2])));
+    const double dot = __dadd_rn(__dadd_rn(__dmul_rn(n[0], b1[0]), __dmul_rn(n[1], b1[1])), __dmul_rn(n[2], b1[2]));
+    const double cr = __ddiv_rn(dot, nn);
+    const double res = __dsub_rn(M_PI / 2.0, fabs(acos(cr)));
+    const double thr = __ddiv_rn(__dmul_rn((double)thr_deg, M_PI), 180.0);
+    return res < __dmul_rn(thr, (double)scale1);
+}
+
+template <bool TRIANGULATION>
+__global__ __launch_bounds__(64) void k_match_greedy(GreedyArgs A) {
+    __shared__ uint32_t s_used[1024];          // bitset over kf2 keypoints (n2 <= 32768)
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
+    int32_t *matched = A.matched[p];
+    for (int i = lane; i < F1.n; i += 64) matched[i] = -1;
+    for (int i = lane; i < 1024; i += 64) s_used[i] = 0;
+    __syncthreads();
+    const double *E = TRIANGULATION ? A.E12 + 9 * (uint64_t)p : nullptr;
+    int hist[30];
+#pragma unroll
+    for (int b = 0; b < 30; ++b) hist[b] = 0;
+    int num = 0, a = 0, b = 0;
+    while (a < F1.bow.n_nodes && b < F2.bow.n_nodes) {                  // ordered-map merge
+        const int ida = F1.bow.node_id[a], idb = F2.bow.node_id[b];
+        if (ida < idb) { ++a; continue; }
+        if (idb < ida) { ++b; continue; }
+        const int s2 = F2.bow.node_start[b], e2 = F2.bow.node_start[b + 1];
+        for (int pp = F1.bow.node_start[a]; pp < F1.bow.node_start[a + 1]; ++pp) {
+            const int i1 = F1.bow.kp_idx[pp];
+            if (!F1.usable[i1]) continue;
+            const uint4 qa = reinterpret_cast<const uint4 *>(F1.desc)[2 * i1], qb = reinterpret_cast<const uint4 *>(F1.desc)[2 * i1 + 1];
+            const uint32_t qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            uint32_t best = kNone, second = kNone;
+            for (int r = s2 + lane; r < e2; r += 64) {
+                const int i2 = F2.bow.kp_idx[r];
+                if (!F2.usable[i2]) continue;
+                if (s_used[i2 >> 5] & (1u << (i2 & 31))) continue;
+                const uint4 ta = reinterpret_cast<const uint4 *>(F2.desc)[2 * i2], tb = reinterpret_cast<const uint4 *>(F2.desc)[2 * i2 + 1];
+                const uint32_t d = hamming8(qr, ta, tb);
+                const uint32_t pos = (uint32_t)(r - s2);
+                uint32_t key;
+                if (TRIANGULATION) {
+                    if (d > MS_HAMMING_THR_LOW) continue;                                        // :231
+                    if (!epipolar_ok(F1.bearing + 3 * (uint64_t)i1, F2.bearing + 3 * (uint64_t)i2, E,
+                                     A.scale_factors[F1.octave[i1]], A.residual_deg_thr)) continue;   // :237-239
+                    key = (d << 20) | (0xFFFFFu - pos);                                           // ties: LAST wins
+                } else {
+                    key = (d << 20) | pos;                                                        // ties: FIRST wins
+                }
+                const uint32_t lo = min(best, key), hi = max(best, key);
+                second = min(second, hi);
+                best = lo;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t ob = __shfl_xor(best, off, 64), os = __shfl_xor(second, off, 64);
+                const uint32_t lo = min(best, ob), hi = max(best, ob);
+                second = min(min(second, os), hi);
+                best = lo;
+            }
+            if (best == kNone) continue;
+            const uint32_t bd = best >> 20;
+            const uint32_t pos = TRIANGULATION ? 0xFFFFFu - (best & 0xFFFFFu) : (best & 0xFFFFFu);
+            const int bi = F2.bow.kp_idx[s2 + (int)pos];
+            if (!TRIANGULATION) {
+                const uint32_t sd = second == kNone ? (uint32_t)MS_HAMMING_MAX : second >> 20;
+                if (MS_HAMMING_THR_LOW < bd) continue;                                           // :115
+                if (__fmul_rn(A.lowe_ratio, (float)sd) < (float)bd) continue;                    // :120
+            }
+            if (lane == 0) { matched[i1] = bi; s_used[bi >> 5] |= 1u << (bi & 31); }
+            __syncthreads();
+            ++num;
+            if (A.check_orientation) {
+                const int bin = angle_bin(F1.angle[i1], F2.angle[bi]);
+#pragma unroll
+                for (int k = 0; k < 30; ++k) hist[k] += (k == bin);
+            }
+        }
+        ++a; ++b;
+    }
+    __syncthreads();
+    if (A.check_orientation) {
+        // top-3 bins by (size desc, bin asc); everything else is invalid (match_angle_checker.h:108-134)
+        int v0 = -1, v1 = -1, v2 = -1;
+#pragma unroll
+        for (int rep = 0; rep < 3; ++rep) {
+            int bb = -1, bc = -1;
+#pragma unroll
+            for (int k = 0; k < 30; ++k)
+                if (k != v0 && k != v1 && hist[k] > bc) { bc = hist[k]; bb = k; }
+            if (rep == 0) v0 = bb; else if (rep == 1) v1 = bb; else v2 = bb;
+        }
+        int removed = 0;
+        for (int i = lane; i < F1.n; i += 64) {
+            const int m = matched[i];
+            if (m >= 0) {
+                const int bin = angle_bin(F1.angle[i], F2.angle[m]);
+                if (bin != v0 && bin != v1 && bin != v2) { matched[i] = -1; ++removed; }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) removed += __shfl_xor(removed, off, 64);
+        num -= removed;
+    }
+    if (lane == 0) A.n_matches[p] = num;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ms_hamming_best2(ms_ctx *c, const uint32_t *q, int nq, const uint32_t *t, int nt, int n_pairs,
+                     const int32_t *q_bucket, const int32_t *t_bucket, const uint8_t *t_valid,
+                     int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist) {
+    if (!c || !q || !t || !best_idx || !best_dist || !second_dist) return MS_ERR_INVALID;
+    if (nq < 0 || nt < 0 || n_pairs < 0 || nt >= (1 << 20) || n_pairs > 65535) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_best2: size out of range");
+    if (nq == 0 || n_pairs == 0) return MS_OK;
+    if ((q_bucket == nullptr) != (t_bucket == nullptr)) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_best2: give both bucket arrays or neither");
+    if (reinterpret_cast<uintptr_t>(q) % 16 || reinterpret_cast<uintptr_t>(t) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_best2: descriptors must be 16-byte aligned");
+    MS_HIP(c, hipSetDevice(c->device));
+    dim3 grid(ms_div_up(nq, 256), n_pairs);
+    if (q_bucket || t_valid)
+        hipLaunchKernelGGL(k_hamming_best2<true>, grid, dim3(256), 0, c->stream, q, nq, t, nt, q_bucket, t_bucket, t_valid, best_idx, best_dist, second_dist);
+    else
+        hipLaunchKernelGGL(k_hamming_best2<false>, grid, dim3(256), 0, c->stream, q, nq, t, nt, q_bucket, t_bucket, t_valid, best_idx, best_dist, second_dist);
+    MS_KERNEL_CHECK(c, "k_hamming_best2");
+    return MS_OK;
+}
+
+int ms_ratio_test(ms_ctx *c, const int32_t *best_idx, const uint16_t *best_dist, const uint16_t *second_dist,
+                  int n, float lowe_ratio, int max_dist, int32_t *match) {
+    if (!c || !best_idx || !best_dist || !second_dist || !match || n < 0) return MS_ERR_INVALID;
+    if (n == 0) return MS_OK;
+    MS_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_ratio_test, dim3(ms_div_up(n, 256)), dim3(256), 0, c->stream, best_idx, best_dist, second_dist, n, lowe_ratio, max_dist, match);
+    MS_KERNEL_CHECK(c, "k_ratio_test");
+    return MS_OK;
+}
+
+static int launch_greedy(ms_ctx *c, bool tri, const ms_match_frame *p1, const ms_match_frame *p2, int n_pairs,
+                         const double *E12, const float *sf, float thr_deg, float ratio, int check_orientation,
+                         int32_t *const *matched, int32_t *n_matches) {
+    if (!c || !p1 || !p2 || !matched || !n_matches || n_pairs < 0) return MS_ERR_INVALID;
+    if (n_pairs == 0) return MS_OK;
+    for (int p = 0; p < n_pairs; ++p) {
+        if (p2[p].n > 32768 || p1[p].n < 0 || p2[p].n < 0) return ms_fail(c, MS_ERR_CAPACITY, "greedy matcher: kf2 has %d keypoints (max 32768)", p2[p].n);
+        if (reinterpret_cast<uintptr_t>(p1[p].desc) % 16 || reinterpret_cast<uintptr_t>(p2[p].desc) % 16)
+            return ms_fail(c, MS_ERR_INVALID, "greedy matcher: descriptors must be 16-byte aligned");
+    }
+    MS_HIP(c, hipSetDevice(c->device));
+    const size_t fb = sizeof(ms_match_frame) * (size_t)n_pairs, mb = sizeof(int32_t *) * (size_t)n_pairs;
+    void *scr = nullptr;
+    int rc = ms_scratch(c, 2 * fb + mb + 64, &scr);
+    if (rc != MS_OK) return rc;
+    char *base = static_cast<char *>(scr);
+    MS_HIP(c, hipMemcpyAsync(base, p1, fb, hipMemcpyHostToDevice, c->stream));
+    MS_HIP(c, hipMemcpyAsync(base + fb, p2, fb, hipMemcpyHostToDevice, c->stream));
+    MS_HIP(c, hipMemcpyAsync(base + 2 * fb, matched, mb, hipMemcpyHostToDevice, c->stream));
+    GreedyArgs A{};
+    A.f1 = reinterpret_cast<const ms_match_frame *>(base);
+    A.f2 = reinterpret_cast<const ms_match_frame *>(base + fb);
+    A.matched = reinterpret_cast<int32_t *const *>(base + 2 * fb);
+    A.n_matches = n_matches; A.E12 = E12; A.scale_factors = sf; A.lowe_ratio = ratio; A.residual_deg_thr = thr_deg;
+    A.check_orientation = check_orientation;
+    if (tri) hipLaunchKernelGGL(k_match_greedy<true>, dim3(n_pairs), dim3(64), 0, c->stream, A);
+    else hipLaunchKernelGGL(k_match_greedy<false>, dim3(n_pairs), dim3(64), 0, c->stream, A);
+    MS_KERNEL_CHECK(c, "k_match_greedy");
+    return MS_OK;
+}
+
+int ms_match_loop_closure(ms_ctx *c, const ms_match_frame *pairs1, const ms_match_frame *pairs2, int n_pairs,
+                          float lowe_ratio, int check_orientation, int32_t *const *matched, int32_t *n_matches) {
+    return launch_greedy(c, false, pairs1, pairs2, n_pairs, nullptr, nullptr, 0.f, lowe_ratio, check_orientation, matched, n_matches);
+}
+
+int ms_match_triangulation(ms_ctx *c, const ms_match_frame *pairs1, const ms_match_frame *pairs2, int n_pairs,
+                           const double *E12, const float *scale_factors, float residual_deg_thr,
+                           int check_orientation, int32_t *const *matched, int32_t *n_matches) {
+    if (!E12 || !scale_factors) return MS_ERR_INVALID;
+    return launch_greedy(c, true, pairs1, pairs2, n_pairs, E12, scale_factors, residual_deg_thr, 0.f, check_orientation, matched, n_matches);
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// ms_internal.h -- shared internals of libmi355slam (product code; never includes oracle/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/mi355slam.h"
+
+struct ms_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 0;
+    void *scratch = nullptr;      // growable device scratch for small per-call argument tables
+    size_t scratch_bytes = 0;
+    char err[512] = {0};
+};
+
+// device scratch of at least `bytes`, reused across calls on the context stream
+int ms_scratch(ms_ctx *ctx, size_t bytes, void **out);
+
+inline int ms_fail(ms_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define MS_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ms_fail((ctx), MS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                           __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define MS_KERNEL_CHECK(ctx, name)                                                                 \
+    do {                                                                                           \
+        hipError_t e__ = hipGetLastError();                                                        \
+        if (e__ != hipSuccess)                                                                     \
+            return ms_fail((ctx), MS_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// host geometry (geometry.cpp) -- restates static_settings.cpp:9-60 and image_pyramid.cpp:76-78
+namespace msgeo {
+void scale_factors(int levels, float f, float *out);
+void level_sigma_sq(int levels, float f, float *out);
+void level_quotas(int levels, float f, int max_kpts, int32_t *out);
+void level_sizes(int levels, float f, int w0, int h0, int32_t *w, int32_t *h);
+void umax(int32_t *u16);
+// cv::resize INTER_LINEAR 8U coefficient tables (11-bit fixed point)
+void resize_tables(int src_n, int dst_n, bool is_x, std::vector<int16_t> &ofs, std::vector<int16_t> &coef);
+}  // namespace msgeo
+
+inline int ms_div_up(int a, int b) { return (a + b - 1) / b; }
+inline size_t ms_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -1,0 +1,819 @@
+// orb.hip -- image pyramid + ORB extraction for gfx950 (MI355X), batched over frames.
+//
+// Replaces, behind the C ABI of include/mi355slam.h:
+//   ImagePyramid::update            image_pyramid.cpp:68-86     -> k_resize (chained), k_blur
+//   FeatureDetector::detect         feature_detector.cpp:68-134 -> k_fast, k_select
+//   OrbExtractor::detectAndExtract  orb_extractor.cpp:73-164    -> k_tracks, k_describe
+//
+// Data layout in HBM (one extractor, batch of B frames):
+//   level 0      : the caller's device image used in place (or uploaded once into the slab)
+//   slab[f]      : levels 1..n-1 and ALL blurred levels of frame f, each plane h x pitch bytes,
+//                  pitch = w rounded up to 64 B so every row starts 64-B aligned
+//   cand[f][l]   : FAST corner keys of level l (post 3x3 NMS), unordered; capacity w*h/4 (the
+//                  strict-maximum NMS cannot keep more than one pixel per 2x2 block)
+//   det[f][l]    : the selected corners of level l in key order (score desc, y*w+x asc)
+//   out[f]       : final keypoints, structure of arrays, tracker points first then level-major
+//
+// All pixel arithmetic is integer; the float32 steps of orientation/steering use explicit
+// round-to-nearest intrinsics (no FMA contraction) so results are bit-identical to the reference's
+// x86-64 SSE2 scalar build (CMakeLists.txt:4-5: -O2, no -march).
+#include "ms_internal.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr int kPatchRadius = MS_ORB_PATCH_RADIUS;   // 19
+constexpr int kHalfPatch = 15;                       // ORB_FAST_PATCH_HALF_SIZE
+constexpr int kMaxQuota = 4096;                      // per-level selection capacity (LDS sort)
+
+struct LevelGeom {
+    int32_t w, h, pitch, quota;
+    int32_t det_base;                 // first slot of this level in det arrays (prefix of quotas)
+    int32_t cand_cap;                 // capacity of this level's candidate list (entries)
+    int32_t btiles_x, btile_base;     // k_blur tile table (128x16 tiles)
+    int32_t ftiles_x, ftile_base;     // k_fast tile table (64x16 tiles)
+    uint64_t img_off, blur_off;       // byte offsets inside a frame slab
+    uint64_t cand_off;                // entry offset inside a frame's candidate buffer
+    float scale;                      // scaleFactors[l] (float32 chain)
+};
+
+struct PyrGeom {
+    int32_t levels, lk_level, fast_threshold, max_kpts, max_tracks, capacity;
+    int32_t width, height, btiles_total, ftiles_total;
+    uint64_t slab_stride, cand_stride;     // per frame: bytes / entries
+    int32_t umax[16];
+    LevelGeom L[MS_MAX_LEVELS];
+};
+
+struct FrameSrc {          // where pyramid level 0 lives for this call
+    const uint8_t *lvl0;
+    uint64_t lvl0_frame_stride;
+    int32_t lvl0_pitch;
+    uint8_t *slab;
+};
+
+__device__ __forceinline__ const uint8_t *level_ptr(const FrameSrc &s, const PyrGeom *g, int f, int l, int &pitch) {
+    if (l == 0) { pitch = s.lvl0_pitch; return s.lvl0 + (uint64_t)f * s.lvl0_frame_stride; }
+    pitch = g->L[l].pitch;
+    return s.slab + (uint64_t)f * g->slab_stride + g->L[l].img_off;
+}
+__device__ __forceinline__ uint8_t *blur_ptr(const FrameSrc &s, const PyrGeom *g, int f, int l) {
+    return s.slab + (uint64_t)f * g->slab_stride + g->L[l].blur_off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// copy a non-aligned caller image into the slab's level-0 plane (only when in-place use is impossible)
+__global__ __launch_bounds__(256) void k_copy_level0(const uint8_t *src, uint64_t frame_stride, uint64_t row_stride,
+                                                     uint8_t *slab, uint64_t slab_stride, uint64_t off, int w, int h, int pitch) {
+    const int f = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x < w && y < h) slab[(uint64_t)f * slab_stride + off + (uint64_t)y * pitch + x] = src[(uint64_t)f * frame_stride + (uint64_t)y * row_stride + x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// P1: cv::resize INTER_LINEAR, 8U (image_pyramid.cpp:79).  Level l from level l-1 of the same frame.
+// 4 destination pixels per lane, one dword store; taps through the vector cache (neighbouring
+// lanes share source bytes).  HBM-bound: reads level l-1 once, writes level l once.
+__global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, int l,
+                                                const int16_t *__restrict__ xofs, const int16_t *__restrict__ xcoef,
+                                                const int16_t *__restrict__ yofs, const int16_t *__restrict__ ycoef) {
+    const LevelGeom &D = g->L[l];
+    const int sw = g->L[l - 1].w, sh = g->L[l - 1].h;
+    const int f = blockIdx.z;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy >= D.h || dx0 >= D.w) return;
+    int spitch;
+    const uint8_t *S = level_ptr(src, g, f, l - 1, spitch);
+    uint8_t *dst = src.slab + (uint64_t)f * g->slab_stride + D.img_off;
+    const int sy = yofs[dy];
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);   // clip(sy, 0, ssize.height)
+    const uint8_t *S0 = S + (uint64_t)sy0 * spitch, *S1 = S + (uint64_t)sy1 * spitch;
+    const int b0 = ycoef[2 * dy], b1 = ycoef[2 * dy + 1];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dx = dx0 + i;
+        if (dx < D.w) {
+            const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+            const int a0 = xcoef[2 * dx], a1 = xcoef[2 * dx + 1];
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (uint32_t)v << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(dst + (uint64_t)dy * D.pitch + dx0) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P2: cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8U fixed point (image_pyramid.cpp:84).
+// One launch covers every level of every frame (tile table in PyrGeom).  Tile = 128x16 outputs,
+// (16+6)x(128+6) input bytes staged in LDS, separable: 8.8 taps, 16-bit rows, 32-bit columns.
+__device__ __forceinline__ int reflect101(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+__global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g) {
+    __shared__ uint8_t s_in[22][136];
+    __shared__ uint16_t s_h[22][128];
+    const int kq[7] = {18, 34, 48, 56, 48, 34, 18};
+    int t = blockIdx.x, l = 0;
+    while (l + 1 < g->levels && t >= g->L[l + 1].btile_base) ++l;
+    t -= g->L[l].btile_base;
+    const LevelGeom &G = g->L[l];
+    const int x0 = (t % G.btiles_x) * 128, y0 = (t / G.btiles_x) * 16;
+    const int f = blockIdx.y, w = G.w, h = G.h;
+    int pitch;
+    const uint8_t *img = level_ptr(src, g, f, l, pitch);
+    const int tid = threadIdx.x;
+    for (int r = tid >> 6; r < 22; r += 4) {
+        const uint8_t *row = img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch;
+        for (int c = tid & 63; c < 134; c += 64) s_in[r][c] = row[reflect101(x0 - 3 + c, w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < 22 * 128; i += 256) {
+        const int r = i >> 7, c = i & 127;
+        unsigned a = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a += (unsigned)kq[k] * s_in[r][c + k];
+        s_h[r][c] = (uint16_t)a;
+    }
+    __syncthreads();
+    uint8_t *dst = blur_ptr(src, g, f, l);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int item = tid + 256 * j, r = item >> 5, c4 = (item & 31) * 4;
+        const int y = y0 + r, x = x0 + c4;
+        if (y < h && x < w) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t a = 0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) a += (uint32_t)kq[k] * s_h[r + k][c4 + i];
+                packed |= ((a + 32768u) >> 16) << (8 * i);
+            }
+            *reinterpret_cast<uint32_t *>(dst + (uint64_t)y * G.pitch + x) = packed;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// D1: FAST-9/16 corners + score + 3x3 strict NMS (this build's detector behind
+// feature_detector.cpp:89-98).  One launch covers every level of every frame.  Tile = 64x16.
+//   phase 1: every score position of the (16+2)x(64+2) halo tile tests the 16-pixel ring with two
+//            16-bit masks (brighter / darker) and a shift-and test for 9 contiguous bits; corners are
+//            compacted into an LDS list
+//   phase 2: the list is scored densely (sliding min / max of 9 over the circular ring)
+//   phase 3: 3x3 strict-maximum NMS on the LDS score tile; survivors leave as 32-bit keys
+//            ((255-score)<<24 | y*w+x) with ONE global atomic per tile
+__device__ __forceinline__ bool contig9(uint32_t m) {
+    m |= m << 16;
+    uint32_t r = m & (m >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= m >> 8;
+    return r != 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
+    __shared__ uint8_t s_img[24][80];
+    __shared__ uint8_t s_sc[18][68];
+    __shared__ uint16_t s_list[18 * 66];
+    __shared__ uint32_t s_out[256];
+    __shared__ int s_n, s_m, s_base;
+    const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    int t = blockIdx.x, l = 0;
+    while (l + 1 < g->levels && t >= g->L[l + 1].ftile_base) ++l;
+    t -= g->L[l].ftile_base;
+    const LevelGeom &G = g->L[l];
+    const int x0 = (t % G.ftiles_x) * 64, y0 = (t / G.ftiles_x) * 16;
+    const int f = blockIdx.y, w = G.w, h = G.h, thr = g->fast_threshold;
+    int pitch;
+    const uint8_t *img = level_ptr(src, g, f, l, pitch);
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_n = 0; s_m = 0; }
+    for (int r = tid >> 6; r < 24; r += 4) {
+        const int y = y0 - 4 + r;
+        for (int c = tid & 63; c < 72; c += 64) {
+            const int x = x0 - 4 + c;
+            s_img[r][c] = (x >= 0 && y >= 0 && x < w && y < h) ? img[(uint64_t)y * pitch + x] : 0;
+        }
+    }
+    for (int i = tid; i < 18 * 68; i += 256) (&s_sc[0][0])[i] = 0;
+    __syncthreads();
+    // phase 1
+    for (int p = tid; p < 18 * 66; p += 256) {
+        const int r = p / 66, c = p - r * 66;
+        const int x = x0 - 1 + c, y = y0 - 1 + r;
+        if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3) continue;
+        const int cv = s_img[r + 3][c + 3], hi = cv + thr, lo = cv - thr;
+        uint32_t mb = 0, md = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int v = s_img[r + 3 + rdy[k]][c + 3 + rdx[k]];
+            mb |= (uint32_t)(v > hi) << k;
+            md |= (uint32_t)(v < lo) << k;
+        }
+        if (contig9(mb) || contig9(md)) s_list[atomicAdd(&s_n, 1)] = (uint16_t)p;
+    }
+    __syncthreads();
+    // phase 2
+    const int n = s_n;
+    for (int i = tid; i < n; i += 256) {
+        const int p = s_list[i], r = p / 66, c = p - r * 66;
+        const int cv = s_img[r + 3][c + 3];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = cv - (int)s_img[r + 3 + rdy[k]][c + 3 + rdx[k]];
+        int mn[16], mx[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+        int mn4[16], mx4[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
+        int best = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+            const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+            best = max(best, max(m9, -x9));
+        }
+        s_sc[r][c] = (uint8_t)(best > thr ? best : 0);
+    }
+    __syncthreads();
+    // phase 3
+    {
+        const int r = tid >> 4, c4 = (tid & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c4 + i, x = x0 + c, y = y0 + r;
+            const int s = s_sc[r + 1][c + 1];
+            if (s && x < w && y < h) {
+                const bool keep = s > s_sc[r][c] && s > s_sc[r][c + 1] && s > s_sc[r][c + 2] && s > s_sc[r + 1][c] &&
+                                  s > s_sc[r + 1][c + 2] && s > s_sc[r + 2][c] && s > s_sc[r + 2][c + 1] && s > s_sc[r + 2][c + 2];
+                if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - s) << 24) | (uint32_t)(y * w + x);
+            }
+        }
+    }
+    __syncthreads();
+    const int m = s_m;
+    if (m == 0) return;
+    if (tid == 0) s_base = atomicAdd(&cand_count[f * g->levels + l], m);
+    __syncthreads();
+    if (tid < m) {
+        const int pos = s_base + tid;
+        if (pos < G.cand_cap) cand[(uint64_t)f * g->cand_stride + G.cand_off + pos] = s_out[tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// D1 selection: per (frame, level) keep the `quota` smallest keys (= strongest corners, ties by raster
+// index), sort them, then apply the 19 px border filter of feature_detector.cpp:106-123 and the camera
+// validity mask (dropInvalidKeypoints, orb_extractor.cpp:221-237) with an ORDERED compaction.
+// Radix select (4 x 8 bits, LDS histogram) -> LDS bitonic sort of <= 4096 keys.  Deterministic:
+// the unordered candidate list only feeds order-insensitive steps.
+__global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t *__restrict__ cand, const int32_t *__restrict__ cand_count,
+                                                const uint8_t *__restrict__ valid_mask,
+                                                int16_t *__restrict__ det_x, int16_t *__restrict__ det_y, uint8_t *__restrict__ det_score,
+                                                int32_t *__restrict__ det_count) {
+    __shared__ uint32_t s_key[kMaxQuota];
+    __shared__ int s_hist[256];
+    __shared__ int s_cnt, s_digit, s_k, s_run;
+    __shared__ int s_scan[256];
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom &G = g->L[l];
+    const uint32_t *keys = cand + (uint64_t)f * g->cand_stride + G.cand_off;
+    const int n = min(cand_count[f * g->levels + l], G.cand_cap);
+    const int quota = G.quota;
+    uint32_t kth = 0xFFFFFFFFu;
+    if (n > quota && quota > 0) {
+        uint32_t prefix = 0, mask = 0;
+        if (tid == 0) s_k = quota;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            s_hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                const uint32_t k = keys[i];
+                if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int k = s_k, d = 0;
+                while (d < 255 && s_hist[d] < k) { k -= s_hist[d]; ++d; }
+                s_digit = d; s_k = k;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)s_digit << shift;
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        kth = prefix;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    if (quota > 0)
+        for (int i = tid; i < n; i += 256) {
+            const uint32_t k = keys[i];
+            if (k <= kth) { const int p = atomicAdd(&s_cnt, 1); if (p < kMaxQuota) s_key[p] = k; }
+        }
+    __syncthreads();
+    const int m = min(s_cnt, kMaxQuota);
+    int np2 = 1;
+    while (np2 < m) np2 <<= 1;
+    for (int i = m + tid; i < np2; i += 256) s_key[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = s_key[i], b = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // ordered compaction of the survivors of the border / validity filter
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    const int W0 = g->width, H0 = g->height;
+    for (int base = 0; base < m; base += 256) {
+        const int i = base + tid;
+        int x = 0, y = 0, sc = 0, ok = 0;
+        if (i < m) {
+            const uint32_t k = s_key[i];
+            const int idx = (int)(k & 0xFFFFFFu);
+            y = idx / G.w; x = idx - y * G.w; sc = 255 - (int)(k >> 24);
+            ok = x >= kPatchRadius && y >= kPatchRadius && x < G.w - kPatchRadius && y < G.h - kPatchRadius;
+            if (ok && valid_mask) {
+                const int mx = __float2int_rn(__fmul_rn((float)x, G.scale)), my = __float2int_rn(__fmul_rn((float)y, G.scale));
+                ok = mx >= 0 && my >= 0 && mx < W0 && my < H0 && valid_mask[(uint64_t)my * W0 + mx] != 0;
+            }
+        }
+        s_scan[tid] = ok;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int run = s_run;
+        if (ok) {
+            const uint64_t slot = (uint64_t)f * g->max_kpts + G.det_base + run + s_scan[tid] - 1;
+            det_x[slot] = (int16_t)x; det_y[slot] = (int16_t)y; det_score[slot] = (uint8_t)sc;
+        }
+        __syncthreads();
+        if (tid == 255) s_run = run + s_scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) det_count[f * g->levels + l] = s_run;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tracker features (orb_extractor.cpp:89-124): level lk_level, x = cvRound(pt.x/scale), margin 19,
+// camera validity at (pt.x, pt.y); survivors keep their input order.  One wave per frame.
+__global__ __launch_bounds__(64) void k_tracks(const PyrGeom *g, const float *__restrict__ track_xy, const int32_t *__restrict__ track_id,
+                                               const int32_t *__restrict__ n_tracks, const uint8_t *__restrict__ valid_mask,
+                                               int16_t *__restrict__ trk_x, int16_t *__restrict__ trk_y, float *__restrict__ trk_px,
+                                               float *__restrict__ trk_py, int32_t *__restrict__ trk_id, int32_t *__restrict__ trk_count) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = n_tracks ? min(n_tracks[f], g->max_tracks) : 0;
+    const LevelGeom &G = g->L[g->lk_level];
+    int run = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool ok = false; int x = 0, y = 0; float px = 0.f, py = 0.f;
+        if (i < n) {
+            px = track_xy[((uint64_t)f * g->max_tracks + i) * 2];
+            py = track_xy[((uint64_t)f * g->max_tracks + i) * 2 + 1];
+            x = __float2int_rn(__fdiv_rn(px, G.scale));
+            y = __float2int_rn(__fdiv_rn(py, G.scale));
+            ok = x >= kPatchRadius && y >= kPatchRadius && x < G.w - kPatchRadius && y < G.h - kPatchRadius;
+            if (ok && valid_mask) {
+                const int mx = __float2int_rn(px), my = __float2int_rn(py);
+                ok = mx >= 0 && my >= 0 && mx < g->width && my < g->height && valid_mask[(uint64_t)my * g->width + mx] != 0;
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+            const uint64_t slot = (uint64_t)f * g->max_tracks + run + __popcll(bal & ((1ull << lane) - 1ull));
+            trk_x[slot] = (int16_t)x; trk_y[slot] = (int16_t)y; trk_px[slot] = px; trk_py[slot] = py;
+            trk_id[slot] = track_id ? track_id[(uint64_t)f * g->max_tracks + i] : i;
+        }
+        run += __popcll(bal);
+    }
+    if (lane == 0) trk_count[f] = run;
+}
+
+// ------------------------------------------------------------------------------------------------
+// O1 + O2: one wavefront per keypoint.
+//   ic_angle (orb_extractor.cpp:245-275): integer moments over the radius-15 disc of the UNBLURRED
+//   level, 961 candidate offsets strided over the 64 lanes, DPP/shuffle reduction, cv::fastAtan2.
+//   descriptor (orb_extractor.cpp:284-352): lane j evaluates BRIEF tests j, j+64, j+128, j+192 on the
+//   BLURRED level; four 64-bit ballots are the 256 descriptor bits (test t -> word t/32, bit t%32).
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__device__ __forceinline__ float dev_fast_atan2(float y, float x) {   // cv::fastAtan2 (atan_f32), degrees
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__device__ __forceinline__ float dev_poly_cos(float v) {   // openvslam/trigonometric.h:17-24
+    const float c1 = 0.99940307f, c2 = -0.49558072f, c3 = 0.03679168f;
+    const float v2 = __fmul_rn(v, v);
+    return __fadd_rn(c1, __fmul_rn(v2, __fadd_rn(c2, __fmul_rn(c3, v2))));
+}
+__device__ __forceinline__ float dev_cos(float v) {        // openvslam/trigonometric.h:26-42
+    const float PI = 3.14159265358979f, PI_2 = PI / 2.0f, TWO_PI = 2.0f * PI, INV_TWO_PI = 1.0f / TWO_PI, THREE_PI_2 = 3.0f * PI_2;
+    v = __fsub_rn(v, __fmul_rn((float)(int)floorf(__fmul_rn(v, INV_TWO_PI)), TWO_PI));
+    v = (0.0f < v) ? v : -v;
+    if (v < PI_2) return dev_poly_cos(v);
+    else if (v < PI) return -dev_poly_cos(__fsub_rn(PI, v));
+    else if (v < THREE_PI_2) return -dev_poly_cos(__fsub_rn(v, PI));
+    else return dev_poly_cos(__fsub_rn(TWO_PI, v));
+}
+__device__ __forceinline__ float dev_sin(float v) { return dev_cos(__fsub_rn(3.14159265358979f / 2.0f, v)); }
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g,
+                                                  const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
+                                                  const int16_t *__restrict__ trk_x, const int16_t *__restrict__ trk_y, const float *__restrict__ trk_px,
+                                                  const float *__restrict__ trk_py, const int32_t *__restrict__ trk_id, const int32_t *__restrict__ trk_count,
+                                                  float *__restrict__ out_x, float *__restrict__ out_y, float *__restrict__ out_angle,
+                                                  int32_t *__restrict__ out_octave, uint32_t *__restrict__ out_desc, int32_t *__restrict__ out_track,
+                                                  int32_t *__restrict__ out_count) {
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int levels = g->levels;
+    // segment table of this frame: [tracks][level 0][level 1]...
+    const int nt = trk_count[f];
+    int level = -1, idx = slot, total = nt;
+    bool is_track = false;
+    if (slot < nt) is_track = true;
+    else idx = slot - nt;
+    for (int l = 0; l < levels; ++l) {
+        const int c = det_count[f * levels + l];
+        if (!is_track && level < 0) { if (idx < c) level = l; else idx -= c; }
+        total += c;
+    }
+    if (slot == 0 && lane == 0) out_count[f] = total;
+    if (slot >= total) return;
+    int x, y, oct, tid_out;
+    float ox, oy;
+    if (is_track) {
+        const uint64_t s = (uint64_t)f * g->max_tracks + slot;
+        x = trk_x[s]; y = trk_y[s]; ox = trk_px[s]; oy = trk_py[s]; oct = g->lk_level; tid_out = trk_id[s];
+    } else {
+        const uint64_t s = (uint64_t)f * g->max_kpts + g->L[level].det_base + idx;
+        x = det_x[s]; y = det_y[s]; oct = level; tid_out = -1;
+        ox = __fmul_rn((float)x, g->L[level].scale);     // orb_extractor.cpp:156
+        oy = __fmul_rn((float)y, g->L[level].scale);
+    }
+    int pitch;
+    const uint8_t *img = level_ptr(src, g, f, oct, pitch);
+    const uint8_t *ctr = img + (int64_t)y * pitch + x;
+    // O1: moments
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
+        if (abs(u) <= g->umax[abs(v)]) {
+            const int I = ctr[(int64_t)v * pitch + u];
+            m10 += u * I; m01 += v * I;
+        }
+    }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const float angle_deg = dev_fast_atan2((float)m01, (float)m10);
+    // O2: steered BRIEF on the blurred level
+    const float angle = (float)__ddiv_rn(__dmul_rn((double)angle_deg, M_PI), 180.0);
+    const float ca = dev_cos(angle), sa = dev_sin(angle);
+    const int bp = g->L[oct].pitch;
+    const uint8_t *bctr = blur_ptr(src, g, f, oct) + (int64_t)y * bp + x;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int8_t *p = c_pattern + (q * 64 + lane) * 4;
+        const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
+        const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa), __fmul_rn(y2, ca)));
+        const int c2 = __float2int_rn(__fsub_rn(__fmul_rn(x2, ca), __fmul_rn(y2, sa)));
+        bits[q] = __ballot(bctr[(int64_t)r1 * bp + c1] < bctr[(int64_t)r2 * bp + c2]);
+    }
+    const uint64_t o = (uint64_t)f * g->capacity + slot;
+    if (lane < 8) out_desc[o * 8 + lane] = (uint32_t)(bits[lane >> 1] >> ((lane & 1) * 32));
+    if (lane == 0) { out_x[o] = ox; out_y[o] = oy; out_angle[o] = angle_deg; out_octave[o] = oct; out_track[o] = tid_out; }
+}
+
+}  // namespace
+
+// =================================================================================================
+// host side of the extractor
+// =================================================================================================
+struct ms_orb {
+    ms_ctx *ctx = nullptr;
+    ms_orb_config cfg{};
+    PyrGeom geom{};
+    PyrGeom *d_geom = nullptr;
+    uint8_t *d_slab = nullptr;
+    uint32_t *d_cand = nullptr;
+    int32_t *d_cand_count = nullptr, *d_det_count = nullptr, *d_trk_count = nullptr;
+    int16_t *d_det_x = nullptr, *d_det_y = nullptr, *d_trk_x = nullptr, *d_trk_y = nullptr;
+    uint8_t *d_det_score = nullptr, *d_mask = nullptr;
+    float *d_trk_px = nullptr, *d_trk_py = nullptr, *d_track_xy = nullptr;
+    int32_t *d_trk_id = nullptr, *d_track_id = nullptr, *d_n_tracks = nullptr;
+    // outputs
+    float *d_x = nullptr, *d_y = nullptr, *d_angle = nullptr;
+    int32_t *d_octave = nullptr, *d_track = nullptr, *d_count = nullptr;
+    uint32_t *d_desc = nullptr;
+    // resize tables per level (device)
+    int16_t *d_xofs[MS_MAX_LEVELS] = {nullptr}, *d_xcoef[MS_MAX_LEVELS] = {nullptr};
+    int16_t *d_yofs[MS_MAX_LEVELS] = {nullptr}, *d_ycoef[MS_MAX_LEVELS] = {nullptr};
+    // state of the last call
+    FrameSrc last_src{};
+    int last_frames = 0;
+    bool lvl0_in_slab = false;
+    uint64_t lvl0_off = 0;
+    int lvl0_pitch = 0;
+};
+
+template <typename T>
+static int dev_calloc(ms_ctx *c, T **p, size_t n) {
+    MS_HIP(c, hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T) ? n * sizeof(T) : 1));
+    MS_HIP(c, hipMemsetAsync(*p, 0, n * sizeof(T) ? n * sizeof(T) : 1, c->stream));
+    return MS_OK;
+}
+#define MS_TRY(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
+
+extern "C" {
+
+int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
+    if (!ctx || !cfg || !out) return MS_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->levels < 1 || cfg->levels > MS_MAX_LEVELS || cfg->max_kpts < 1 || cfg->max_batch < 1 || cfg->max_tracks < 0 ||
+        cfg->lk_track_level < 0 || cfg->lk_track_level >= cfg->levels || cfg->fast_threshold < 1 || cfg->fast_threshold > 254 ||
+        !(cfg->scale_factor > 1.0f) || cfg->width > 32767 || cfg->height > 32767 ||
+        (int64_t)cfg->width * cfg->height >= (1 << 24))
+        return ms_fail(ctx, MS_ERR_INVALID, "ms_orb_create: unsupported configuration");
+    MS_HIP(ctx, hipSetDevice(ctx->device));
+    ms_orb *o = new ms_orb();
+    o->ctx = ctx;
+    o->cfg = *cfg;
+    PyrGeom &G = o->geom;
+    G.levels = cfg->levels; G.lk_level = cfg->lk_track_level; G.fast_threshold = cfg->fast_threshold;
+    G.max_kpts = cfg->max_kpts; G.max_tracks = cfg->max_tracks; G.capacity = cfg->max_kpts + cfg->max_tracks;
+    G.width = cfg->width; G.height = cfg->height;
+    int32_t w[MS_MAX_LEVELS], h[MS_MAX_LEVELS], quota[MS_MAX_LEVELS];
+    float sf[MS_MAX_LEVELS];
+    msgeo::level_sizes(cfg->levels, cfg->scale_factor, cfg->width, cfg->height, w, h);
+    msgeo::level_quotas(cfg->levels, cfg->scale_factor, cfg->max_kpts, quota);
+    msgeo::scale_factors(cfg->levels, cfg->scale_factor, sf);
+    msgeo::umax(G.umax);
+    uint64_t off = 0, coff = 0;
+    int det_base = 0, bt = 0, ft = 0;
+    for (int l = 0; l < cfg->levels; ++l) {
+        if (w[l] < 2 * kPatchRadius + 2 || h[l] < 2 * kPatchRadius + 2 || quota[l] > kMaxQuota) {
+            delete o;
+            return ms_fail(ctx, MS_ERR_INVALID, "ms_orb_create: level %d is %dx%d (min 40x40) / quota %d (max %d)", l, w[l], h[l], quota[l], kMaxQuota);
+        }
+        LevelGeom &L = G.L[l];
+        L.w = w[l]; L.h = h[l]; L.pitch = (int)ms_align_up(w[l], 64); L.quota = quota[l]; L.scale = sf[l];
+        L.det_base = det_base; det_base += quota[l];
+        L.img_off = off; off += (uint64_t)L.pitch * L.h;
+        L.blur_off = off; off += (uint64_t)L.pitch * L.h;
+        L.cand_cap = ((w[l] + 1) / 2) * ((h[l] + 1) / 2) + 256;   // strict 3x3 maxima: <= one per 2x2 block
+        L.cand_off = coff; coff += L.cand_cap;
+        L.btiles_x = ms_div_up(w[l], 128); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 16);
+        L.ftiles_x = ms_div_up(w[l], 64); L.ftile_base = ft; ft += L.ftiles_x * ms_div_up(h[l], 16);
+    }
+    G.btiles_total = bt; G.ftiles_total = ft;
+    G.slab_stride = ms_align_up(off, 256); G.cand_stride = coff;
+    o->lvl0_off = G.L[0].img_off; o->lvl0_pitch = G.L[0].pitch;
+    const size_t B = cfg->max_batch, cap = G.capacity;
+    int rc = MS_OK;
+    auto A = [&](int r) { if (rc == MS_OK) rc = r; };
+    A(dev_calloc(ctx, &o->d_geom, 1));
+    A(dev_calloc(ctx, &o->d_slab, B * G.slab_stride));
+    A(dev_calloc(ctx, &o->d_cand, B * G.cand_stride));
+    A(dev_calloc(ctx, &o->d_cand_count, B * MS_MAX_LEVELS));
+    A(dev_calloc(ctx, &o->d_det_count, B * MS_MAX_LEVELS));
+    A(dev_calloc(ctx, &o->d_trk_count, B));
+    A(dev_calloc(ctx, &o->d_det_x, B * cfg->max_kpts));
+    A(dev_calloc(ctx, &o->d_det_y, B * cfg->max_kpts));
+    A(dev_calloc(ctx, &o->d_det_score, B * cfg->max_kpts));
+    const size_t T = (size_t)std::max(cfg->max_tracks, 1);
+    A(dev_calloc(ctx, &o->d_trk_x, B * T)); A(dev_calloc(ctx, &o->d_trk_y, B * T));
+    A(dev_calloc(ctx, &o->d_trk_px, B * T)); A(dev_calloc(ctx, &o->d_trk_py, B * T));
+    A(dev_calloc(ctx, &o->d_trk_id, B * T)); A(dev_calloc(ctx, &o->d_track_xy, B * T * 2));
+    A(dev_calloc(ctx, &o->d_track_id, B * T)); A(dev_calloc(ctx, &o->d_n_tracks, B));
+    A(dev_calloc(ctx, &o->d_x, B * cap)); A(dev_calloc(ctx, &o->d_y, B * cap)); A(dev_calloc(ctx, &o->d_angle, B * cap));
+    A(dev_calloc(ctx, &o->d_octave, B * cap)); A(dev_calloc(ctx, &o->d_track, B * cap)); A(dev_calloc(ctx, &o->d_count, B));
+    A(dev_calloc(ctx, &o->d_desc, B * cap * 8));
+    if (rc == MS_OK && hipMemcpyAsync(o->d_geom, &o->geom, sizeof(PyrGeom), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
+    for (int l = 1; l < cfg->levels && rc == MS_OK; ++l) {
+        std::vector<int16_t> xo, xc, yo, yc;
+        msgeo::resize_tables(w[l - 1], w[l], true, xo, xc);
+        msgeo::resize_tables(h[l - 1], h[l], false, yo, yc);
+        auto up = [&](int16_t **d, const std::vector<int16_t> &v) {
+            if (rc != MS_OK) return;
+            if (hipMalloc(reinterpret_cast<void **>(d), v.size() * 2) != hipSuccess ||
+                hipMemcpy(*d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = MS_ERR_HIP;
+        };
+        up(&o->d_xofs[l], xo); up(&o->d_xcoef[l], xc); up(&o->d_yofs[l], yo); up(&o->d_ycoef[l], yc);
+    }
+    if (rc == MS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
+    if (rc != MS_OK) { ms_orb_destroy(o); return ms_fail(ctx, rc, "ms_orb_create: device allocation failed"); }
+    *out = o;
+    return MS_OK;
+}
+
+void ms_orb_destroy(ms_orb *o) {
+    if (!o) return;
+    (void)hipSetDevice(o->ctx->device);
+    (void)hipStreamSynchronize(o->ctx->stream);
+    void *ptrs[] = {o->d_geom, o->d_slab, o->d_cand, o->d_cand_count, o->d_det_count, o->d_trk_count, o->d_det_x, o->d_det_y,
+                    o->d_det_score, o->d_mask, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_track_xy,
+                    o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int l = 0; l < MS_MAX_LEVELS; ++l) {
+        if (o->d_xofs[l]) (void)hipFree(o->d_xofs[l]);
+        if (o->d_xcoef[l]) (void)hipFree(o->d_xcoef[l]);
+        if (o->d_yofs[l]) (void)hipFree(o->d_yofs[l]);
+        if (o->d_ycoef[l]) (void)hipFree(o->d_ycoef[l]);
+    }
+    delete o;
+}
+
+int ms_orb_capacity(const ms_orb *o) { return o ? o->geom.capacity : MS_ERR_INVALID; }
+
+int ms_orb_set_valid_mask(ms_orb *o, const uint8_t *mask) {
+    if (!o) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    if (!mask) { if (o->d_mask) { MS_HIP(c, hipFree(o->d_mask)); o->d_mask = nullptr; } return MS_OK; }
+    const size_t n = (size_t)o->cfg.width * o->cfg.height;
+    if (!o->d_mask) MS_HIP(c, hipMalloc(reinterpret_cast<void **>(&o->d_mask), n));
+    MS_HIP(c, hipMemcpy(o->d_mask, mask, n, hipMemcpyHostToDevice));
+    return MS_OK;
+}
+
+int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames, size_t frame_stride, size_t row_stride,
+                   const float *track_xy, const int32_t *track_id, const int32_t *n_tracks) {
+    if (!o || !images) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    const PyrGeom &G = o->geom;
+    if (n_frames < 1 || n_frames > o->cfg.max_batch) return ms_fail(c, MS_ERR_CAPACITY, "ms_orb_extract: n_frames %d outside [1,%d]", n_frames, o->cfg.max_batch);
+    if (row_stride < (size_t)G.width || frame_stride < row_stride * (size_t)(G.height - 1) + G.width)
+        return ms_fail(c, MS_ERR_INVALID, "ms_orb_extract: strides smaller than the frame");
+    MS_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    FrameSrc src{};
+    src.slab = o->d_slab;
+    const bool aligned = on_device && (reinterpret_cast<uintptr_t>(images) % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    if (aligned) {   // use the caller's frames in place as pyramid level 0 (image_pyramid.cpp:75 without the copy)
+        src.lvl0 = images; src.lvl0_frame_stride = frame_stride; src.lvl0_pitch = (int)row_stride;
+        o->lvl0_in_slab = false;
+    } else {
+        uint8_t *dst = o->d_slab + o->lvl0_off;
+        if (on_device) {
+            dim3 grid(ms_div_up(G.width, 256), G.height, n_frames);
+            hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, images, (uint64_t)frame_stride, (uint64_t)row_stride, o->d_slab,
+                               G.slab_stride, o->lvl0_off, G.width, G.height, o->lvl0_pitch);
+            MS_KERNEL_CHECK(c, "k_copy_level0");
+        } else {
+            for (int f = 0; f < n_frames; ++f)
+                MS_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * G.slab_stride, o->lvl0_pitch, images + (size_t)f * frame_stride, row_stride,
+                                           G.width, G.height, hipMemcpyHostToDevice, st));
+        }
+        src.lvl0 = dst; src.lvl0_frame_stride = G.slab_stride; src.lvl0_pitch = o->lvl0_pitch;
+        o->lvl0_in_slab = true;
+    }
+    const bool have_tracks = track_xy && n_tracks && o->cfg.max_tracks > 0;
+    if (have_tracks) {
+        const size_t T = o->cfg.max_tracks;
+        MS_HIP(c, hipMemcpyAsync(o->d_track_xy, track_xy, (size_t)n_frames * T * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+        MS_HIP(c, hipMemcpyAsync(o->d_n_tracks, n_tracks, (size_t)n_frames * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (track_id) MS_HIP(c, hipMemcpyAsync(o->d_track_id, track_id, (size_t)n_frames * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    MS_HIP(c, hipMemsetAsync(o->d_cand_count, 0, (size_t)n_frames * G.levels * sizeof(int32_t), st));
+    for (int l = 1; l < G.levels; ++l) {
+        dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4), n_frames);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, src, o->d_geom, l, o->d_xofs[l], o->d_xcoef[l], o->d_yofs[l], o->d_ycoef[l]);
+        MS_KERNEL_CHECK(c, "k_resize");
+    }
+    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->d_geom);
+    MS_KERNEL_CHECK(c, "k_blur");
+    hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count);
+    MS_KERNEL_CHECK(c, "k_fast");
+    hipLaunchKernelGGL(k_select, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
+                       o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+    MS_KERNEL_CHECK(c, "k_select");
+    hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
+                       (have_tracks && track_id) ? o->d_track_id : nullptr, have_tracks ? o->d_n_tracks : nullptr, o->d_mask,
+                       o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
+    MS_KERNEL_CHECK(c, "k_tracks");
+    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_det_x, o->d_det_y,
+                       o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
+                       o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count);
+    MS_KERNEL_CHECK(c, "k_describe");
+    o->last_src = src;
+    o->last_frames = n_frames;
+    return MS_OK;
+}
+
+int ms_orb_device_view(ms_orb *o, ms_keypoints *v) {
+    if (!o || !v) return MS_ERR_INVALID;
+    v->capacity = o->geom.capacity; v->count = o->d_count; v->x = o->d_x; v->y = o->d_y; v->angle = o->d_angle;
+    v->octave = o->d_octave; v->desc = o->d_desc; v->track_id = o->d_track;
+    return MS_OK;
+}
+
+int ms_orb_download(ms_orb *o, int frame, float *x, float *y, float *angle, int32_t *octave, uint32_t *desc, int32_t *track_id, int32_t *n) {
+    if (!o || !n) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    if (frame < 0 || frame >= o->last_frames) return ms_fail(c, MS_ERR_INVALID, "ms_orb_download: frame %d not in last batch", frame);
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    int32_t cnt = 0;
+    MS_HIP(c, hipMemcpy(&cnt, o->d_count + frame, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const size_t cap = o->geom.capacity, b = (size_t)frame * cap, k = (size_t)cnt;
+    if (x) MS_HIP(c, hipMemcpy(x, o->d_x + b, k * 4, hipMemcpyDeviceToHost));
+    if (y) MS_HIP(c, hipMemcpy(y, o->d_y + b, k * 4, hipMemcpyDeviceToHost));
+    if (angle) MS_HIP(c, hipMemcpy(angle, o->d_angle + b, k * 4, hipMemcpyDeviceToHost));
+    if (octave) MS_HIP(c, hipMemcpy(octave, o->d_octave + b, k * 4, hipMemcpyDeviceToHost));
+    if (desc) MS_HIP(c, hipMemcpy(desc, o->d_desc + b * 8, k * 32, hipMemcpyDeviceToHost));
+    if (track_id) MS_HIP(c, hipMemcpy(track_id, o->d_track + b, k * 4, hipMemcpyDeviceToHost));
+    *n = cnt;
+    return MS_OK;
+}
+
+int ms_orb_level_size(const ms_orb *o, int level, int32_t *w, int32_t *h) {
+    if (!o || level < 0 || level >= o->geom.levels || !w || !h) return MS_ERR_INVALID;
+    *w = o->geom.L[level].w; *h = o->geom.L[level].h;
+    return MS_OK;
+}
+
+int ms_orb_download_level(ms_orb *o, int frame, int level, int blurred, uint8_t *dst) {
+    if (!o || !dst) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    if (frame < 0 || frame >= o->last_frames || level < 0 || level >= o->geom.levels) return ms_fail(c, MS_ERR_INVALID, "ms_orb_download_level: bad frame/level");
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    const LevelGeom &L = o->geom.L[level];
+    const uint8_t *p; size_t pitch;
+    if (blurred) { p = o->d_slab + (size_t)frame * o->geom.slab_stride + L.blur_off; pitch = L.pitch; }
+    else if (level == 0) { p = o->last_src.lvl0 + (size_t)frame * o->last_src.lvl0_frame_stride; pitch = o->last_src.lvl0_pitch; }
+    else { p = o->d_slab + (size_t)frame * o->geom.slab_stride + L.img_off; pitch = L.pitch; }
+    MS_HIP(c, hipMemcpy2D(dst, L.w, p, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return MS_OK;
+}
+
+int ms_orb_download_detections(ms_orb *o, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int32_t *n) {
+    if (!o || !n) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    if (frame < 0 || frame >= o->last_frames || level < 0 || level >= o->geom.levels) return ms_fail(c, MS_ERR_INVALID, "ms_orb_download_detections: bad frame/level");
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    int32_t cnt = 0;
+    MS_HIP(c, hipMemcpy(&cnt, o->d_det_count + frame * o->geom.levels + level, 4, hipMemcpyDeviceToHost));
+    const size_t b = (size_t)frame * o->cfg.max_kpts + o->geom.L[level].det_base;
+    std::vector<int16_t> hx(cnt), hy(cnt); std::vector<uint8_t> hs(cnt);
+    if (cnt) {
+        MS_HIP(c, hipMemcpy(hx.data(), o->d_det_x + b, cnt * 2, hipMemcpyDeviceToHost));
+        MS_HIP(c, hipMemcpy(hy.data(), o->d_det_y + b, cnt * 2, hipMemcpyDeviceToHost));
+        MS_HIP(c, hipMemcpy(hs.data(), o->d_det_score + b, cnt, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < cnt; ++i) { if (x) x[i] = hx[i]; if (y) y[i] = hy[i]; if (score) score[i] = hs[i]; }
+    *n = cnt;
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+"""ctypes binding of libmi355slam.so (the MI355X hot path of AaltoML/SLAM-module).
+
+This is plumbing for tests and bench.py: every call goes straight through the C ABI declared in
+include/mi355slam.h.  There is no CPU fallback here and nothing in this package imports oracle/:
+if the HIP library is missing or no gfx950 device is usable, loading / Context() raises.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmi355slam.so")
+MAX_LEVELS = 16
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+class MsError(RuntimeError):
+    pass
+
+
+class OrbConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("levels", C.c_int32), ("scale_factor", C.c_float),
+                ("max_kpts", C.c_int32), ("lk_track_level", C.c_int32), ("fast_threshold", C.c_int32),
+                ("max_tracks", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class KeypointsView(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("count", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("angle", C.c_void_p), ("octave", C.c_void_p), ("desc", C.c_void_p), ("track_id", C.c_void_p)]
+
+
+class Bow(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("node_start", C.c_void_p), ("kp_idx", C.c_void_p)]
+
+
+class MatchFrame(C.Structure):
+    _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("angle", C.c_void_p), ("octave", C.c_void_p),
+                ("bearing", C.c_void_p), ("usable", C.c_void_p), ("bow", Bow)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library; raise loudly if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsError("libmi355slam.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ms_last_error.restype = C.c_char_p
+        _lib.ms_version.restype = C.c_char_p
+        _lib.ms_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _vp(x):
+    """device pointer / numpy array / None -> c_void_p"""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, DevBuf):
+        return C.c_void_p(x.ptr)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError(type(x))
+
+
+class Context:
+    def __init__(self, device=0):
+        self._children = []          # weakrefs to objects that must be destroyed before the context
+        self._h = C.c_void_p()
+        rc = lib().ms_ctx_create(device, C.byref(self._h))
+        if rc != 0:
+            raise MsError("ms_ctx_create(device=%d) failed with %d: no usable gfx950 device (there is no CPU fallback)" % (device, rc))
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            raise MsError("%s failed (%d): %s" % (what, rc, lib().ms_last_error(self._h).decode()))
+
+    def sync(self):
+        self.check(lib().ms_ctx_sync(self._h), "ms_ctx_sync")
+
+    def stream(self):
+        return lib().ms_ctx_stream(self._h)
+
+    def timer_start(self):
+        self.check(lib().ms_timer_start(self._h), "ms_timer_start")
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self.check(lib().ms_timer_stop_ms(self._h, C.byref(ms)), "ms_timer_stop_ms")
+        return ms.value
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = DevBuf(self, arr.nbytes)
+        b.shape, b.dtype = arr.shape, arr.dtype
+        self.check(lib().ms_dev_upload(self._h, C.c_void_p(b.ptr), _vp(arr), C.c_size_t(arr.nbytes)), "ms_dev_upload")
+        return b
+
+    def close(self):
+        if self._h:
+            for r in self._children:
+                o = r()
+                if o is not None:
+                    o.close()
+            self._children = []
+            lib().ms_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DevBuf:
+    """A device allocation owned through the C ABI (ms_dev_alloc / ms_dev_free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx.check(lib().ms_dev_alloc(ctx._h, C.c_size_t(self.nbytes), C.byref(p)), "ms_dev_alloc")
+        ctx._children.append(weakref.ref(self))
+        self.ptr = p.value or 0
+        self.shape, self.dtype = None, None
+
+    def download(self, dtype=None, shape=None):
+        dtype = np.dtype(dtype or self.dtype)
+        shape = shape if shape is not None else self.shape
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx.check(lib().ms_dev_download(self.ctx._h, _vp(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)), "ms_dev_download")
+        return out
+
+    def free(self):
+        if self.ptr and self.ctx._h:
+            lib().ms_dev_free(self.ctx._h, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    close = free
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- geometry (host-side tables of the product) ----
+def scale_factors(levels, f):
+    out = np.zeros(levels, np.float32)
+    assert lib().ms_scale_factors(levels, C.c_float(f), out.ctypes.data_as(f32p)) == 0
+    return out
+
+
+def level_sigma_sq(levels, f):
+    out = np.zeros(levels, np.float32)
+    assert lib().ms_level_sigma_sq(levels, C.c_float(f), out.ctypes.data_as(f32p)) == 0
+    return out
+
+
+def level_quotas(levels, f, max_kpts):
+    out = np.zeros(levels, np.int32)
+    assert lib().ms_level_quotas(levels, C.c_float(f), max_kpts, out.ctypes.data_as(i32p)) == 0
+    return out
+
+
+def level_sizes(levels, f, w, h):
+    ws, hs = np.zeros(levels, np.int32), np.zeros(levels, np.int32)
+    assert lib().ms_level_sizes(levels, C.c_float(f), w, h, ws.ctypes.data_as(i32p), hs.ctypes.data_as(i32p)) == 0
+    return ws, hs
+
+
+class OrbExtractor:
+    """Mirror of slam::OrbExtractor (orb_extractor.hpp:11-30) over the C ABI, batched."""
+
+    def __init__(self, ctx, width, height, levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0,
+                 fast_threshold=20, max_tracks=0, max_batch=1):
+        self.ctx = ctx
+        self.cfg = OrbConfig(width, height, levels, scale_factor, max_kpts, lk_track_level, fast_threshold, max_tracks, max_batch)
+        self._h = C.c_void_p()
+        ctx.check(lib().ms_orb_create(ctx._h, C.byref(self.cfg), C.byref(self._h)), "ms_orb_create")
+        ctx._children.append(weakref.ref(self))
+        self.capacity = lib().ms_orb_capacity(self._h)
+
+    def set_valid_mask(self, mask):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.ctx.check(lib().ms_orb_set_valid_mask(self._h, _vp(m)), "ms_orb_set_valid_mask")
+
+    def extract(self, images, n_frames=None, frame_stride=None, row_stride=None, track_xy=None, track_id=None, n_tracks=None):
+        """images: numpy uint8 [n,h,w] / [h,w] (host) or a device pointer (int / DevBuf) with explicit strides."""
+        on_device = 0
+        if isinstance(images, np.ndarray):
+            images = np.ascontiguousarray(images, np.uint8)
+            if images.ndim == 2:
+                images = images[None]
+            n_frames = images.shape[0]
+            row_stride = images.shape[2]
+            frame_stride = images.shape[1] * images.shape[2]
+            self._keep = images
+        else:
+            on_device = 1
+            row_stride = row_stride or self.cfg.width
+            frame_stride = frame_stride or row_stride * self.cfg.height
+        txy = tid = nt = None
+        if track_xy is not None:
+            T = self.cfg.max_tracks
+            txy = np.zeros((n_frames, T, 2), np.float32)
+            tid = np.zeros((n_frames, T), np.int32)
+            nt = np.zeros(n_frames, np.int32)
+            for f in range(n_frames):
+                k = len(track_xy[f])
+                assert k <= T
+                nt[f] = k
+                if k:
+                    txy[f, :k] = np.asarray(track_xy[f], np.float32).reshape(k, 2)
+                    tid[f, :k] = np.asarray(track_id[f], np.int32) if track_id is not None else np.arange(k)
+        self.ctx.check(lib().ms_orb_extract(self._h, _vp(images), on_device, n_frames, C.c_size_t(frame_stride),
+                                            C.c_size_t(row_stride), _vp(txy), _vp(tid), _vp(nt)), "ms_orb_extract")
+        self.n_frames = n_frames
+
+    def device_view(self):
+        v = KeypointsView()
+        self.ctx.check(lib().ms_orb_device_view(self._h, C.byref(v)), "ms_orb_device_view")
+        return v
+
+    def download(self, frame):
+        cap = self.capacity
+        out = dict(x=np.zeros(cap, np.float32), y=np.zeros(cap, np.float32), angle=np.zeros(cap, np.float32),
+                   octave=np.zeros(cap, np.int32), desc=np.zeros((cap, 8), np.uint32), track_id=np.zeros(cap, np.int32))
+        n = C.c_int32()
+        self.ctx.check(lib().ms_orb_download(self._h, frame, _vp(out["x"]), _vp(out["y"]), _vp(out["angle"]), _vp(out["octave"]),
+                                             _vp(out["desc"]), _vp(out["track_id"]), C.byref(n)), "ms_orb_download")
+        return {k: v[:n.value].copy() for k, v in out.items()}
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        self.ctx.check(lib().ms_orb_level_size(self._h, level, C.byref(w), C.byref(h)), "ms_orb_level_size")
+        return w.value, h.value
+
+    def download_level(self, frame, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self.ctx.check(lib().ms_orb_download_level(self._h, frame, level, int(blurred), _vp(out)), "ms_orb_download_level")
+        return out
+
+    def download_detections(self, frame, level):
+        q = self.cfg.max_kpts
+        x, y, s = np.zeros(q, np.int32), np.zeros(q, np.int32), np.zeros(q, np.int32)
+        n = C.c_int32()
+        self.ctx.check(lib().ms_orb_download_detections(self._h, frame, level, _vp(x), _vp(y), _vp(s), C.byref(n)), "ms_orb_download_detections")
+        return x[:n.value].copy(), y[:n.value].copy(), s[:n.value].copy()
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib().ms_orb_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- matching ----
+def hamming_best2(ctx, q, t, n_pairs=1, q_bucket=None, t_bucket=None, t_valid=None):
+    """q: [n_pairs*nq, 8] uint32 (numpy, uploaded) -> (best_idx, best_dist, second_dist) numpy arrays."""
+    q = np.ascontiguousarray(q, np.uint32).reshape(-1, 8)
+    t = np.ascontiguousarray(t, np.uint32).reshape(-1, 8)
+    nq, nt = len(q) // n_pairs, len(t) // n_pairs
+    dq, dt = ctx.upload(q), ctx.upload(t)
+    dqb = ctx.upload(np.asarray(q_bucket, np.int32)) if q_bucket is not None else None
+    dtb = ctx.upload(np.asarray(t_bucket, np.int32)) if t_bucket is not None else None
+    dtv = ctx.upload(np.asarray(t_valid, np.uint8)) if t_valid is not None else None
+    bi, bd, sd = ctx.alloc(4 * nq * n_pairs + 4), ctx.alloc(2 * nq * n_pairs + 4), ctx.alloc(2 * nq * n_pairs + 4)
+    ctx.check(lib().ms_hamming_best2(ctx._h, _vp(dq), nq, _vp(dt), nt, n_pairs, _vp(dqb), _vp(dtb), _vp(dtv), _vp(bi), _vp(bd), _vp(sd)),
+              "ms_hamming_best2")
+    ctx.sync()
+    return (bi.download(np.int32, (nq * n_pairs,)), bd.download(np.uint16, (nq * n_pairs,)), sd.download(np.uint16, (nq * n_pairs,)))
+
+
+def ratio_test(ctx, best_idx, best_dist, second_dist, lowe_ratio, max_dist=50):
+    n = len(best_idx)
+    a, b, c = ctx.upload(np.asarray(best_idx, np.int32)), ctx.upload(np.asarray(best_dist, np.uint16)), ctx.upload(np.asarray(second_dist, np.uint16))
+    m = ctx.alloc(4 * n + 4)
+    ctx.check(lib().ms_ratio_test(ctx._h, _vp(a), _vp(b), _vp(c), n, C.c_float(lowe_ratio), max_dist, _vp(m)), "ms_ratio_test")
+    ctx.sync()
+    return m.download(np.int32, (n,))
+
+
+class FrameOnDevice:
+    """Uploads one keyframe's matcher inputs and builds the ms_match_frame struct."""
+
+    def __init__(self, ctx, desc, angle, usable, bucket, octave=None, bearing=None):
+        bucket = np.asarray(bucket, np.int32)
+        order = np.argsort(bucket, kind="stable").astype(np.int32)
+        ids, counts = np.unique(bucket, return_counts=True)
+        start = np.zeros(len(ids) + 1, np.int32)
+        start[1:] = np.cumsum(counts)
+        self.n = len(bucket)
+        self.bufs = dict(desc=ctx.upload(np.asarray(desc, np.uint32).reshape(-1, 8)), angle=ctx.upload(np.asarray(angle, np.float32)),
+                         usable=ctx.upload(np.asarray(usable, np.uint8)), node_id=ctx.upload(ids.astype(np.int32)),
+                         node_start=ctx.upload(start), kp_idx=ctx.upload(order))
+        if octave is not None:
+            self.bufs["octave"] = ctx.upload(np.asarray(octave, np.int32))
+        if bearing is not None:
+            self.bufs["bearing"] = ctx.upload(np.asarray(bearing, np.float64).reshape(-1, 3))
+        b = self.bufs
+        self.struct = MatchFrame(self.n, b["desc"].ptr, b["angle"].ptr, b["octave"].ptr if "octave" in b else 0,
+                                 b["bearing"].ptr if "bearing" in b else 0, b["usable"].ptr,
+                                 Bow(len(ids), b["node_id"].ptr, b["node_start"].ptr, b["kp_idx"].ptr))
+
+
+def _run_greedy(ctx, frames1, frames2, call):
+    n = len(frames1)
+    A1 = (MatchFrame * n)(*[f.struct for f in frames1])
+    A2 = (MatchFrame * n)(*[f.struct for f in frames2])
+    outs = [ctx.alloc(4 * max(f.n, 1)) for f in frames1]
+    ptrs = (C.c_void_p * n)(*[o.ptr for o in outs])
+    nm = ctx.alloc(4 * n)
+    call(A1, A2, n, ptrs, nm)
+    ctx.sync()
+    counts = nm.download(np.int32, (n,))
+    return counts, [o.download(np.int32, (f.n,)) for o, f in zip(outs, frames1)]
+
+
+def match_loop_closure(ctx, frames1, frames2, lowe_ratio, check_orientation=True):
+    def call(A1, A2, n, ptrs, nm):
+        ctx.check(lib().ms_match_loop_closure(ctx._h, A1, A2, n, C.c_float(lowe_ratio), int(check_orientation), ptrs, _vp(nm)),
+                  "ms_match_loop_closure")
+    return _run_greedy(ctx, frames1, frames2, call)
+
+
+def match_triangulation(ctx, frames1, frames2, E12, scale_factors_, thr_deg, check_orientation=True):
+    dE = ctx.upload(np.asarray(E12, np.float64).reshape(-1, 9))
+    dsf = ctx.upload(np.asarray(scale_factors_, np.float32))
+
+    def call(A1, A2, n, ptrs, nm):
+        ctx.check(lib().ms_match_triangulation(ctx._h, A1, A2, n, _vp(dE), _vp(dsf), C.c_float(thr_deg), int(check_orientation), ptrs, _vp(nm)),
+                  "ms_match_triangulation")
+    return _run_greedy(ctx, frames1, frames2, call)

@@ -1,0 +1,142 @@
+"""GPU parity: pyramid, detector, orientation and descriptors through the C ABI vs the CPU oracle.
+
+Bar: bit-exact pixels, keypoint coordinates/order, angles (float32 bit patterns) and descriptor bits.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(oracle, **kw):
+    d = dict(levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0, fast_threshold=20)
+    d.update(kw)
+    return oracle.cfg(**d), d
+
+
+def _extract_both(oracle, ctx, imgs, mask=None, tracks=None, track_ids=None, max_tracks=0, **kw):
+    import mi355slam
+    ocfg, d = _cfg(oracle, **kw)
+    n, h, w = imgs.shape
+    ex = mi355slam.OrbExtractor(ctx, w, h, levels=d["levels"], scale_factor=d["scale_factor"], max_kpts=d["max_kpts"],
+                                lk_track_level=d["lk_track_level"], fast_threshold=d["fast_threshold"],
+                                max_tracks=max_tracks, max_batch=n)
+    if mask is not None:
+        ex.set_valid_mask(mask)
+    ex.extract(imgs, track_xy=tracks, track_id=track_ids)
+    got = [ex.download(f) for f in range(n)]
+    want = [oracle.orb_extract(ocfg, imgs[f], valid_mask=mask,
+                               track_xy=None if tracks is None else np.asarray(tracks[f], np.float32).reshape(-1, 2),
+                               track_id=None if track_ids is None else track_ids[f]) for f in range(n)]
+    return ex, got, want
+
+
+def _assert_same_keypoints(got, want):
+    assert len(got["x"]) == len(want["x"])
+    for k in ("x", "y", "angle"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k      # float32 bit patterns
+    assert np.array_equal(got["octave"], want["octave"])
+    assert np.array_equal(got["track_id"], want["track_id"])
+    assert np.array_equal(got["desc"], want["desc"])
+
+
+def test_pyramid_pixels_bit_exact(oracle, ctx):
+    img = oracle.synth_frame(640, 480, 1000)
+    ex, got, want = _extract_both(oracle, ctx, img[None])
+    ocfg, _ = _cfg(oracle)
+    levels, blurs = oracle.build_pyramid(ocfg, img)
+    for l in range(8):
+        assert ex.level_size(l) == (levels[l].shape[1], levels[l].shape[0])
+        assert np.array_equal(ex.download_level(0, l, False), levels[l]), "level %d" % l
+        assert np.array_equal(ex.download_level(0, l, True), blurs[l]), "blurred level %d" % l
+
+
+def test_detections_match_oracle_per_level(oracle, ctx):
+    img = oracle.synth_frame(640, 480, 1001)
+    ex, _, _ = _extract_both(oracle, ctx, img[None])
+    ocfg, _ = _cfg(oracle)
+    levels, _ = oracle.build_pyramid(ocfg, img)
+    quotas = oracle.level_quotas(8, 1.2, 2000)
+    for l in range(8):
+        xs, ys, sc = oracle.detect_level(levels[l], 20, int(quotas[l]))
+        gx, gy, gs = ex.download_detections(0, l)
+        assert np.array_equal(gx, xs) and np.array_equal(gy, ys) and np.array_equal(gs, sc), "level %d" % l
+
+
+def test_c1_vga_frame_bit_exact(oracle, ctx):
+    """BASELINE config C1: one 640x480 synthetic frame, 8 levels, 2000 keypoints."""
+    img = oracle.synth_frame(640, 480, 1000)
+    _, got, want = _extract_both(oracle, ctx, img[None])
+    assert len(want[0]["x"]) > 1000
+    _assert_same_keypoints(got[0], want[0])
+
+
+def test_720p_batch_bit_exact(oracle, ctx):
+    imgs = np.stack([oracle.synth_frame(1280, 720, 1000 + i, 2 * i, i) for i in range(3)])
+    _, got, want = _extract_both(oracle, ctx, imgs)
+    for f in range(3):
+        _assert_same_keypoints(got[f], want[f])
+    assert not np.array_equal(got[0]["desc"][:100], got[1]["desc"][:100])
+
+
+def test_pure_ramp_gives_no_keypoints(oracle, ctx):
+    """A pure gradient has no corners: the early return of orb_extractor.cpp:137."""
+    y, x = np.mgrid[0:480, 0:640]
+    img = ((x * 96) // 639 + (y * 64) // 479).astype(np.uint8)
+    _, got, want = _extract_both(oracle, ctx, img[None])
+    assert len(want[0]["x"]) == 0 and len(got[0]["x"]) == 0
+
+
+def test_random_noise_saturates_quota(oracle, ctx):
+    """Noise floods every level with corners: exercises the radix select / quota cut and score ties."""
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (300, 400), dtype=np.uint8)
+    _, got, want = _extract_both(oracle, ctx, img[None], levels=4, max_kpts=1500)
+    _assert_same_keypoints(got[0], want[0])
+
+
+def test_odd_sizes_and_thresholds(oracle, ctx):
+    for (w, h, thr, levels, sf) in [(331, 257, 10, 5, 1.2), (200, 120, 35, 3, 1.5), (97, 83, 20, 2, 1.1)]:
+        img = oracle.synth_frame(w, h, 5 + w)
+        _, got, want = _extract_both(oracle, ctx, img[None], levels=levels, scale_factor=sf, fast_threshold=thr, max_kpts=700)
+        _assert_same_keypoints(got[0], want[0])
+
+
+def test_tracks_and_valid_mask(oracle, ctx):
+    rng = np.random.default_rng(3)
+    img = oracle.synth_frame(640, 480, 1002)
+    mask = np.ones((480, 640), np.uint8)
+    mask[:, :60] = 0
+    mask[400:, :] = 0
+    tracks = [np.stack([rng.uniform(-5, 645, 150), rng.uniform(-5, 485, 150)], 1).astype(np.float32)]
+    ids = [np.arange(1000, 1150, dtype=np.int32)]
+    for lk in (0, 2):
+        _, got, want = _extract_both(oracle, ctx, img[None], mask=mask, tracks=tracks, track_ids=ids, max_tracks=200, lk_track_level=lk)
+        assert (want[0]["track_id"] >= 0).sum() > 50
+        _assert_same_keypoints(got[0], want[0])
+
+
+def test_unaligned_device_input_is_copied(oracle, ctx):
+    """Device frames with an odd stride cannot be used in place; the device-side copy path must agree."""
+    import mi355slam
+    img = oracle.synth_frame(333, 222, 77)
+    padded = np.zeros((222, 341), np.uint8)
+    padded[:, :333] = img
+    buf = ctx.upload(padded)
+    ex = mi355slam.OrbExtractor(ctx, 333, 222, levels=4, max_kpts=500)
+    ex.extract(buf, n_frames=1, frame_stride=padded.size, row_stride=341)
+    got = ex.download(0)
+    want = oracle.orb_extract(oracle.cfg(levels=4, max_kpts=500), img)
+    _assert_same_keypoints(got, want)
+
+
+def test_extract_is_deterministic_across_runs(oracle, ctx):
+    import mi355slam
+    imgs = np.stack([oracle.synth_frame(640, 480, 2000 + i) for i in range(4)])
+    ex = mi355slam.OrbExtractor(ctx, 640, 480, max_batch=4)
+    ex.extract(imgs)
+    a = [ex.download(f) for f in range(4)]
+    ex.extract(imgs)
+    b = [ex.download(f) for f in range(4)]
+    for f in range(4):
+        _assert_same_keypoints(a[f], b[f])

@@ -1,0 +1,133 @@
+"""GPU parity: Hamming search and the greedy BoW matchers through the C ABI vs the CPU oracle (bit-exact indices)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(seed, nq=2000, nt=2000, inliers=1400, flip=0.08):
+    """SURVEY 8d C3 generator: targets = permuted noisy copies of queries + random outliers."""
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32)
+    perm = rng.permutation(nq)[:inliers]
+    noise = np.packbits(rng.random((inliers, 256)) < flip, axis=1, bitorder="little").view(np.uint32)
+    t = np.concatenate([q[perm] ^ noise, rng.integers(0, 2**32, (nt - inliers, 8), dtype=np.uint64).astype(np.uint32)])
+    t = t[rng.permutation(nt)]
+    return q, t
+
+
+def test_hamming_best2_c3_pairs(oracle, ctx):
+    import mi355slam
+    pairs = [make_pair(s) for s in range(4)]
+    q = np.concatenate([p[0] for p in pairs]); t = np.concatenate([p[1] for p in pairs])
+    bi, bd, sd = mi355slam.hamming_best2(ctx, q, t, n_pairs=4)
+    for p in range(4):
+        wi, wd, ws = oracle.hamming_best2(pairs[p][0], pairs[p][1])
+        sl = slice(p * 2000, (p + 1) * 2000)
+        assert np.array_equal(bi[sl], wi) and np.array_equal(bd[sl], wd) and np.array_equal(sd[sl], ws)
+    assert (bd < 50).mean() > 0.6
+
+
+def test_hamming_ties_lowest_index_and_ragged(oracle, ctx):
+    import mi355slam
+    rng = np.random.default_rng(1)
+    for nq, nt in [(1, 1), (3, 700), (257, 255), (513, 1025), (64, 0)]:
+        q = rng.integers(0, 4, (nq, 8)).astype(np.uint32)        # few distinct values -> many exact ties
+        t = rng.integers(0, 4, (nt, 8)).astype(np.uint32)
+        bi, bd, sd = mi355slam.hamming_best2(ctx, q, t)
+        wi, wd, ws = oracle.hamming_best2(q, t)
+        assert np.array_equal(bi, wi) and np.array_equal(bd, wd) and np.array_equal(sd, ws)
+        if nt == 0:
+            assert (bi == -1).all() and (bd == 256).all()
+
+
+def test_hamming_masks(oracle, ctx):
+    import mi355slam
+    rng = np.random.default_rng(2)
+    q, t = make_pair(11, 600, 900, 400)
+    qb = rng.integers(0, 20, 600).astype(np.int32); tb = rng.integers(0, 20, 900).astype(np.int32)
+    tv = (rng.random(900) < 0.7).astype(np.uint8)
+    for kw in (dict(q_bucket=qb, t_bucket=tb), dict(t_valid=tv), dict(q_bucket=qb, t_bucket=tb, t_valid=tv)):
+        bi, bd, sd = mi355slam.hamming_best2(ctx, q, t, **kw)
+        wi, wd, ws = oracle.hamming_best2(q, t, **kw)
+        assert np.array_equal(bi, wi) and np.array_equal(bd, wd) and np.array_equal(sd, ws)
+
+
+def test_ratio_test_rule(oracle, ctx):
+    import mi355slam
+    q, t = make_pair(5)
+    bi, bd, sd = mi355slam.hamming_best2(ctx, q, t)
+    for ratio in (0.75, 0.9, 1.0):
+        m = mi355slam.ratio_test(ctx, bi, bd, sd, ratio)
+        want = np.where((bd <= 50) & ~(np.float32(ratio) * sd.astype(np.float32) < bd.astype(np.float32)), bi, -1)
+        assert np.array_equal(m, want)
+
+
+def _frames(seed, n1=2000, n2=2000, buckets=100):
+    """Two keyframes whose true correspondences share a vocabulary node (as DBoW2 would give) most of the time."""
+    rng = np.random.default_rng(seed)
+    inl = int(0.7 * min(n1, n2))
+    q = rng.integers(0, 2**32, (n1, 8), dtype=np.uint64).astype(np.uint32)
+    b1 = rng.integers(0, buckets, n1).astype(np.int32)
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    src = rng.permutation(n1)[:inl]
+    noise = np.packbits(rng.random((inl, 256)) < 0.06, axis=1, bitorder="little").view(np.uint32)
+    t = np.concatenate([q[src] ^ noise, rng.integers(0, 2**32, (n2 - inl, 8), dtype=np.uint64).astype(np.uint32)])
+    b2 = np.concatenate([np.where(rng.random(inl) < 0.9, b1[src], rng.integers(0, buckets, inl)), rng.integers(0, buckets, n2 - inl)]).astype(np.int32)
+    a2 = np.concatenate([(a1[src] + 40 + rng.normal(0, 6, inl)) % 360, rng.uniform(0, 360, n2 - inl)]).astype(np.float32)
+    sh = rng.permutation(n2)
+    t, b2, a2 = t[sh], b2[sh], a2[sh]
+    u1 = (rng.random(n1) < 0.8).astype(np.uint8); u2 = (rng.random(n2) < 0.8).astype(np.uint8)
+    return q, t, b1, b2, a1, a2, u1, u2
+
+
+def test_match_loop_closure_exact_greedy(oracle, ctx):
+    import mi355slam
+    f1s, f2s, wants = [], [], []
+    for seed, (n1, n2, nb) in enumerate([(2000, 2000, 100), (500, 1500, 7), (300, 200, 1), (50, 60, 400)]):
+        q, t, b1, b2, a1, a2, u1, u2 = _frames(100 + seed, n1, n2, nb)
+        # low-entropy descriptors in one case to force ties and contention for the same target
+        if seed == 2:
+            q &= 0x3; t &= 0x3
+        f1s.append(mi355slam.FrameOnDevice(ctx, q, a1, u1, b1)); f2s.append(mi355slam.FrameOnDevice(ctx, t, a2, u2, b2))
+        wants.append(oracle.match_loop_closure(q, a1, u1, b1, t, a2, u2, b2, 0.75, True))
+    counts, matched = mi355slam.match_loop_closure(ctx, f1s, f2s, 0.75, True)
+    for i, (wn, wm) in enumerate(wants):
+        assert counts[i] == wn and np.array_equal(matched[i], wm), i
+    assert wants[0][0] > 100
+    # orientation check off
+    counts, matched = mi355slam.match_loop_closure(ctx, f1s[:1], f2s[:1], 0.9, False)
+    q, t, b1, b2, a1, a2, u1, u2 = _frames(100, 2000, 2000, 100)
+    wn, wm = oracle.match_loop_closure(q, a1, u1, b1, t, a2, u2, b2, 0.9, False)
+    assert counts[0] == wn and np.array_equal(matched[0], wm)
+
+
+def _rot(rng):
+    a = rng.normal(size=3) * 0.1
+    th = np.linalg.norm(a); k = a / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def test_match_triangulation_exact_greedy(oracle, ctx):
+    import mi355slam
+    rng = np.random.default_rng(9)
+    sf = oracle.scale_factors(8, 1.2)
+    f1s, f2s, wants, Es = [], [], [], []
+    for seed, (n1, n2, nb) in enumerate([(1500, 1600, 100), (400, 300, 5)]):
+        q, t, b1, b2, a1, a2, u1, u2 = _frames(300 + seed, n1, n2, nb)
+        R1, R2 = _rot(rng), _rot(rng); t1, t2 = rng.normal(size=3), rng.normal(size=3)
+        # bearings: 3-D points seen from both cameras so that many pairs satisfy the epipolar gate
+        X = rng.uniform(-3, 3, (max(n1, n2), 3)) + np.array([0, 0, 8.0])
+        be1 = (R1 @ X[:n1].T).T + t1; be1 /= np.linalg.norm(be1, axis=1, keepdims=True)
+        idx = rng.integers(0, n1, n2)
+        be2 = (R2 @ X[idx].T).T + t2; be2 /= np.linalg.norm(be2, axis=1, keepdims=True)
+        o1 = rng.integers(0, 8, n1).astype(np.int32)
+        E = oracle.create_E21(R2, t2, R1, t1)            # call order of keyframe_matcher.cpp:171-175
+        f1s.append(mi355slam.FrameOnDevice(ctx, q, a1, u1, b1, octave=o1, bearing=be1))
+        f2s.append(mi355slam.FrameOnDevice(ctx, t, a2, u2, b2, bearing=be2))
+        Es.append(E)
+        wants.append(oracle.match_triangulation(q, a1, o1, be1, u1, b1, t, a2, be2, u2, b2, E, sf, 2.0, True))
+    counts, matched = mi355slam.match_triangulation(ctx, f1s, f2s, np.stack(Es), sf, 2.0, True)
+    for i, (wn, wm) in enumerate(wants):
+        assert counts[i] == wn and np.array_equal(matched[i], wm), i
