@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract + match throughput on synthetic 720p frames (BASELINE.json config C2 + C3 policy).
+
+One "step" = one pass of the hot path over one batch of 256 synthetic 1280x720 frames that are already
+resident in HBM: pyramid (8 levels x1.2) -> FAST -> top-2000 selection -> orientation -> 256-bit steered
+BRIEF, then brute-force Hamming best/second-best + ratio test of every frame's descriptors against the
+previous frame's (256 pairs, up to 2000x2000 each).  Multi-GPU: one process per GPU, every rank runs its
+own batch (independent sequences, no data-path collective); RCCL is used only to agree on the timing.
+
+Prints ONE JSON line (see the contract in the task statement).  `roofline` is computed for the dominant
+kernel from HIP-event durations taken inside the timed region; `cpu_baseline` times the CPU oracle (port of
+the reference algorithm, test infrastructure) on a bounded sample of the same workload on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "slam-module_amd"))
+
+W, H, LEVELS, SCALE, MAX_KPTS, FAST_THR, BATCH = 1280, 720, 8, 1.2, 2000, 20, 256
+LOWE_RATIO = 0.75
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_batch(n, base_seed):
+    """8 sequences of n/8 frames: frame i = synth(seed, shift=(2k, k)) so consecutive frames really match."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mso                                  # generator only (integer synthetic frames)
+    import numpy as np
+    per = max(n // 8, 1)
+    return np.stack([mso.synth_frame(W, H, base_seed + i // per, 2 * (i % per), i % per) for i in range(n)])
+
+
+def cpu_baseline(frames, n_sample):
+    """CPU oracle (port) on the first n_sample frames: extract each + match against the previous one; 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mso
+    cfg = mso.cfg(levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR)
+    t0 = time.perf_counter()
+    prev = None
+    for f in range(n_sample):
+        kp = mso.orb_extract(cfg, frames[f])
+        if prev is not None:
+            mso.hamming_best2(kp["desc"], prev["desc"])
+        else:
+            mso.hamming_best2(kp["desc"], kp["desc"])
+        prev = kp
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d synthetic 720p frames (extract + 2000x2000 Hamming best2), oracle/libmso.so, 1 thread" % (n_sample, BATCH)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch                                   # plumbing: device memory for the inputs + torch.distributed
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import mi355slam                                # after torch: both must share one HIP runtime
+
+    ctx = mi355slam.Context(local_rank)
+    frames_np = synth_batch(BATCH, 1000 + 8 * rank)
+    frames = torch.from_numpy(frames_np).cuda()     # inputs resident in HBM before the timed region
+    ex = mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=BATCH)
+    ex.set_profiling(True)
+    cap = ex.capacity
+    view = None
+    pair_q = torch.arange(BATCH, dtype=torch.int32, device="cuda")
+    pair_t = torch.roll(pair_q, 1)                  # frame f against frame f-1 (frame 0 against the last one)
+    best_idx = torch.empty(BATCH * cap, dtype=torch.int32, device="cuda")
+    best_dist = torch.empty(BATCH * cap, dtype=torch.int16, device="cuda")
+    second_dist = torch.empty(BATCH * cap, dtype=torch.int16, device="cuda")
+    match = torch.empty(BATCH * cap, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step(profile_match=False):
+        nonlocal view
+        ex.extract(frames.data_ptr(), n_frames=BATCH, frame_stride=W * H, row_stride=W)
+        if view is None:
+            view = ex.device_view()
+        if profile_match:
+            ctx.event_mark(0)
+        mi355slam.hamming_best2_sets(ctx, view.desc, cap, view.count, view.desc, cap, view.count, pair_q.data_ptr(), pair_t.data_ptr(),
+                                     BATCH, best_idx.data_ptr(), best_dist.data_ptr(), second_dist.data_ptr())
+        if profile_match:
+            ctx.event_mark(1)
+        mi355slam.ratio_test_device(ctx, best_idx.data_ptr(), best_dist.data_ptr(), second_dist.data_ptr(), BATCH * cap, LOWE_RATIO, 50, match.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    stage_sum = {}
+    match_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(profile_match=True)
+        # per-kernel HIP-event durations of this step (the events are already in the stream; reading them waits for the step)
+        for k, v in ex.stage_ms().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+        match_ms += ctx.event_elapsed_ms(0, 1)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    n_kp = np.frombuffer(ctx_download(ctx, view.count, 4 * BATCH), dtype=np.int32)
+    n_match = int((match.view(BATCH, cap) >= 0).sum().item())
+    frames_total = BATCH * args.steps * world
+    value = frames_total / dt
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per launch, SURVEY 8d / DESIGN.md) ----
+    ws, hs = mi355slam.level_sizes(LEVELS, SCALE, W, H)
+    P = int((ws.astype(np.int64) * hs).sum()); N0 = W * H; K = float(n_kp.mean())
+    alg = {   # bytes per frame
+        "resize": (P - int(ws[-1]) * int(hs[-1])) + (P - N0),      # read levels 0..n-2, write levels 1..n-1
+        "blur": 2 * P, "fast": P, "select": 4 * K, "tracks": 0, "describe": 1821 * K,
+        "hamming": 32 * 2 * K + 8 * K,
+    }
+    avg_ms = {k: v / args.steps for k, v in stage_sum.items()}
+    avg_ms["hamming"] = match_ms / args.steps
+    dom = max(avg_ms, key=avg_ms.get)
+    kernels = {k: {"ms_per_launch": round(avg_ms[k], 4), "alg_GBs": round(alg[k] * BATCH / (avg_ms[k] * 1e-3) / 1e9, 1) if avg_ms[k] > 0 else None}
+               for k in avg_ms}
+    achieved = alg[dom] * BATCH / (avg_ms[dom] * 1e-3) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "whole_step_alg_GBs": round((4 * P + 1821 * K + 72 * K) * BATCH * args.steps / dt / 1e9, 1)}
+    out = {
+        "metric": "frames/sec ORB extract+match (720p)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "C2+C3: ORB extract 1280x720, 8 levels x1.2, 2000 kpts/frame, FAST thr 20, batch 256 synthetic frames/GPU, "
+                               "+ Hamming brute-force best2 + ratio 0.75 of each frame vs the previous (256 pairs, <=2000x2000)",
+                   "batch_per_gpu": BATCH, "keypoints_per_frame": round(K, 1), "ratio_matches_per_frame": round(n_match / BATCH, 1)},
+        "roofline": roofline, "kernels": kernels,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np, 24)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def ctx_download(ctx, dev_ptr, nbytes):
+    import ctypes as C
+    import mi355slam
+    buf = (C.c_char * nbytes)()
+    ctx.check(mi355slam.lib().ms_dev_download(ctx._h, buf, C.c_void_p(dev_ptr), C.c_size_t(nbytes)), "ms_dev_download")
+    return bytes(buf)
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,9 @@ const char *ms_version(void);
 /* HIP-event timing on the context stream (bench.py measures the hot path with these). */
 int ms_timer_start(ms_ctx *ctx);
 int ms_timer_stop_ms(ms_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */
+/* 16 general event slots: mark = hipEventRecord on the context stream; elapsed synchronises on slot b. */
+int ms_event_mark(ms_ctx *ctx, int slot);
+int ms_event_elapsed_ms(ms_ctx *ctx, int slot_a, int slot_b, float *ms);
 /* plain device memory helpers so a C caller needs no HIP headers */
 int ms_dev_alloc(ms_ctx *ctx, size_t bytes, void **out);
 int ms_dev_free(ms_ctx *ctx, void *p);
@@ -129,6 +132,13 @@ int ms_orb_download(ms_orb *orb, int frame, float *x, float *y, float *angle, in
                     uint32_t *desc, int32_t *track_id, int32_t *n);
 int ms_orb_capacity(const ms_orb *orb);
 
+/* Per-kernel timing of ms_orb_extract with HIP events on the context stream (off by default).
+ * Stage order: 0 resize (all levels), 1 blur, 2 fast, 3 select, 4 tracks, 5 describe.
+ * ms_orb_stage_ms synchronises and returns the durations of the LAST ms_orb_extract call. */
+#define MS_ORB_STAGES 6
+int ms_orb_set_profiling(ms_orb *orb, int enable);
+int ms_orb_stage_ms(ms_orb *orb, float *ms /* [MS_ORB_STAGES] */);
+
 /* ImagePyramid::getLevel / getBlurredLevel (image_pyramid.hpp:24-25): copy one level of one frame
  * of the last batch to host, tightly packed w*h bytes (debug / parity testing). */
 int ms_orb_level_size(const ms_orb *orb, int level, int32_t *w, int32_t *h);
@@ -151,6 +161,16 @@ int ms_orb_download_detections(ms_orb *orb, int frame, int level, int32_t *x, in
 int ms_hamming_best2(ms_ctx *ctx, const uint32_t *q, int nq, const uint32_t *t, int nt, int n_pairs,
                      const int32_t *q_bucket, const int32_t *t_bucket, const uint8_t *t_valid,
                      int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist);
+
+/* Same search over SETS of descriptors kept in two pools (e.g. the per-frame outputs of ms_orb_extract,
+ * ms_keypoints.desc with stride = capacity and count = ms_keypoints.count): set s of a pool starts at
+ * pool + s*stride*8 words and holds count[s] rows (count == NULL: stride rows).  Pair p compares set
+ * pair_q[p] of the query pool with set pair_t[p] of the target pool (NULL: set p).  Outputs are
+ * [n_pairs * q_stride]; rows beyond a set's count get (-1, 256, 256).  All pointers are device memory. */
+int ms_hamming_best2_sets(ms_ctx *ctx, const uint32_t *q_pool, int q_stride, const int32_t *q_count,
+                          const uint32_t *t_pool, int t_stride, const int32_t *t_count,
+                          const int32_t *pair_q, const int32_t *pair_t, int n_pairs,
+                          int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist);
 
 /* Accept rule of matchForLoopClosures without the greedy state (keyframe_matcher.cpp:115-122):
  * match[i] = best_idx if best <= 50 and ratio*second >= best, else -1.  Device pointers. */

@@ -48,6 +48,7 @@ void ms_ctx_destroy(ms_ctx *c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &e : c->slots) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -72,6 +73,20 @@ int ms_timer_stop_ms(ms_ctx *c, float *ms) {
     MS_HIP(c, hipEventRecord(c->ev1, c->stream));
     MS_HIP(c, hipEventSynchronize(c->ev1));
     MS_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MS_OK;
+}
+
+int ms_event_mark(ms_ctx *c, int slot) {
+    if (!c || slot < 0 || slot >= 16) return MS_ERR_INVALID;
+    if (!c->slots[slot]) MS_HIP(c, hipEventCreate(&c->slots[slot]));
+    MS_HIP(c, hipEventRecord(c->slots[slot], c->stream));
+    return MS_OK;
+}
+
+int ms_event_elapsed_ms(ms_ctx *c, int a, int b, float *ms) {
+    if (!c || !ms || a < 0 || a >= 16 || b < 0 || b >= 16 || !c->slots[a] || !c->slots[b]) return MS_ERR_INVALID;
+    MS_HIP(c, hipEventSynchronize(c->slots[b]));
+    MS_HIP(c, hipEventElapsedTime(ms, c->slots[a], c->slots[b]));
     return MS_OK;
 }
 

@@ -26,23 +26,40 @@ __device__ __forceinline__ uint32_t hamming8(const uint32_t q[8], const uint4 a,
     return d;
 }
 
+struct HamArgs {
+    const uint32_t *q, *t;            // descriptor pools
+    int32_t q_stride, t_stride;       // rows between consecutive sets of a pool
+    const int32_t *q_count, *t_count; // optional per-set row counts (device); NULL = nq / nt
+    const int32_t *pair_q, *pair_t;   // optional set index of each pair; NULL = pair index
+    int32_t nq, nt;                   // rows per set (upper bound when counts are given)
+    const int32_t *qb, *tb;           // optional bucket ids, laid out like the pools
+    const uint8_t *tv;                // optional target validity, laid out like the target pool
+    int32_t *best_idx; uint16_t *best_dist, *second_dist;   // [n_pairs * q_stride]
+};
+
 template <bool MASKED>
-__global__ __launch_bounds__(256) void k_hamming_best2(const uint32_t *__restrict__ q, int nq, const uint32_t *__restrict__ t, int nt,
-                                                       const int32_t *__restrict__ qb, const int32_t *__restrict__ tb, const uint8_t *__restrict__ tv,
-                                                       int32_t *__restrict__ best_idx, uint16_t *__restrict__ best_dist, uint16_t *__restrict__ second_dist) {
+__global__ __launch_bounds__(256) void k_hamming_best2(HamArgs A) {
     __shared__ uint4 s_t[256][2];
     __shared__ int32_t s_b[256];
     __shared__ uint8_t s_v[256];
     const int p = blockIdx.y, tid = threadIdx.x;
     const int qi = blockIdx.x * 256 + tid;
-    const uint32_t *Q = q + (uint64_t)p * nq * 8;
-    const uint4 *T = reinterpret_cast<const uint4 *>(t + (uint64_t)p * nt * 8);
+    const int qs = A.pair_q ? A.pair_q[p] : p, ts = A.pair_t ? A.pair_t[p] : p;
+    const int nq = A.q_count ? min(A.q_count[qs], A.nq) : A.nq;
+    const int nt = A.t_count ? min(A.t_count[ts], A.nt) : A.nt;
+    const uint64_t o = (uint64_t)p * A.q_stride + qi;
+    if (blockIdx.x * 256 >= nq) {                      // whole block beyond this pair's queries
+        if (qi < A.q_stride) { A.best_idx[o] = -1; A.best_dist[o] = MS_HAMMING_MAX; A.second_dist[o] = MS_HAMMING_MAX; }
+        return;
+    }
+    const uint4 *Q = reinterpret_cast<const uint4 *>(A.q + (uint64_t)qs * A.q_stride * 8);
+    const uint4 *T = reinterpret_cast<const uint4 *>(A.t + (uint64_t)ts * A.t_stride * 8);
     uint32_t qr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t my_bucket = 0;
     if (qi < nq) {
-        const uint4 a = reinterpret_cast<const uint4 *>(Q)[2 * qi], b = reinterpret_cast<const uint4 *>(Q)[2 * qi + 1];
+        const uint4 a = Q[2 * qi], b = Q[2 * qi + 1];
         qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = b.x; qr[5] = b.y; qr[6] = b.z; qr[7] = b.w;
-        if (MASKED && qb) my_bucket = qb[(uint64_t)p * nq + qi];
+        if (MASKED && A.qb) my_bucket = A.qb[(uint64_t)qs * A.q_stride + qi];
     }
     uint32_t best = kNone, second = kNone;
     for (int base = 0; base < nt; base += 256) {
@@ -51,8 +68,8 @@ __global__ __launch_bounds__(256) void k_hamming_best2(const uint32_t *__restric
         if (j < nt) {
             s_t[tid][0] = T[2 * j]; s_t[tid][1] = T[2 * j + 1];
             if (MASKED) {
-                s_b[tid] = tb ? tb[(uint64_t)p * nt + j] : 0;
-                s_v[tid] = tv ? tv[(uint64_t)p * nt + j] : 1;
+                s_b[tid] = A.tb ? A.tb[(uint64_t)ts * A.t_stride + j] : 0;
+                s_v[tid] = A.tv ? A.tv[(uint64_t)ts * A.t_stride + j] : 1;
             }
         }
         __syncthreads();
@@ -61,7 +78,7 @@ __global__ __launch_bounds__(256) void k_hamming_best2(const uint32_t *__restric
             const uint32_t d = hamming8(qr, s_t[k][0], s_t[k][1]);
             uint32_t key = (d << 20) | (uint32_t)(base + k);
             if (MASKED) {
-                const bool ok = s_v[k] != 0 && (!(qb && tb) || s_b[k] == my_bucket);
+                const bool ok = s_v[k] != 0 && (!(A.qb && A.tb) || s_b[k] == my_bucket);
                 key = ok ? key : kNone;
             }
             const uint32_t lo = min(best, key), hi = max(best, key);
@@ -69,11 +86,11 @@ __global__ __launch_bounds__(256) void k_hamming_best2(const uint32_t *__restric
             best = lo;
         }
     }
-    if (qi < nq) {
-        const uint64_t o = (uint64_t)p * nq + qi;
-        best_idx[o] = best == kNone ? -1 : (int32_t)(best & 0xFFFFFu);
-        best_dist[o] = best == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(best >> 20);
-        second_dist[o] = second == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(second >> 20);
+    if (qi < A.q_stride) {
+        const bool live = qi < nq;
+        A.best_idx[o] = (!live || best == kNone) ? -1 : (int32_t)(best & 0xFFFFFu);
+        A.best_dist[o] = (!live || best == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(best >> 20);
+        A.second_dist[o] = (!live || second == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(second >> 20);
     }
 }
 
@@ -229,22 +246,42 @@ __global__ __launch_bounds__(64) void k_match_greedy(GreedyArgs A) {
 
 extern "C" {
 
+static int launch_hamming(ms_ctx *c, const HamArgs &A, int n_pairs) {
+    if (A.nq < 0 || A.nt < 0 || n_pairs < 0 || A.nt >= (1 << 20) || n_pairs > 65535 || A.q_stride < A.nq || A.t_stride < A.nt)
+        return ms_fail(c, MS_ERR_INVALID, "hamming search: size out of range");
+    if (A.q_stride == 0 || n_pairs == 0) return MS_OK;
+    if ((A.qb == nullptr) != (A.tb == nullptr)) return ms_fail(c, MS_ERR_INVALID, "hamming search: give both bucket arrays or neither");
+    if (reinterpret_cast<uintptr_t>(A.q) % 16 || reinterpret_cast<uintptr_t>(A.t) % 16 || (A.q_stride * 32) % 16)
+        return ms_fail(c, MS_ERR_INVALID, "hamming search: descriptors must be 16-byte aligned");
+    MS_HIP(c, hipSetDevice(c->device));
+    dim3 grid(ms_div_up(A.q_stride, 256), n_pairs);
+    if (A.qb || A.tv) hipLaunchKernelGGL(k_hamming_best2<true>, grid, dim3(256), 0, c->stream, A);
+    else hipLaunchKernelGGL(k_hamming_best2<false>, grid, dim3(256), 0, c->stream, A);
+    MS_KERNEL_CHECK(c, "k_hamming_best2");
+    return MS_OK;
+}
+
 int ms_hamming_best2(ms_ctx *c, const uint32_t *q, int nq, const uint32_t *t, int nt, int n_pairs,
                      const int32_t *q_bucket, const int32_t *t_bucket, const uint8_t *t_valid,
                      int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist) {
     if (!c || !q || !t || !best_idx || !best_dist || !second_dist) return MS_ERR_INVALID;
-    if (nq < 0 || nt < 0 || n_pairs < 0 || nt >= (1 << 20) || n_pairs > 65535) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_best2: size out of range");
-    if (nq == 0 || n_pairs == 0) return MS_OK;
-    if ((q_bucket == nullptr) != (t_bucket == nullptr)) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_best2: give both bucket arrays or neither");
-    if (reinterpret_cast<uintptr_t>(q) % 16 || reinterpret_cast<uintptr_t>(t) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_best2: descriptors must be 16-byte aligned");
-    MS_HIP(c, hipSetDevice(c->device));
-    dim3 grid(ms_div_up(nq, 256), n_pairs);
-    if (q_bucket || t_valid)
-        hipLaunchKernelGGL(k_hamming_best2<true>, grid, dim3(256), 0, c->stream, q, nq, t, nt, q_bucket, t_bucket, t_valid, best_idx, best_dist, second_dist);
-    else
-        hipLaunchKernelGGL(k_hamming_best2<false>, grid, dim3(256), 0, c->stream, q, nq, t, nt, q_bucket, t_bucket, t_valid, best_idx, best_dist, second_dist);
-    MS_KERNEL_CHECK(c, "k_hamming_best2");
-    return MS_OK;
+    HamArgs A{};
+    A.q = q; A.t = t; A.q_stride = nq; A.t_stride = nt; A.nq = nq; A.nt = nt;
+    A.qb = q_bucket; A.tb = t_bucket; A.tv = t_valid;
+    A.best_idx = best_idx; A.best_dist = best_dist; A.second_dist = second_dist;
+    return launch_hamming(c, A, n_pairs);
+}
+
+int ms_hamming_best2_sets(ms_ctx *c, const uint32_t *q_pool, int q_stride, const int32_t *q_count,
+                          const uint32_t *t_pool, int t_stride, const int32_t *t_count,
+                          const int32_t *pair_q, const int32_t *pair_t, int n_pairs,
+                          int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist) {
+    if (!c || !q_pool || !t_pool || !best_idx || !best_dist || !second_dist) return MS_ERR_INVALID;
+    HamArgs A{};
+    A.q = q_pool; A.t = t_pool; A.q_stride = q_stride; A.t_stride = t_stride; A.nq = q_stride; A.nt = t_stride;
+    A.q_count = q_count; A.t_count = t_count; A.pair_q = pair_q; A.pair_t = pair_t;
+    A.best_idx = best_idx; A.best_dist = best_dist; A.second_dist = second_dist;
+    return launch_hamming(c, A, n_pairs);
 }
 
 int ms_ratio_test(ms_ctx *c, const int32_t *best_idx, const uint16_t *best_dist, const uint16_t *second_dist,

@@ -560,6 +560,9 @@ struct ms_orb {
     // resize tables per level (device)
     int16_t *d_xofs[MS_MAX_LEVELS] = {nullptr}, *d_xcoef[MS_MAX_LEVELS] = {nullptr};
     int16_t *d_yofs[MS_MAX_LEVELS] = {nullptr}, *d_ycoef[MS_MAX_LEVELS] = {nullptr};
+    // optional per-stage HIP events (ms_orb_set_profiling)
+    bool profiling = false;
+    hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
     // state of the last call
     FrameSrc last_src{};
     int last_frames = 0;
@@ -666,6 +669,7 @@ void ms_orb_destroy(ms_orb *o) {
                     o->d_det_score, o->d_mask, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_track_xy,
                     o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
         if (o->d_xofs[l]) (void)hipFree(o->d_xofs[l]);
         if (o->d_xcoef[l]) (void)hipFree(o->d_xcoef[l]);
@@ -676,6 +680,24 @@ void ms_orb_destroy(ms_orb *o) {
 }
 
 int ms_orb_capacity(const ms_orb *o) { return o ? o->geom.capacity : MS_ERR_INVALID; }
+
+int ms_orb_set_profiling(ms_orb *o, int enable) {
+    if (!o) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    if (enable && !o->ev[0])
+        for (int i = 0; i <= MS_ORB_STAGES; ++i) MS_HIP(c, hipEventCreate(&o->ev[i]));
+    o->profiling = enable != 0;
+    return MS_OK;
+}
+
+int ms_orb_stage_ms(ms_orb *o, float *ms) {
+    if (!o || !ms) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    if (!o->profiling || o->last_frames == 0) return ms_fail(c, MS_ERR_INVALID, "ms_orb_stage_ms: profiling is off or nothing ran");
+    MS_HIP(c, hipEventSynchronize(o->ev[MS_ORB_STAGES]));
+    for (int i = 0; i < MS_ORB_STAGES; ++i) MS_HIP(c, hipEventElapsedTime(&ms[i], o->ev[i], o->ev[i + 1]));
+    return MS_OK;
+}
 
 int ms_orb_set_valid_mask(ms_orb *o, const uint8_t *mask) {
     if (!o) return MS_ERR_INVALID;
@@ -727,26 +749,36 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         if (track_id) MS_HIP(c, hipMemcpyAsync(o->d_track_id, track_id, (size_t)n_frames * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
     MS_HIP(c, hipMemsetAsync(o->d_cand_count, 0, (size_t)n_frames * G.levels * sizeof(int32_t), st));
+    int stage = 0;
+#define MS_STAGE_MARK() do { if (o->profiling) MS_HIP(c, hipEventRecord(o->ev[stage++], st)); } while (0)
+    MS_STAGE_MARK();
     for (int l = 1; l < G.levels; ++l) {
         dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4), n_frames);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, src, o->d_geom, l, o->d_xofs[l], o->d_xcoef[l], o->d_yofs[l], o->d_ycoef[l]);
         MS_KERNEL_CHECK(c, "k_resize");
     }
+    MS_STAGE_MARK();
     hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->d_geom);
     MS_KERNEL_CHECK(c, "k_blur");
+    MS_STAGE_MARK();
     hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count);
     MS_KERNEL_CHECK(c, "k_fast");
+    MS_STAGE_MARK();
     hipLaunchKernelGGL(k_select, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
                        o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
     MS_KERNEL_CHECK(c, "k_select");
+    MS_STAGE_MARK();
     hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
                        (have_tracks && track_id) ? o->d_track_id : nullptr, have_tracks ? o->d_n_tracks : nullptr, o->d_mask,
                        o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
     MS_KERNEL_CHECK(c, "k_tracks");
+    MS_STAGE_MARK();
     hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
                        o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count);
     MS_KERNEL_CHECK(c, "k_describe");
+    MS_STAGE_MARK();
+#undef MS_STAGE_MARK
     o->last_src = src;
     o->last_frames = n_frames;
     return MS_OK;

@@ -101,6 +101,14 @@ class Context:
         self.check(lib().ms_timer_stop_ms(self._h, C.byref(ms)), "ms_timer_stop_ms")
         return ms.value
 
+    def event_mark(self, slot):
+        self.check(lib().ms_event_mark(self._h, slot), "ms_event_mark")
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self.check(lib().ms_event_elapsed_ms(self._h, a, b, C.byref(ms)), "ms_event_elapsed_ms")
+        return ms.value
+
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
 
@@ -135,6 +143,8 @@ class DevBuf:
         self.ctx, self.nbytes = ctx, int(nbytes)
         p = C.c_void_p()
         ctx.check(lib().ms_dev_alloc(ctx._h, C.c_size_t(self.nbytes), C.byref(p)), "ms_dev_alloc")
+        if len(ctx._children) > 4096:
+            ctx._children = [r for r in ctx._children if r() is not None]
         ctx._children.append(weakref.ref(self))
         self.ptr = p.value or 0
         self.shape, self.dtype = None, None
@@ -248,6 +258,14 @@ class OrbExtractor:
                                              _vp(out["desc"]), _vp(out["track_id"]), C.byref(n)), "ms_orb_download")
         return {k: v[:n.value].copy() for k, v in out.items()}
 
+    def set_profiling(self, enable=True):
+        self.ctx.check(lib().ms_orb_set_profiling(self._h, int(enable)), "ms_orb_set_profiling")
+
+    def stage_ms(self):
+        ms = (C.c_float * 6)()
+        self.ctx.check(lib().ms_orb_stage_ms(self._h, ms), "ms_orb_stage_ms")
+        return dict(zip(("resize", "blur", "fast", "select", "tracks", "describe"), [float(v) for v in ms]))
+
     def level_size(self, level):
         w, h = C.c_int32(), C.c_int32()
         self.ctx.check(lib().ms_orb_level_size(self._h, level, C.byref(w), C.byref(h)), "ms_orb_level_size")
@@ -293,6 +311,18 @@ def hamming_best2(ctx, q, t, n_pairs=1, q_bucket=None, t_bucket=None, t_valid=No
               "ms_hamming_best2")
     ctx.sync()
     return (bi.download(np.int32, (nq * n_pairs,)), bd.download(np.uint16, (nq * n_pairs,)), sd.download(np.uint16, (nq * n_pairs,)))
+
+
+def hamming_best2_sets(ctx, q_pool, q_stride, q_count, t_pool, t_stride, t_count, pair_q, pair_t, n_pairs, best_idx, best_dist, second_dist):
+    """All arguments are device pointers (int / DevBuf / None); asynchronous on the context stream."""
+    ctx.check(lib().ms_hamming_best2_sets(ctx._h, _vp(q_pool), q_stride, _vp(q_count), _vp(t_pool), t_stride, _vp(t_count),
+                                          _vp(pair_q), _vp(pair_t), n_pairs, _vp(best_idx), _vp(best_dist), _vp(second_dist)),
+              "ms_hamming_best2_sets")
+
+
+def ratio_test_device(ctx, best_idx, best_dist, second_dist, n, lowe_ratio, max_dist, match):
+    ctx.check(lib().ms_ratio_test(ctx._h, _vp(best_idx), _vp(best_dist), _vp(second_dist), n, C.c_float(lowe_ratio), max_dist, _vp(match)),
+              "ms_ratio_test")
 
 
 def ratio_test(ctx, best_idx, best_dist, second_dist, lowe_ratio, max_dist=50):
