@@ -212,6 +212,53 @@ int ms_match_triangulation(ms_ctx *ctx, const ms_match_frame *pairs1, const ms_m
                            const double *E12, const float *scale_factors, float residual_deg_thr,
                            int check_orientation, int32_t *const *matched, int32_t *n_matches);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bundle adjustment -- replaces the g2o optimisation inside localBundleAdjust / poseBundleAdjust /
+ * globalBundleAdjust (bundle_adjuster.hpp:30-51; bundle_adjuster.cpp:149-154, :322-323, :372-373,
+ * :482-483, :577-578): EdgeSE3ProjectXYZ + EdgeSE3Expmap residuals, Huber kernel, Levenberg-Marquardt.
+ * The host wrapper builds the problem exactly as bundle_adjuster.cpp:156-319 builds the g2o graph.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_pose, n_point, n_obs, n_pose_edge;
+    const double *pose;          /* [n_pose*7]  qx,qy,qz,qw,tx,ty,tz  world->camera (g2o::SE3Quat of poseCW, :250) */
+    const uint8_t *pose_fixed;   /* [n_pose]    vertex->setFixed (:252, :351) */
+    const double *point;         /* [n_point*3] MapPoint::position (:266) */
+    const uint8_t *point_fixed;  /* [n_point] or NULL (pose-only BA fixes every point, :465) */
+    const int32_t *obs_pose;     /* [n_obs] index of the keyframe vertex of each EdgeSE3ProjectXYZ */
+    const int32_t *obs_point;    /* [n_obs] index of its map-point vertex */
+    const double *obs_uv;        /* [n_obs*2] measurement bearing.xy / bearing.z (:52) */
+    const double *obs_info;      /* [n_obs]   information = focal^2 / levelSigmaSq[octave] times I2 (:51-53) */
+    double huber_delta;          /* sqrt(5.991) (:56); <= 0 disables the robust kernel */
+    const int32_t *edge_i;       /* [n_pose_edge] EdgeSE3Expmap vertex 0 (:76, :99, :355) */
+    const int32_t *edge_j;       /* [n_pose_edge] vertex 1 */
+    const double *edge_meas;     /* [n_pose_edge*7] measurement SE3 */
+    const double *edge_info;     /* [n_pose_edge*36] 6x6 information, row-major, (rotation, translation) order */
+    int32_t max_iters;           /* optimizer.optimize(iterations) */
+} ms_ba_problem;                 /* all pointers are HOST memory, read during ms_ba_create only */
+
+typedef struct {
+    int32_t iterations;          /* LM iterations run */
+    int32_t trials;              /* damped solves, including rejected ones */
+    int32_t stopped_early;       /* 1 if g2o's Terminate condition ended the run */
+    double final_lambda;
+    double chi2_initial, chi2_final;   /* activeRobustChi2 before / after */
+} ms_ba_result;
+
+typedef struct ms_ba ms_ba;
+
+/* Upload `n` independent problems (different sizes allowed) and build their index structures. */
+int ms_ba_create(ms_ctx *ctx, const ms_ba_problem *problems, int n, ms_ba **out);
+void ms_ba_destroy(ms_ba *ba);
+/* Run the full LM schedule of every problem from its initial estimates, one workgroup per problem,
+ * entirely on the device; asynchronous on the context stream, repeatable. */
+int ms_ba_solve(ms_ba *ba);
+/* Results of problem i (synchronises): poses [n_pose*7], points [n_point*3], per-observation chi2
+ * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL. */
+int ms_ba_download(ms_ba *ba, int i, double *pose, double *point, double *chi2_per_obs, ms_ba_result *res);
+/* create + solve + download + destroy for one problem. */
+int ms_ba_solve_host(ms_ctx *ctx, const ms_ba_problem *problem, double *pose_out, double *point_out,
+                     double *chi2_per_obs, ms_ba_result *res);
+
 #ifdef __cplusplus
 }
 #endif

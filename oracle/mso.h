@@ -141,6 +141,34 @@ int mso_best2_candidates(const uint32_t *qdesc, const uint32_t *tdesc, const int
                          const uint8_t *skip, const int32_t *t_octave,
                          unsigned *best, unsigned *second, int *best_oct, int *second_oct);
 
+/* ---- B1-B6: bundle adjustment (bundle_adjuster.cpp:43-111, :141-394; g2o semantics restated in ba.c) ---- */
+typedef struct {
+    int n_pose, n_point, n_obs, n_edge;
+    double *pose;               /* [n_pose*7] qx,qy,qz,qw,tx,ty,tz  world->camera (g2o SE3Quat); updated in place */
+    const uint8_t *pose_fixed;  /* [n_pose] */
+    double *point;              /* [n_point*3]; updated in place */
+    const uint8_t *point_fixed; /* [n_point] or NULL */
+    const int32_t *obs_pose, *obs_point;   /* [n_obs] */
+    const double *obs_uv;       /* [n_obs*2] bearing.xy / bearing.z (bundle_adjuster.cpp:52) */
+    const double *obs_info;     /* [n_obs]  focal^2 / sigma^2_octave (bundle_adjuster.cpp:51) */
+    double huber_delta;         /* sqrt(5.991) (bundle_adjuster.cpp:56); <= 0 disables the kernel */
+    const int32_t *edge_i, *edge_j;        /* EdgeSE3Expmap vertices 0 and 1 */
+    const double *edge_meas;    /* [n_edge*7] */
+    const double *edge_info;    /* [n_edge*36] row-major */
+    int max_iters;
+} mso_ba_problem;
+
+typedef struct { int iters, trials_total, stop_reason; double lambda, chi2_init, chi2_final; } mso_ba_stats;
+
+/* full_system = 1 solves the undamped-ordering-free dense (poses+points) system, 0 the Schur complement. */
+int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int full_system);
+void mso_se3_exp(const double *update6, double *pose7);
+void mso_se3_log(const double *pose7, double *out6);
+/* test hooks: residual + Jacobians of the two edge types */
+void mso_ba_proj_edge(const double *pose7, const double *X, const double *uv, double *e2, double *Jp12, double *Jl6);
+void mso_ba_pose_edge(const double *Ti, const double *Tj, const double *M, double *e6, double *Ji36, double *Jj36);
+void mso_se3_mul(const double *a, const double *b, double *r);
+
 /* ---- synthetic inputs (integer-only) ---- */
 void mso_synth_frame(uint8_t *img, int w, int h, uint32_t seed, int shift_x, int shift_y);
 

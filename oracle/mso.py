@@ -275,3 +275,66 @@ def match_triangulation(desc1, angle1, octave1, bearing1, usable1, bucket1,
                                       _p(d2, u32p), _p(a2, f32p), _p(be2, f64p), _p(u2, u8p), len(d2), C.byref(b2),
                                       _p(E, f64p), _p(sf, f32p), C.c_float(thr_deg), int(check_orientation), _p(m, i32p))
     return n, m
+
+
+# ---- bundle adjustment ----
+class BaProblem(C.Structure):
+    _fields_ = [("n_pose", C.c_int), ("n_point", C.c_int), ("n_obs", C.c_int), ("n_edge", C.c_int),
+                ("pose", f64p), ("pose_fixed", u8p), ("point", f64p), ("point_fixed", u8p),
+                ("obs_pose", i32p), ("obs_point", i32p), ("obs_uv", f64p), ("obs_info", f64p), ("huber_delta", C.c_double),
+                ("edge_i", i32p), ("edge_j", i32p), ("edge_meas", f64p), ("edge_info", f64p), ("max_iters", C.c_int)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("trials_total", C.c_int), ("stop_reason", C.c_int),
+                ("lambda_", C.c_double), ("chi2_init", C.c_double), ("chi2_final", C.c_double)]
+
+
+def ba_solve(prob, max_iters=10, full_system=False):
+    """prob: dict from tests/ba_synth.py (numpy arrays).  Returns dict(pose, point, chi2, stats)."""
+    pose = np.ascontiguousarray(prob["pose"], np.float64).copy()
+    point = np.ascontiguousarray(prob["point"], np.float64).copy()
+    keep = dict(pf=np.ascontiguousarray(prob["pose_fixed"], np.uint8),
+                lf=None if prob.get("point_fixed") is None else np.ascontiguousarray(prob["point_fixed"], np.uint8),
+                op=np.ascontiguousarray(prob["obs_pose"], np.int32), ol=np.ascontiguousarray(prob["obs_point"], np.int32),
+                uv=np.ascontiguousarray(prob["obs_uv"], np.float64), info=np.ascontiguousarray(prob["obs_info"], np.float64),
+                ei=np.ascontiguousarray(prob["edge_i"], np.int32), ej=np.ascontiguousarray(prob["edge_j"], np.int32),
+                em=np.ascontiguousarray(prob["edge_meas"], np.float64), ew=np.ascontiguousarray(prob["edge_info"], np.float64))
+    P = BaProblem(len(pose), len(point), len(keep["op"]), len(keep["ei"]), _p(pose, f64p), _p(keep["pf"], u8p), _p(point, f64p),
+                  _p(keep["lf"], u8p), _p(keep["op"], i32p), _p(keep["ol"], i32p), _p(keep["uv"], f64p), _p(keep["info"], f64p),
+                  float(prob["huber_delta"]), _p(keep["ei"], i32p), _p(keep["ej"], i32p), _p(keep["em"], f64p), _p(keep["ew"], f64p), max_iters)
+    chi2 = np.zeros(max(len(keep["op"]), 1), np.float64)
+    st = BaStats()
+    rc = lib().mso_ba_solve(C.byref(P), _p(chi2, f64p), C.byref(st), int(full_system))
+    assert rc == 0
+    return dict(pose=pose, point=point, chi2=chi2[:len(keep["op"])],
+                stats=dict(iters=st.iters, trials=st.trials_total, stop=st.stop_reason, lam=st.lambda_, chi2_init=st.chi2_init, chi2_final=st.chi2_final))
+
+
+def se3_exp(u):
+    u = np.ascontiguousarray(u, np.float64); out = np.zeros(7)
+    lib().mso_se3_exp(_p(u, f64p), _p(out, f64p)); return out
+
+
+def se3_log(p):
+    p = np.ascontiguousarray(p, np.float64); out = np.zeros(6)
+    lib().mso_se3_log(_p(p, f64p), _p(out, f64p)); return out
+
+
+def se3_mul(a, b):
+    a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64); out = np.zeros(7)
+    lib().mso_se3_mul(_p(a, f64p), _p(b, f64p), _p(out, f64p)); return out
+
+
+def ba_proj_edge(pose, X, uv):
+    pose = np.ascontiguousarray(pose, np.float64); X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
+    e, Jp, Jl = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 3))
+    lib().mso_ba_proj_edge(_p(pose, f64p), _p(X, f64p), _p(uv, f64p), _p(e, f64p), _p(Jp, f64p), _p(Jl, f64p))
+    return e, Jp, Jl
+
+
+def ba_pose_edge(Ti, Tj, M):
+    Ti = np.ascontiguousarray(Ti, np.float64); Tj = np.ascontiguousarray(Tj, np.float64); M = np.ascontiguousarray(M, np.float64)
+    e, Ji, Jj = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+    lib().mso_ba_pose_edge(_p(Ti, f64p), _p(Tj, f64p), _p(M, f64p), _p(e, f64p), _p(Ji, f64p), _p(Jj, f64p))
+    return e, Ji, Jj

@@ -385,3 +385,68 @@ def match_triangulation(ctx, frames1, frames2, E12, scale_factors_, thr_deg, che
         ctx.check(lib().ms_match_triangulation(ctx._h, A1, A2, n, _vp(dE), _vp(dsf), C.c_float(thr_deg), int(check_orientation), ptrs, _vp(nm)),
                   "ms_match_triangulation")
     return _run_greedy(ctx, frames1, frames2, call)
+
+
+# ---- bundle adjustment ----
+class BaProblemC(C.Structure):
+    _fields_ = [("n_pose", C.c_int32), ("n_point", C.c_int32), ("n_obs", C.c_int32), ("n_pose_edge", C.c_int32),
+                ("pose", C.c_void_p), ("pose_fixed", C.c_void_p), ("point", C.c_void_p), ("point_fixed", C.c_void_p),
+                ("obs_pose", C.c_void_p), ("obs_point", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_info", C.c_void_p),
+                ("huber_delta", C.c_double), ("edge_i", C.c_void_p), ("edge_j", C.c_void_p), ("edge_meas", C.c_void_p),
+                ("edge_info", C.c_void_p), ("max_iters", C.c_int32)]
+
+
+class BaResultC(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("stopped_early", C.c_int32), ("final_lambda", C.c_double),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double)]
+
+
+def _ba_struct(prob, max_iters):
+    """prob: dict of numpy arrays (see tests/ba_synth.py).  Returns (struct, keepalive)."""
+    k = dict(pose=np.ascontiguousarray(prob["pose"], np.float64), pf=np.ascontiguousarray(prob["pose_fixed"], np.uint8),
+             point=np.ascontiguousarray(prob["point"], np.float64),
+             lf=None if prob.get("point_fixed") is None else np.ascontiguousarray(prob["point_fixed"], np.uint8),
+             op=np.ascontiguousarray(prob["obs_pose"], np.int32), ol=np.ascontiguousarray(prob["obs_point"], np.int32),
+             uv=np.ascontiguousarray(prob["obs_uv"], np.float64), info=np.ascontiguousarray(prob["obs_info"], np.float64),
+             ei=np.ascontiguousarray(prob["edge_i"], np.int32), ej=np.ascontiguousarray(prob["edge_j"], np.int32),
+             em=np.ascontiguousarray(prob["edge_meas"], np.float64), ew=np.ascontiguousarray(prob["edge_info"], np.float64))
+    a = lambda x: None if x is None else x.ctypes.data
+    s = BaProblemC(len(k["pose"]), len(k["point"]), len(k["op"]), len(k["ei"]), a(k["pose"]), a(k["pf"]), a(k["point"]), a(k["lf"]),
+                   a(k["op"]), a(k["ol"]), a(k["uv"]), a(k["info"]), float(prob["huber_delta"]), a(k["ei"]), a(k["ej"]), a(k["em"]), a(k["ew"]), max_iters)
+    return s, k
+
+
+class BundleAdjuster:
+    """A batch of independent BA problems resident on the device (ms_ba_create / ms_ba_solve / ms_ba_download)."""
+
+    def __init__(self, ctx, problems, max_iters=10):
+        self.ctx = ctx
+        structs, self._keep = zip(*[_ba_struct(p, max_iters) for p in problems])
+        self.n = len(structs)
+        self.dims = [(s.n_pose, s.n_point, s.n_obs) for s in structs]
+        arr = (BaProblemC * self.n)(*structs)
+        self._h = C.c_void_p()
+        ctx.check(lib().ms_ba_create(ctx._h, arr, self.n, C.byref(self._h)), "ms_ba_create")
+        ctx._children.append(weakref.ref(self))
+
+    def solve(self):
+        self.ctx.check(lib().ms_ba_solve(self._h), "ms_ba_solve")
+
+    def download(self, i):
+        npz, nl, no = self.dims[i]
+        pose, point, chi2 = np.zeros((npz, 7)), np.zeros((nl, 3)), np.zeros(no)
+        r = BaResultC()
+        self.ctx.check(lib().ms_ba_download(self._h, i, _vp(pose), _vp(point), _vp(chi2), C.byref(r)), "ms_ba_download")
+        return dict(pose=pose, point=point, chi2=chi2,
+                    stats=dict(iters=r.iterations, trials=r.trials, stop=r.stopped_early, lam=r.final_lambda, chi2_init=r.chi2_initial, chi2_final=r.chi2_final))
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib().ms_ba_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

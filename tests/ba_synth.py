@@ -1,0 +1,109 @@
+"""Synthetic bundle-adjustment problems shared by tests and bench.py.
+
+Cameras on a slightly curved 10 m path (0.2 m spacing) looking at points in an 8 x 4 x 6 m box 4-10 m ahead; each point
+is seen by a contiguous run of `run` cameras; observations are normalised image coordinates with N(0, (1/500)^2) noise,
+information 500^2 / sigma^2_octave (bundle_adjuster.cpp:51), Huber delta sqrt(5.991); consecutive cameras are chained by
+EdgeSE3Expmap odometry edges (bundle_adjuster.cpp:293-311) with Omega = diag(r^2 I3, p^2 I3) * 0.26667 / dt.
+Poses are world->camera (q = x,y,z,w ; t).  numpy Philox generator, seed stated by the caller.
+"""
+import numpy as np
+
+HUBER_DELTA = float(np.sqrt(np.float32(5.991)))     # constexpr float CHI2_THRESHOLD = 5.991 (bundle_adjuster.cpp:28)
+
+
+def _quat_from_R(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0); w = 0.5 * s; s = 0.5 / s
+        q = np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
+    else:
+        i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (j + 1) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0); q = np.zeros(4); q[i] = 0.5 * s; s = 0.5 / s
+        q[3] = (R[k, j] - R[j, k]) * s; q[j] = (R[j, i] + R[i, j]) * s; q[k] = (R[k, i] + R[i, k]) * s
+    if q[3] < 0: q = -q
+    return q / np.linalg.norm(q)
+
+
+def _R_from_quat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _rotvec(v):
+    th = np.linalg.norm(v)
+    if th < 1e-12: return np.eye(3)
+    k = v / th; K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _pose(R, t):
+    return np.concatenate([_quat_from_R(R), t])
+
+
+def _compose(a, b):      # a * b
+    Ra, Rb = _R_from_quat(a[:4]), _R_from_quat(b[:4])
+    return _pose(Ra @ Rb, Ra @ b[4:] + a[4:])
+
+
+def _inverse(a):
+    R = _R_from_quat(a[:4]).T
+    return _pose(R, -R @ a[4:])
+
+
+def make_problem(n_pose=50, n_point=2000, run=10, seed=42, noise=1.0 / 500, perturb=True, fix_first=False, prior_r=100.0, prior_p=50.0, dt=0.1,
+                 outlier_frac=0.0):
+    rng = np.random.Generator(np.random.Philox(seed))
+    sf2 = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32) ** 2     # levelSigmaSq
+    gt_pose = []
+    for i in range(n_pose):
+        c = np.array([0.2 * i - 0.1 * (n_pose - 1), 0.05 * np.sin(0.3 * i), 0.02 * i])
+        R = _rotvec(np.array([0.0, 0.004 * (i - n_pose / 2), 0.0])) @ _rotvec(np.array([0.01 * np.sin(i), 0, 0]))
+        gt_pose.append(_pose(R, -R @ c))                      # world->camera
+    gt_pose = np.array(gt_pose)
+    half = 0.1 * (n_pose - 1)
+    gt_point = np.stack([rng.uniform(-half - 1, half + 1, n_point), rng.uniform(-2, 2, n_point), rng.uniform(4, 10, n_point)], 1)
+    run = min(run, n_pose)
+    obs_pose, obs_point, uv, info = [], [], [], []
+    for l in range(n_point):
+        s = int(rng.integers(0, n_pose - run + 1))
+        for i in range(s, s + run):
+            p = _R_from_quat(gt_pose[i, :4]) @ gt_point[l] + gt_pose[i, 4:]
+            assert p[2] > 0.5                                   # cheirality
+            z = p[:2] / p[2] + rng.normal(0, noise, 2)
+            if outlier_frac > 0 and rng.random() < outlier_frac:
+                z = z + rng.normal(0, 60 * noise, 2)
+            octv = int(rng.integers(0, 8))
+            obs_pose.append(i); obs_point.append(l); uv.append(z); info.append(500.0 ** 2 / float(sf2[octv]))
+    edge_i, edge_j, edge_meas, edge_info = [], [], [], []
+    W = np.diag([prior_r ** 2] * 3 + [prior_p ** 2] * 3) * (0.26667 / dt)
+    for i in range(1, n_pose):                                  # vertex0 = kf, vertex1 = previous kf (bundle_adjuster.cpp:76-77)
+        odo_noise = np.concatenate([rng.normal(0, 0.001, 3), rng.normal(0, 0.002, 3)]) if perturb else np.zeros(6)
+        M = _compose(gt_pose[i - 1], _inverse(gt_pose[i]))      # poseDifference(prev, kf), mapdb.cpp:224-229
+        M = _compose(_pose(_rotvec(odo_noise[:3]), odo_noise[3:]), M)
+        edge_i.append(i); edge_j.append(i - 1); edge_meas.append(M); edge_info.append(W)
+    pose, point = gt_pose.copy(), gt_point.copy()
+    if perturb:
+        for i in range(n_pose):
+            d = _pose(_rotvec(rng.normal(0, np.radians(0.5) / np.sqrt(3), 3)), rng.normal(0, 0.02 / np.sqrt(3), 3))
+            pose[i] = _compose(d, pose[i])
+        point = point + rng.normal(0, 0.02 / np.sqrt(3), point.shape)
+    pose_fixed = np.zeros(n_pose, np.uint8)
+    if fix_first:
+        pose_fixed[0] = 1; pose[0] = gt_pose[0]
+    return dict(pose=pose, point=point, pose_fixed=pose_fixed, point_fixed=None,
+                obs_pose=np.array(obs_pose, np.int32), obs_point=np.array(obs_point, np.int32), obs_uv=np.array(uv), obs_info=np.array(info),
+                huber_delta=HUBER_DELTA, edge_i=np.array(edge_i, np.int32), edge_j=np.array(edge_j, np.int32),
+                edge_meas=np.array(edge_meas).reshape(-1, 7), edge_info=np.array(edge_info).reshape(-1, 36),
+                gt_pose=gt_pose, gt_point=gt_point)
+
+
+def residuals(prob, pose, point):
+    """Per-observation reprojection residual (2-vector) in normalised image units."""
+    out = np.zeros((len(prob["obs_pose"]), 2))
+    Rs = [_R_from_quat(p[:4]) for p in pose]
+    for o, (i, l) in enumerate(zip(prob["obs_pose"], prob["obs_point"])):
+        p = Rs[i] @ point[l] + pose[i, 4:]
+        out[o] = prob["obs_uv"][o] - p[:2] / p[2]
+    return out
