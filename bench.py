@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--ba-batch", type=int, default=256)
+    ap.add_argument("--ba-steps", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +159,9 @@ def main():
                    "batch_per_gpu": BATCH, "keypoints_per_frame": round(K, 1), "ratio_matches_per_frame": round(n_match / BATCH, 1)},
         "roofline": roofline, "kernels": kernels,
     }
+    # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 windows per launch, device-resident ----
+    if not args.no_ba:
+        out["local_ba"] = bench_ba(ctx, args, world, rank, dist if world > 1 else None, torch)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, 24)
@@ -163,6 +169,55 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+
+
+def bench_ba(ctx, args, world, rank, dist, torch):
+    """C4: 50 keyframes x 2000 points x 20000 observations, 10 LM iterations, Huber sqrt(5.991), 49 odometry edges."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ba_synth
+    import mi355slam
+    distinct = [ba_synth.make_problem(50, 2000, 10, seed=42 + 8 * rank + i) for i in range(4)]
+    probs = [distinct[i % len(distinct)] for i in range(args.ba_batch)]
+    ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=10)
+    ba.solve(); ctx.sync()                                   # warm-up
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ctx.event_mark(2)
+    for _ in range(args.ba_steps):
+        ba.solve()
+    ctx.event_mark(3)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ctx.event_elapsed_ms(2, 3) / args.ba_steps
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st = ba.download(0)["stats"]
+    # single-window latency (one workgroup on one CU)
+    one = mi355slam.BundleAdjuster(ctx, probs[:1], max_iters=10)
+    one.solve(); ctx.sync()
+    ctx.event_mark(4); one.solve(); ctx.event_mark(5)
+    single_ms = ctx.event_elapsed_ms(4, 5)
+    alg_bytes_per_solve = 6.61e6 * st["iters"]               # SURVEY 8d: 6.61 MB per LM iteration at C4
+    res = {"metric": "local-BA solves/sec (50 KF x 2000 pts x 20k obs, 10 LM iters)", "value": round(args.ba_batch * args.ba_steps * world / dt, 1),
+           "unit": "solves/s", "windows_per_launch": args.ba_batch, "ms_per_launch": round(kernel_ms, 3), "lm_iterations": st["iters"],
+           "lm_trials": st["trials"], "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
+           "alg_GBs": round(alg_bytes_per_solve * args.ba_batch / (kernel_ms * 1e-3) / 1e9, 1), "dtype": "f64"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mso
+        t1 = time.perf_counter()
+        for i in range(4):
+            mso.ba_solve(distinct[i], 10, False)
+        res["cpu_baseline"] = {"value": round(4 / (time.perf_counter() - t1), 2), "unit": "solves/s", "cores": 1, "kind": "port",
+                               "sample": "4 C4 windows, oracle/libmso.so (Schur + dense Cholesky), 1 thread"}
+    ba.close(); one.close()
+    return res
 
 
 def ctx_download(ctx, dev_ptr, nbytes):
