@@ -32,8 +32,8 @@ struct LevelGeom {
     int32_t w, h, pitch, quota;
     int32_t det_base;                 // first slot of this level in det arrays (prefix of quotas)
     int32_t cand_cap;                 // capacity of this level's candidate list (entries)
-    int32_t btiles_x, btile_base;     // k_blur tile table (128x16 tiles)
-    int32_t ftiles_x, ftile_base;     // k_fast tile table (64x16 tiles)
+    int32_t btiles_x, btile_base;     // k_blur tile table (248x16 tiles)
+    int32_t ftiles_x, ftile_base;     // k_fast tile table (248x30 tiles)
     uint64_t img_off, blur_off;       // byte offsets inside a frame slab
     uint64_t cand_off;                // entry offset inside a frame's candidate buffer
     float scale;                      // scaleFactors[l] (float32 chain)
@@ -73,13 +73,35 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t *src, uint64_
 
 // ------------------------------------------------------------------------------------------------
 // P1: cv::resize INTER_LINEAR, 8U (image_pyramid.cpp:79).  Level l from level l-1 of the same frame.
-// 4 destination pixels per lane, one dword store; taps through the vector cache (neighbouring
-// lanes share source bytes).  HBM-bound: reads level l-1 once, writes level l once.
-__global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, int l,
-                                                const int16_t *__restrict__ xofs, const int16_t *__restrict__ xcoef,
-                                                const int16_t *__restrict__ yofs, const int16_t *__restrict__ ycoef) {
+// 4 destination pixels per lane, one dword store.  Per source row a lane fetches three aligned dwords
+// (12 bytes cover the <= 8-byte tap window of its 4 pixels for scale factors up to 2) and funnel-shifts
+// them into a 64-bit window; the per-column (offset, a0, a1) and per-row (row0, row1, b0, b1) tables are
+// packed so a lane needs two 16-byte table loads.  HBM-bound by design: reads level l-1, writes level l.
+struct ResizeTab {
+    const int16_t *xtab;   // [dw][4] : sx, a0, a1, 0
+    const int16_t *ytab;   // [dh][4] : sy0, sy1 (clamped rows), b0, b1
+};
+
+__device__ __forceinline__ int resize_px(uint64_t w0, uint64_t w1, int k, int a0, int a1, int b0, int b1) {
+    const int r0 = (int)((w0 >> (8 * k)) & 255) * a0 + (int)((w0 >> (8 * k + 8)) & 255) * a1;
+    const int r1 = (int)((w1 >> (8 * k)) & 255) * a0 + (int)((w1 >> (8 * k + 8)) & 255) * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    return min(max(v, 0), 255);
+}
+
+__device__ __forceinline__ uint64_t window8(const uint8_t *row, int sx0, int last_dword) {
+    const int base = sx0 & ~3, sh = 8 * (sx0 & 3);
+    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(row + min(base, last_dword));
+    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(row + min(base + 4, last_dword));
+    const uint32_t d2 = *reinterpret_cast<const uint32_t *>(row + min(base + 8, last_dword));
+    const uint64_t lo = ((uint64_t)d1 << 32) | d0;
+    return sh ? (lo >> sh) | ((uint64_t)d2 << (64 - sh)) : lo;
+}
+
+template <bool WIDE>   // WIDE: tap window of 4 pixels may exceed 8 bytes (scale factor > 2) -> per-tap byte loads
+__global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, int l, ResizeTab T) {
     const LevelGeom &D = g->L[l];
-    const int sw = g->L[l - 1].w, sh = g->L[l - 1].h;
+    const int sw = g->L[l - 1].w;
     const int f = blockIdx.z;
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -87,22 +109,24 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
     int spitch;
     const uint8_t *S = level_ptr(src, g, f, l - 1, spitch);
     uint8_t *dst = src.slab + (uint64_t)f * g->slab_stride + D.img_off;
-    const int sy = yofs[dy];
-    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);   // clip(sy, 0, ssize.height)
-    const uint8_t *S0 = S + (uint64_t)sy0 * spitch, *S1 = S + (uint64_t)sy1 * spitch;
-    const int b0 = ycoef[2 * dy], b1 = ycoef[2 * dy + 1];
-    uint32_t packed = 0;
+    const short4 yt = reinterpret_cast<const short4 *>(T.ytab)[dy];
+    const uint8_t *S0 = S + (uint64_t)yt.x * spitch, *S1 = S + (uint64_t)yt.y * spitch;
+    const int b0 = yt.z, b1 = yt.w;
+    short4 xt[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int dx = dx0 + i;
-        if (dx < D.w) {
-            const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
-            const int a0 = xcoef[2 * dx], a1 = xcoef[2 * dx + 1];
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            packed |= (uint32_t)v << (8 * i);
+    for (int i = 0; i < 4; ++i) xt[i] = reinterpret_cast<const short4 *>(T.xtab)[min(dx0 + i, D.w - 1)];
+    uint32_t packed = 0;
+    if (!WIDE) {
+        const int sx0 = xt[0].x, last = (sw - 1) & ~3;
+        const uint64_t w0 = window8(S0, sx0, last), w1 = window8(S1, sx0, last);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) packed |= (uint32_t)resize_px(w0, w1, xt[i].x - sx0, xt[i].y, xt[i].z, b0, b1) << (8 * i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sx = xt[i].x, sx1 = min(sx + 1, sw - 1);
+            const uint64_t w0 = (uint64_t)S0[sx] | ((uint64_t)S0[sx1] << 8), w1 = (uint64_t)S1[sx] | ((uint64_t)S1[sx1] << 8);
+            packed |= (uint32_t)resize_px(w0, w1, 0, xt[i].y, xt[i].z, b0, b1) << (8 * i);
         }
     }
     *reinterpret_cast<uint32_t *>(dst + (uint64_t)dy * D.pitch + dx0) = packed;
@@ -110,68 +134,100 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
 
 // ------------------------------------------------------------------------------------------------
 // P2: cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8U fixed point (image_pyramid.cpp:84).
-// One launch covers every level of every frame (tile table in PyrGeom).  Tile = 128x16 outputs,
-// (16+6)x(128+6) input bytes staged in LDS, separable: 8.8 taps, 16-bit rows, 32-bit columns.
+// One launch covers every level of every frame (tile table in PyrGeom).  No LDS: a lane owns one dword
+// (4 pixels) of a row; a wave owns a 256-pixel row segment and walks 4 output rows.
+//   vertical pass   on the raw bytes, two pixels per instruction: even/odd bytes of the dword are two
+//                   16-bit lanes (sums stay < 2^16 because the 8.8 taps add up to 256) -> v_pk_mad_u16
+//   horizontal pass on the 16-bit column sums of the lane and its two neighbours (ds_bpermute shuffles),
+//                   v_dot2_u32_u16 with the rounding constant as the initial accumulator
+// Lanes 0 and 63 only provide halo (248 outputs per 256 loaded pixels); REFLECT_101 is applied when the
+// bytes are loaded, which commutes with the vertical pass.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int reflect101(int i, int n) {
     i = i < 0 ? -i : i;
     i = i >= n ? 2 * n - 2 - i : i;
     return min(max(i, 0), n - 1);
 }
 
+__device__ __forceinline__ uint32_t load4_reflect(const uint8_t *row, int x, int w) {
+    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d |= (uint32_t)row[reflect101(x + i, w)] << (8 * i);
+    return d;
+}
+
+__device__ __forceinline__ uint32_t vsum7(const uint32_t *v) {   // 18,34,48,56,48,34,18 on two packed 16-bit lanes
+    const us2_t k0 = {18, 18}, k1 = {34, 34}, k2 = {48, 48}, k3 = {56, 56};
+    const us2_t a = __builtin_bit_cast(us2_t, v[0]) + __builtin_bit_cast(us2_t, v[6]);
+    const us2_t b = __builtin_bit_cast(us2_t, v[1]) + __builtin_bit_cast(us2_t, v[5]);
+    const us2_t c = __builtin_bit_cast(us2_t, v[2]) + __builtin_bit_cast(us2_t, v[4]);
+    const us2_t d = __builtin_bit_cast(us2_t, v[3]);
+    return __builtin_bit_cast(uint32_t, (us2_t)(a * k0 + b * k1 + c * k2 + d * k3));
+}
+
+__device__ __forceinline__ uint32_t dot2(uint32_t a, unsigned lo, unsigned hi, uint32_t acc) {
+    const us2_t k = {(unsigned short)lo, (unsigned short)hi};
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), k, acc, false);
+}
+
+constexpr int kBlurSeg = 248;   // outputs per wave row segment
+
 __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g) {
-    __shared__ uint8_t s_in[22][136];
-    __shared__ uint16_t s_h[22][128];
-    const int kq[7] = {18, 34, 48, 56, 48, 34, 18};
     int t = blockIdx.x, l = 0;
     while (l + 1 < g->levels && t >= g->L[l + 1].btile_base) ++l;
     t -= g->L[l].btile_base;
     const LevelGeom &G = g->L[l];
-    const int x0 = (t % G.btiles_x) * 128, y0 = (t / G.btiles_x) * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = (t % G.btiles_x) * kBlurSeg - 4 + lane * 4;
+    const int y0 = (t / G.btiles_x) * 16 + wave * 4;
     const int f = blockIdx.y, w = G.w, h = G.h;
+    if (y0 >= h) return;
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
-    const int tid = threadIdx.x;
-    for (int r = tid >> 6; r < 22; r += 4) {
-        const uint8_t *row = img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch;
-        for (int c = tid & 63; c < 134; c += 64) s_in[r][c] = row[reflect101(x0 - 3 + c, w)];
-    }
-    __syncthreads();
-    for (int i = tid; i < 22 * 128; i += 256) {
-        const int r = i >> 7, c = i & 127;
-        unsigned a = 0;
+    uint32_t e[10], o[10];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) a += (unsigned)kq[k] * s_in[r][c + k];
-        s_h[r][c] = (uint16_t)a;
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t d = load4_reflect(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch, x, w);
+        e[r] = d & 0x00FF00FFu;
+        o[r] = (d >> 8) & 0x00FF00FFu;
     }
-    __syncthreads();
     uint8_t *dst = blur_ptr(src, g, f, l);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int item = tid + 256 * j, r = item >> 5, c4 = (item & 31) * 4;
-        const int y = y0 + r, x = x0 + c4;
-        if (y < h && x < w) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t a = 0;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) a += (uint32_t)kq[k] * s_h[r + k][c4 + i];
-                packed |= ((a + 32768u) >> 16) << (8 * i);
-            }
-            *reinterpret_cast<uint32_t *>(dst + (uint64_t)y * G.pitch + x) = packed;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t Ce = vsum7(e + j), Co = vsum7(o + j);            // columns (x, x+2) and (x+1, x+3)
+        const uint32_t Le = __shfl_up(Ce, 1, 64), Lo = __shfl_up(Co, 1, 64);
+        const uint32_t Re = __shfl_down(Ce, 1, 64), Ro = __shfl_down(Co, 1, 64);
+        uint32_t o0 = dot2(Lo, 18, 48, 32768u); o0 = dot2(Le, 0, 34, o0); o0 = dot2(Ce, 56, 34, o0); o0 = dot2(Co, 48, 18, o0);
+        uint32_t o1 = dot2(Le, 0, 18, 32768u); o1 = dot2(Lo, 0, 34, o1); o1 = dot2(Ce, 48, 48, o1); o1 = dot2(Co, 56, 34, o1); o1 = dot2(Re, 18, 0, o1);
+        uint32_t o2 = dot2(Lo, 0, 18, 32768u); o2 = dot2(Ce, 34, 56, o2); o2 = dot2(Co, 48, 48, o2); o2 = dot2(Re, 34, 0, o2); o2 = dot2(Ro, 18, 0, o2);
+        uint32_t o3 = dot2(Ce, 18, 48, 32768u); o3 = dot2(Co, 34, 56, o3); o3 = dot2(Re, 48, 18, o3); o3 = dot2(Ro, 34, 0, o3);
+        const int y = y0 + j;
+        if (y < h && lane >= 1 && lane <= 62 && x < w)
+            *reinterpret_cast<uint32_t *>(dst + (uint64_t)y * G.pitch + x) = (o0 >> 16) | ((o1 >> 16) << 8) | ((o2 >> 16) << 16) | ((o3 >> 16) << 24);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // D1: FAST-9/16 corners + score + 3x3 strict NMS (this build's detector behind
-// feature_detector.cpp:89-98).  One launch covers every level of every frame.  Tile = 64x16.
-//   phase 1: every score position of the (16+2)x(64+2) halo tile tests the 16-pixel ring with two
-//            16-bit masks (brighter / darker) and a shift-and test for 9 contiguous bits; corners are
-//            compacted into an LDS list
-//   phase 2: the list is scored densely (sliding min / max of 9 over the circular ring)
-//   phase 3: 3x3 strict-maximum NMS on the LDS score tile; survivors leave as 32-bit keys
-//            ((255-score)<<24 | y*w+x) with ONE global atomic per tile
+// feature_detector.cpp:89-98).  One launch covers every level of every frame.
+// Tile = 248 x 14 outputs; 256 x 16 score positions (1 px NMS halo, rounded to dwords): small tiles keep
+// the LDS footprint at 12 KB so 8 workgroups (32 waves) share a CU -- the kernel is latency-bound (dependent loads,
+// five barriers, one returning atomic per tile), not ALU-bound, and needs the occupancy.
+//   phase A1  compass pre-test on EVERY position, in registers, two pixels per instruction: a lane owns
+//             one dword (4 pixels) of a row, the even/odd bytes are two 16-bit lanes; the sign bits of
+//             (centre+t - ring) and (ring - (centre-t)) are counted for the ring pixels N, S, E, W.
+//             An arc of 9 contiguous ring pixels always covers two of those four, so a pixel with fewer
+//             than two brighter AND fewer than two darker compass pixels cannot be a corner (exact
+//             reject).  Survivors are compacted into an LDS list.
+//   phase A2  dense over the survivors: full 16-pixel ring test with two 16-bit masks built by
+//             v_alignbit from sign bits, 9-contiguous test by shift-and; corners are scored in place
+//             (sliding min / max of 9 over the circular ring) into the LDS score tile
+//   phase C   3x3 strict-maximum NMS on the LDS score tile; survivors leave as 32-bit keys
+//             ((255-score)<<24 | y*w+x) with ONE global atomic per tile
+constexpr int kFastSeg = 248, kFastRows = 14, kFastPosRows = kFastRows + 2, kFastRowsPerWave = kFastPosRows / 4;
+
 __device__ __forceinline__ bool contig9(uint32_t m) {
     m |= m << 16;
     uint32_t r = m & (m >> 1);
@@ -181,85 +237,130 @@ __device__ __forceinline__ bool contig9(uint32_t m) {
     return r != 0;
 }
 
+__device__ __forceinline__ uint32_t load4_zero(const uint8_t *row, int x, int w) {
+    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (x + i >= 0 && x + i < w) d |= (uint32_t)row[x + i] << (8 * i);
+    return d;
+}
+
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
+}
+
+// counts of brighter / darker compass pixels, packed 16-bit lanes (pixels 0,2 in E, pixels 1,3 in O)
+struct Compass { uint32_t be, de, bo, dox; };
+__device__ __forceinline__ void compass_add(Compass &M, uint32_t W, uint32_t hie, uint32_t loe, uint32_t hio, uint32_t loo) {
+    const uint32_t re = W & 0x00FF00FFu, ro = (W >> 8) & 0x00FF00FFu;
+    M.be += (pk_sub(hie, re) >> 15) & 0x00010001u; M.de += (pk_sub(re, loe) >> 15) & 0x00010001u;
+    M.bo += (pk_sub(hio, ro) >> 15) & 0x00010001u; M.dox += (pk_sub(ro, loo) >> 15) & 0x00010001u;
+}
+
 __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
-    __shared__ uint8_t s_img[24][80];
-    __shared__ uint8_t s_sc[18][68];
-    __shared__ uint16_t s_list[18 * 66];
-    __shared__ uint32_t s_out[256];
-    __shared__ int s_n, s_m, s_base;
+    __shared__ uint8_t s_sc[kFastPosRows][264];
+    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPosRows * 256];   // compass survivors; reused as the NMS output buffer
+    __shared__ int s_np, s_m, s_base;
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2048 keys >= 124*7 possible NMS survivors
     const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     int t = blockIdx.x, l = 0;
     while (l + 1 < g->levels && t >= g->L[l + 1].ftile_base) ++l;
     t -= g->L[l].ftile_base;
     const LevelGeom &G = g->L[l];
-    const int x0 = (t % G.ftiles_x) * 64, y0 = (t / G.ftiles_x) * 16;
+    const int X0 = (t % G.ftiles_x) * kFastSeg, Y0 = (t / G.ftiles_x) * kFastRows;
     const int f = blockIdx.y, w = G.w, h = G.h, thr = g->fast_threshold;
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_n = 0; s_m = 0; }
-    for (int r = tid >> 6; r < 24; r += 4) {
-        const int y = y0 - 4 + r;
-        for (int c = tid & 63; c < 72; c += 64) {
-            const int x = x0 - 4 + c;
-            s_img[r][c] = (x >= 0 && y >= 0 && x < w && y < h) ? img[(uint64_t)y * pitch + x] : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_np = 0; s_m = 0; }
+    for (int i = tid; i < kFastPosRows * 264 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
+    __syncthreads();
+    // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
+    {
+        const int x = X0 - 4 + 4 * lane;
+        const uint32_t T2 = (uint32_t)thr * 0x00010001u;
+        // rows y-3 .. y+3+3 of the wave's 4 position rows: 10 loads issued together
+        uint32_t rows[kFastRowsPerWave + 6];
+        const int yw = Y0 - 1 + wave * kFastRowsPerWave;
+#pragma unroll
+        for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
+#pragma unroll
+        for (int r = 0; r < kFastRowsPerWave; ++r) {
+            const int pr = wave * kFastRowsPerWave + r, y = Y0 - 1 + pr;
+            if (y < 3 || y >= h - 3) continue;                           // wave-uniform
+            const uint32_t C = rows[r + 3], Cn = rows[r + 6], Cs = rows[r];
+            const uint32_t Lw = __shfl_up(C, 1, 64), Rw = __shfl_down(C, 1, 64);
+            const uint32_t ce = C & 0x00FF00FFu, co = (C >> 8) & 0x00FF00FFu;
+            const uint32_t hie = ce + T2, hio = co + T2, loe = pk_sub(ce, T2), loo = pk_sub(co, T2);
+            Compass M = {0, 0, 0, 0};
+            compass_add(M, Cn, hie, loe, hio, loo);                                       // (0,+3)
+            compass_add(M, Cs, hie, loe, hio, loo);                                       // (0,-3)
+            compass_add(M, __builtin_amdgcn_alignbyte(Rw, C, 3), hie, loe, hio, loo);     // (+3,0)
+            compass_add(M, __builtin_amdgcn_alignbyte(C, Lw, 1), hie, loe, hio, loo);     // (-3,0)
+            const uint32_t pe = ((M.be + 0x7FFE7FFEu) | (M.de + 0x7FFE7FFEu)) & 0x80008000u;   // count >= 2 -> bit 15 of the lane
+            const uint32_t po = ((M.bo + 0x7FFE7FFEu) | (M.dox + 0x7FFE7FFEu)) & 0x80008000u;
+            uint32_t flags = ((pe >> 15) & 1u) | ((po >> 14) & 2u) | ((pe >> 29) & 4u) | ((po >> 28) & 8u);   // pixel i -> bit i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 4 * lane + i, px = x + i;
+                if (!(c >= 3 && c <= 252 && px >= 3 && px < w - 3)) flags &= ~(1u << i);
+            }
+            if (flags) {
+                int pos = atomicAdd(&s_np, __popc(flags));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (flags & (1u << i)) s_pre[pos++] = (uint16_t)((pr << 8) | (4 * lane + i));
+            }
         }
     }
-    for (int i = tid; i < 18 * 68; i += 256) (&s_sc[0][0])[i] = 0;
     __syncthreads();
-    // phase 1
-    for (int p = tid; p < 18 * 66; p += 256) {
-        const int r = p / 66, c = p - r * 66;
-        const int x = x0 - 1 + c, y = y0 - 1 + r;
-        if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3) continue;
-        const int cv = s_img[r + 3][c + 3], hi = cv + thr, lo = cv - thr;
+    // ---- phase A2 + B: full ring test on the survivors; corners are scored in place (the 16 ring differences
+    //      are already in registers, and a second pass would cost another memory round trip + barrier)
+    const int np = s_np;
+    for (int i = tid; i < np; i += 256) {
+        const int e = s_pre[i], pr = e >> 8, c = e & 255;
+        const uint8_t *p = img + (uint64_t)(Y0 - 1 + pr) * pitch + (X0 - 4 + c);
+        const int cv = p[0];
+        int d[16];
         uint32_t mb = 0, md = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int v = s_img[r + 3 + rdy[k]][c + 3 + rdx[k]];
-            mb |= (uint32_t)(v > hi) << k;
-            md |= (uint32_t)(v < lo) << k;
+            d[k] = cv - (int)p[rdy[k] * pitch + rdx[k]];
+            mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(d[k] + thr), 31);   // ring brighter: d < -t  -> sign of d + t
+            md = __builtin_amdgcn_alignbit(md, (uint32_t)(thr - d[k]), 31);   // ring darker:   d >  t  -> sign of t - d
         }
-        if (contig9(mb) || contig9(md)) s_list[atomicAdd(&s_n, 1)] = (uint16_t)p;
+        if (contig9(mb & 0xFFFFu) || contig9(md & 0xFFFFu)) {
+            int mn[16], mx[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+            int mn4[16], mx4[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
+            int best = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+                const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+                best = max(best, max(m9, -x9));
+            }
+            s_sc[pr][c] = (uint8_t)best;          // a corner at threshold t has score > t by construction
+        }
     }
     __syncthreads();
-    // phase 2
-    const int n = s_n;
-    for (int i = tid; i < n; i += 256) {
-        const int p = s_list[i], r = p / 66, c = p - r * 66;
-        const int cv = s_img[r + 3][c + 3];
-        int d[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = cv - (int)s_img[r + 3 + rdy[k]][c + 3 + rdx[k]];
-        int mn[16], mx[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-        int mn4[16], mx4[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
-        int best = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-            const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-            best = max(best, max(m9, -x9));
-        }
-        s_sc[r][c] = (uint8_t)(best > thr ? best : 0);
-    }
-    __syncthreads();
-    // phase 3
-    {
-        const int r = tid >> 4, c4 = (tid & 15) * 4;
+    // ---- phase C: NMS over outputs px X0..X0+247 (columns 4..251), rows Y0..Y0+29 (position rows 1..30)
+    for (int item = tid; item < kFastRows * 62; item += 256) {
+        const int pr = 1 + item / 62, c4 = 4 + 4 * (item % 62);
+        const uint32_t sd = *reinterpret_cast<const uint32_t *>(&s_sc[pr][c4]);
+        if (sd == 0) continue;
+        const int y = Y0 - 1 + pr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = c4 + i, x = x0 + c, y = y0 + r;
-            const int s = s_sc[r + 1][c + 1];
-            if (s && x < w && y < h) {
-                const bool keep = s > s_sc[r][c] && s > s_sc[r][c + 1] && s > s_sc[r][c + 2] && s > s_sc[r + 1][c] &&
-                                  s > s_sc[r + 1][c + 2] && s > s_sc[r + 2][c] && s > s_sc[r + 2][c + 1] && s > s_sc[r + 2][c + 2];
-                if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - s) << 24) | (uint32_t)(y * w + x);
-            }
+            const int sc = (sd >> (8 * i)) & 255, c = c4 + i, px = X0 - 4 + c;
+            if (sc == 0 || px >= w || y >= h) continue;
+            const bool keep = sc > s_sc[pr - 1][c - 1] && sc > s_sc[pr - 1][c] && sc > s_sc[pr - 1][c + 1] && sc > s_sc[pr][c - 1] &&
+                              sc > s_sc[pr][c + 1] && sc > s_sc[pr + 1][c - 1] && sc > s_sc[pr + 1][c] && sc > s_sc[pr + 1][c + 1];
+            if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - sc) << 24) | (uint32_t)(y * w + px);
         }
     }
     __syncthreads();
@@ -267,9 +368,9 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     if (m == 0) return;
     if (tid == 0) s_base = atomicAdd(&cand_count[f * g->levels + l], m);
     __syncthreads();
-    if (tid < m) {
-        const int pos = s_base + tid;
-        if (pos < G.cand_cap) cand[(uint64_t)f * g->cand_stride + G.cand_off + pos] = s_out[tid];
+    for (int i = tid; i < m; i += 256) {
+        const int pos = s_base + i;
+        if (pos < G.cand_cap) cand[(uint64_t)f * g->cand_stride + G.cand_off + pos] = s_out[i];
     }
 }
 
@@ -506,12 +607,18 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     const uint8_t *ctr = img + (int64_t)y * pitch + x;
     // O1: moments
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
-        if (abs(u) <= g->umax[abs(v)]) {
-            const int I = ctr[(int64_t)v * pitch + u];
-            m10 += u * I; m01 += v * I;
+    {
+        int I[16], uu[16], vv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                 // 961 offsets of the 31x31 box over 64 lanes: 16 gathers in flight
+            const int i = lane + 64 * k;
+            const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
+            const bool in = i < 31 * 31 && abs(u) <= g->umax[min(abs(v), 15)];
+            uu[k] = in ? u : 0; vv[k] = in ? v : 0;
+            I[k] = ctr[(int64_t)vv[k] * pitch + uu[k]];
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { m10 += uu[k] * I[k]; m01 += vv[k] * I[k]; }
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle_deg = dev_fast_atan2((float)m01, (float)m10);
@@ -558,8 +665,8 @@ struct ms_orb {
     int32_t *d_octave = nullptr, *d_track = nullptr, *d_count = nullptr;
     uint32_t *d_desc = nullptr;
     // resize tables per level (device)
-    int16_t *d_xofs[MS_MAX_LEVELS] = {nullptr}, *d_xcoef[MS_MAX_LEVELS] = {nullptr};
-    int16_t *d_yofs[MS_MAX_LEVELS] = {nullptr}, *d_ycoef[MS_MAX_LEVELS] = {nullptr};
+    int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
+    bool wide[MS_MAX_LEVELS] = {false};
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
     hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
@@ -617,8 +724,8 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         L.blur_off = off; off += (uint64_t)L.pitch * L.h;
         L.cand_cap = ((w[l] + 1) / 2) * ((h[l] + 1) / 2) + 256;   // strict 3x3 maxima: <= one per 2x2 block
         L.cand_off = coff; coff += L.cand_cap;
-        L.btiles_x = ms_div_up(w[l], 128); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 16);
-        L.ftiles_x = ms_div_up(w[l], 64); L.ftile_base = ft; ft += L.ftiles_x * ms_div_up(h[l], 16);
+        L.btiles_x = ms_div_up(w[l], kBlurSeg); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 16);
+        L.ftiles_x = ms_div_up(w[l], kFastSeg); L.ftile_base = ft; ft += L.ftiles_x * ms_div_up(h[l], kFastRows);
     }
     G.btiles_total = bt; G.ftiles_total = ft;
     G.slab_stride = ms_align_up(off, 256); G.cand_stride = coff;
@@ -648,12 +755,20 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         std::vector<int16_t> xo, xc, yo, yc;
         msgeo::resize_tables(w[l - 1], w[l], true, xo, xc);
         msgeo::resize_tables(h[l - 1], h[l], false, yo, yc);
+        std::vector<int16_t> xt(4 * (size_t)w[l]), yt(4 * (size_t)h[l]);
+        for (int d = 0; d < w[l]; ++d) { xt[4 * d] = xo[d]; xt[4 * d + 1] = xc[2 * d]; xt[4 * d + 2] = xc[2 * d + 1]; xt[4 * d + 3] = 0; }
+        for (int d = 0; d < h[l]; ++d) {      // clip(sy, 0, ssize.height) applied to both tap rows
+            yt[4 * d] = (int16_t)std::min(std::max((int)yo[d], 0), h[l - 1] - 1);
+            yt[4 * d + 1] = (int16_t)std::min(std::max((int)yo[d] + 1, 0), h[l - 1] - 1);
+            yt[4 * d + 2] = yc[2 * d]; yt[4 * d + 3] = yc[2 * d + 1];
+        }
+        for (int d = 0; d + 3 < w[l]; d += 4) if (xo[d + 3] + 1 - xo[d] > 7) o->wide[l] = true;   // taps beyond an 8-byte window
         auto up = [&](int16_t **d, const std::vector<int16_t> &v) {
             if (rc != MS_OK) return;
             if (hipMalloc(reinterpret_cast<void **>(d), v.size() * 2) != hipSuccess ||
                 hipMemcpy(*d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = MS_ERR_HIP;
         };
-        up(&o->d_xofs[l], xo); up(&o->d_xcoef[l], xc); up(&o->d_yofs[l], yo); up(&o->d_ycoef[l], yc);
+        up(&o->d_xtab[l], xt); up(&o->d_ytab[l], yt);
     }
     if (rc == MS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
     if (rc != MS_OK) { ms_orb_destroy(o); return ms_fail(ctx, rc, "ms_orb_create: device allocation failed"); }
@@ -671,10 +786,8 @@ void ms_orb_destroy(ms_orb *o) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
-        if (o->d_xofs[l]) (void)hipFree(o->d_xofs[l]);
-        if (o->d_xcoef[l]) (void)hipFree(o->d_xcoef[l]);
-        if (o->d_yofs[l]) (void)hipFree(o->d_yofs[l]);
-        if (o->d_ycoef[l]) (void)hipFree(o->d_ycoef[l]);
+        if (o->d_xtab[l]) (void)hipFree(o->d_xtab[l]);
+        if (o->d_ytab[l]) (void)hipFree(o->d_ytab[l]);
     }
     delete o;
 }
@@ -754,7 +867,9 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     MS_STAGE_MARK();
     for (int l = 1; l < G.levels; ++l) {
         dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4), n_frames);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, src, o->d_geom, l, o->d_xofs[l], o->d_xcoef[l], o->d_yofs[l], o->d_ycoef[l]);
+        const ResizeTab T{o->d_xtab[l], o->d_ytab[l]};
+        if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, src, o->d_geom, l, T);
+        else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, src, o->d_geom, l, T);
         MS_KERNEL_CHECK(c, "k_resize");
     }
     MS_STAGE_MARK();

@@ -96,7 +96,7 @@ def test_random_noise_saturates_quota(oracle, ctx):
 
 
 def test_odd_sizes_and_thresholds(oracle, ctx):
-    for (w, h, thr, levels, sf) in [(331, 257, 10, 5, 1.2), (200, 120, 35, 3, 1.5), (97, 83, 20, 2, 1.1)]:
+    for (w, h, thr, levels, sf) in [(331, 257, 10, 5, 1.2), (200, 120, 35, 3, 1.5), (97, 83, 20, 2, 1.1), (400, 300, 20, 2, 2.5), (250, 250, 15, 3, 2.0)]:
         img = oracle.synth_frame(w, h, 5 + w)
         _, got, want = _extract_both(oracle, ctx, img[None], levels=levels, scale_factor=sf, fast_threshold=thr, max_kpts=700)
         _assert_same_keypoints(got[0], want[0])
