@@ -123,14 +123,11 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from mi355slam import shard
+    frames_total, dt = shard.aggregate(dist if world > 1 else None, torch, BATCH * args.steps, dt, device="cuda")
 
     n_kp = np.frombuffer(ctx_download(ctx, view.count, 4 * BATCH), dtype=np.int32)
     n_match = int((match.view(BATCH, cap) >= 0).sum().item())
-    frames_total = BATCH * args.steps * world
     value = frames_total / dt
 
     # ---- roofline of the dominant kernel (algorithmic bytes per launch, SURVEY 8d / DESIGN.md) ----
@@ -193,10 +190,8 @@ def bench_ba(ctx, args, world, rank, dist, torch):
         dist.barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ctx.event_elapsed_ms(2, 3) / args.ba_steps
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from mi355slam import shard
+    solves_total, dt = shard.aggregate(dist, torch, args.ba_batch * args.ba_steps, dt, device="cuda")
     st = ba.download(0)["stats"]
     # single-window latency (one workgroup on one CU)
     one = mi355slam.BundleAdjuster(ctx, probs[:1], max_iters=10)
@@ -204,7 +199,7 @@ def bench_ba(ctx, args, world, rank, dist, torch):
     ctx.event_mark(4); one.solve(); ctx.event_mark(5)
     single_ms = ctx.event_elapsed_ms(4, 5)
     alg_bytes_per_solve = 6.61e6 * st["iters"]               # 6.61 MB per LM iteration at C4
-    res = {"metric": "local-BA solves/sec (50 KF x 2000 pts x 20k obs, 10 LM iters)", "value": round(args.ba_batch * args.ba_steps * world / dt, 1),
+    res = {"metric": "local-BA solves/sec (50 KF x 2000 pts x 20k obs, 10 LM iters)", "value": round(solves_total / dt, 1),
            "unit": "solves/s", "windows_per_launch": args.ba_batch, "ms_per_launch": round(kernel_ms, 3), "lm_iterations": st["iters"],
            "lm_trials": st["trials"], "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
            "alg_GBs": round(alg_bytes_per_solve * args.ba_batch / (kernel_ms * 1e-3) / 1e9, 1), "dtype": "f64"}

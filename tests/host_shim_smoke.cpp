@@ -1,0 +1,51 @@
+// Compile + link check of the host-side C++ mirrors against libmi355slam.so; when a GPU is present it also runs one
+// extraction, one triangulation match and one two-stage local BA end to end (used by tests/test_host_shims.py).
+#include <cstdio>
+#include <cmath>
+#include "mi355slam/orb_extractor.hpp"
+#include "mi355slam/keyframe_matcher.hpp"
+#include "mi355slam/bundle_adjuster.hpp"
+
+using namespace mi355slam;
+
+int main(int argc, char **argv) {
+    Parameters params;
+    params.maxTracks = 16;
+    StaticSettings settings(params);
+    if (settings.maxNumberOfKeypointsPerLevel().front() != 434) { std::printf("quota mismatch\n"); return 2; }
+    if (argc > 1 && std::string(argv[1]) == "--no-gpu") { std::printf("link ok\n"); return 0; }
+    Context ctx(0);
+    const int W = 320, H = 240;
+    std::vector<std::uint8_t> img((std::size_t)W * H);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) img[(std::size_t)y * W + x] = (std::uint8_t)(((x / 16 + y / 16) & 1) ? 200 : 40);
+    auto extractor = OrbExtractor::build(ctx, settings);
+    KeyPointVector kps; std::vector<int> ids;
+    extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, nullptr, {TrackPoint{100.f, 100.f, 7}}, kps, ids);
+    std::printf("keypoints %zu (first track id %d)\n", kps.size(), ids.empty() ? -99 : ids[0]);
+    if (kps.size() < 50 || ids[0] != 7) return 3;
+    // match the frame against itself through the triangulation matcher (identity geometry -> epipolar residual is 0/0 guarded by E != 0)
+    for (auto &kp : kps) { kp.bearing = {(kp.pt.x - W / 2) / 300.0, (kp.pt.y - H / 2) / 300.0, 1.0}; }
+    KeyframeFeatures f; f.keyPoints = &kps; f.usable.assign(kps.size(), 1);
+    for (unsigned i = 0; i < kps.size(); ++i) f.bowFeatureVec[kps[i].descriptor[0] % 10].push_back(i);
+    DeviceKeyframe d1(ctx, f), d2(ctx, f);
+    const double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t1[3] = {0, 0, 0}, t2[3] = {0.1, 0, 0};
+    double E[9]; create_E_21(R, t2, R, t1, E);
+    auto matches = matchForTriangulationDBoW(ctx, d1, d2, E, settings);
+    std::printf("triangulation matches %zu\n", matches.size());
+    // a tiny two-stage local BA: 3 cameras on a line looking at 30 points
+    BaWindow w; w.currentKeyframe = 2;
+    for (int i = 0; i < 3; ++i) w.poses.push_back({0, 0, 0, 1, -0.2 * i, 0, 0});
+    for (int l = 0; l < 30; ++l) w.points.push_back({-1.0 + 0.07 * l, 0.3 * std::sin(l), 5.0 + 0.05 * l});
+    for (int l = 0; l < 30; ++l) for (int i = 0; i < 3; ++i) {
+        const double X = w.points[l][0] - 0.2 * i, Y = w.points[l][1], Z = w.points[l][2];
+        w.obsPose.push_back(i); w.obsPoint.push_back(l); w.obsUv.push_back({X / Z + 1e-3 * std::sin(l + i), Y / Z}); w.obsInfo.push_back(250000.0);
+    }
+    for (int i = 1; i < 3; ++i) { w.edgeI.push_back(i); w.edgeJ.push_back(i - 1); w.edgeMeas.push_back({0, 0, 0, 1, 0.2, 0, 0});
+        std::array<double, 36> info{}; for (int k = 0; k < 6; ++k) info[7 * k] = 1e4; w.edgeInfo.push_back(info); }
+    BaOutcome o = localBundleAdjust(ctx, w, 50, params);
+    std::printf("BA stage1 chi2 %.3f -> %.3f, stage2 -> %.3f, iterations %d/%d\n", o.stage1.chi2_initial, o.stage1.chi2_final, o.stage2.chi2_final,
+                o.stage1.iterations, o.stage2.iterations);
+    if (!(o.stage2.chi2_final <= o.stage1.chi2_initial)) return 4;
+    std::printf("host shims ok\n");
+    return 0;
+}
