@@ -32,10 +32,9 @@ namespace {
 constexpr int NT = 512;          // threads per problem
 constexpr int NW = NT / 64;      // waves
 constexpr int NB = 16;           // Cholesky panel width
-constexpr int KC = 64;           // k-chunk of the left-looking update
-constexpr int TMAX = 24;         // panel elements per thread: (n6+1)*NB/NT <= TMAX  -> n6 <= 767
+constexpr int CH = 32;           // Schur work items (pairs of observations of one point) per chunk
 constexpr int kMaxFreePoses = 96;
-constexpr size_t kLdsBytes = 150 * 1024;
+constexpr size_t kLdsBytes = 80 * 1024;   // Cholesky panel: (6*96+1) rows x 16 doubles + scratch
 
 struct BaProb {
     int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters, pad_;
@@ -50,12 +49,19 @@ struct BaProb {
     const int32_t *pt_start, *pt_obs;        // observations grouped by point
     const int32_t *fstart, *fobs;            // observations grouped by FREE pose index
     const int32_t *free2pose;                // free index -> pose vertex
+    // Schur work list: pairs (a,b) of observations of one free point with free poses fb <= fa, sorted by (fa,fb),
+    // cut into chunks of CH items of the same pose pair (padding = -1); segments = runs of chunks of one pair
+    int32_t n_chunks, n_seg;
+    const int32_t *chunk_items;              // [n_chunks*CH*2]
+    const int32_t *seg_start, *seg_pair;     // [n_seg+1], [n_seg] (fa<<16 | fb)
     const int32_t *edge_i, *edge_j;
     const double *edge_meas, *edge_info;
     // work
-    double *Hpp, *S, *bp, *dp, *y, *Hll, *bl, *Hinv, *Hpl, *dl, *chi2_obs;
+    double *Hpp, *S, *bp, *dp, *y, *Hll, *bl, *Hinv, *Hpl, *dl, *chi2_obs, *Y;
+    const double *zrow;                      // n6 + 16 zeros
     // results
-    double *stats;                           // [8]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -
+    double *stats;                           // [16]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -, then cycles per phase:
+                                             //       8 eval, 9 linearise, 10 Schur, 11 Cholesky+backsub, 12 points+update, 13 total
 };
 
 // ---------------------------------------------------------------- SE3 helpers (g2o / Eigen conventions)
@@ -333,44 +339,55 @@ __device__ void build_system(const BaProb &P) {
         }
     }
     __syncthreads();
-    // EdgeSE3Expmap edges: few, coupled -> one wave, edges in order, lanes over the 6x6 block entries
-    if (wave == 0) {
-        for (int k = 0; k < P.n_edge; ++k) {
-            const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
-            if (fi < 0 && fj < 0) continue;
-            double e[6], Ji[36], Jj[36];
-            pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
-            const double *W = P.edge_info + 36 * (size_t)k;
-            if (lane < 36) {
-                const int a = lane / 6, b = lane % 6;
-                for (int s = 0; s < 2; ++s) {
-                    const int fs = s ? fj : fi;
-                    if (fs < 0) continue;
-                    const double *Js = s ? Jj : Ji;
-                    for (int t = 0; t < 2; ++t) {
-                        const int ft = t ? fj : fi;
-                        if (ft < 0) continue;
-                        const double *Jt = t ? Jj : Ji;
-                        double v = 0;
-                        for (int r2 = 0; r2 < 6; ++r2) for (int c2 = 0; c2 < 6; ++c2) v += Js[6 * r2 + a] * W[6 * r2 + c2] * Jt[6 * c2 + b];
-                        P.Hpp[(size_t)(6 * fs + a) * n6 + 6 * ft + b] += v;
-                    }
-                    if (b == 0) {
-                        double v = 0;
-                        for (int r2 = 0; r2 < 6; ++r2) { double we = 0; for (int c2 = 0; c2 < 6; ++c2) we += W[6 * r2 + c2] * e[c2]; v += Js[6 * r2 + a] * (-we); }
-                        P.bp[6 * fs + a] += v;
-                    }
+    // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior): one thread per edge, contributions
+    // added with fp64 atomics (a handful of edges; neighbouring edges share a pose block)
+    for (int k = tid; k < P.n_edge; k += NT) {
+        const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
+        if (fi < 0 && fj < 0) continue;
+        double e[6], Ji[36], Jj[36], We[6];
+        pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+        const double *W = P.edge_info + 36 * (size_t)k;
+        for (int a = 0; a < 6; ++a) { double v = 0; for (int b = 0; b < 6; ++b) v += W[6 * a + b] * e[b]; We[a] = -v; }
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int fs = sidx ? fj : fi;
+            if (fs < 0) continue;
+            const double *Js = sidx ? Jj : Ji;
+            for (int a = 0; a < 6; ++a) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + a] * We[r2]; atomicAdd(&P.bp[6 * fs + a], v); }
+            for (int tidx = 0; tidx < 2; ++tidx) {
+                const int ft = tidx ? fj : fi;
+                if (ft < 0) continue;
+                const double *Jt = tidx ? Jj : Ji;
+                double M[36];                                   // W * Jt
+                for (int r2 = 0; r2 < 6; ++r2) for (int b = 0; b < 6; ++b) { double v = 0; for (int c2 = 0; c2 < 6; ++c2) v += W[6 * r2 + c2] * Jt[6 * c2 + b]; M[6 * r2 + b] = v; }
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
+                    double v = 0;
+                    for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + a] * M[6 * r2 + b];
+                    atomicAdd(&P.Hpp[(size_t)(6 * fs + a) * n6 + 6 * ft + b], v);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
     __syncthreads();
 }
 
+__device__ __forceinline__ void schur_fetch(const int32_t *chunk_items, const double *Y, const double *Hpl, int ch, int lane, double2 (&v)[9]) {
+    const int2 *items = reinterpret_cast<const int2 *>(chunk_items) + (size_t)ch * CH;
+    int2 ab[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ab[k] = items[(lane + 64 * k) / 18];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int piece = (lane + 64 * k) % 18;
+        v[k] = double2{0.0, 0.0};
+        if (ab[k].x >= 0) v[k] = piece < 9 ? reinterpret_cast<const double2 *>(Y + 18 * (size_t)ab[k].x)[piece]
+                                           : reinterpret_cast<const double2 *>(Hpl + 18 * (size_t)ab[k].y)[piece - 9];
+    }
+}
+
 // ---------------------------------------------------------------- damped solve
 // Returns false (uniformly) when a pivot is not positive / a point block is singular.
-__device__ bool solve_step(const BaProb &P, double lambda, double *lds, int *s_flag) {
+__device__ bool solve_step(const BaProb &P, double lambda, double *lds, int *s_flag, long long *cyc) {
+    long long t0 = clock64();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6;
     if (tid == 0) *s_flag = 1;
     __syncthreads();
@@ -387,89 +404,133 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, int *s_f
         Hi[0] = A * id; Hi[1] = B * id; Hi[2] = C * id; Hi[3] = (a * f - c * c) * id; Hi[4] = (b * c - a * e) * id; Hi[5] = (a * d - b * b) * id;
     }
     __syncthreads();
-    // Schur complement, row panels of S accumulated in LDS
-    {
-        const size_t row_bytes = (size_t)6 * n * sizeof(double);
-        int R = (int)((kLdsBytes - 8192) / (row_bytes ? row_bytes : 1));
-        R = max(1, min(R, P.np_free));
-        double *panel = lds;                 // [R*6][n]
-        double *prhs = lds + (size_t)R * 6 * n;   // [R*6]
-        for (int p0 = 0; p0 < P.np_free; p0 += R) {
-            const int pe = min(p0 + R, P.np_free), rows = (pe - p0) * 6;
-            for (int i = tid; i < rows * n + rows; i += NT) panel[i] = 0;    // panel and prhs are contiguous
-            __syncthreads();
-            for (int ii = P.fstart[p0] + tid; ii < P.fstart[pe]; ii += NT) {
-                const int a = P.fobs[ii], l = P.obs_point[a];
-                if (P.point_fixed && P.point_fixed[l]) continue;
-                const int fa = P.pidx[P.obs_pose[a]], rb = (fa - p0) * 6;
-                const double *Wa = P.Hpl + 18 * (size_t)a, *h = P.Hinv + 6 * (size_t)l, *bl = P.bl + 3 * (size_t)l;
-                const double Hm[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
-                double Y[18];
+    // Schur complement S = Hpp + lambda I - sum_l Hpl (Hll + lambda I)^-1 Hpl^T (lower block triangle), rhs y = bp - sum Y bl.
+    // Deterministic and atomic-free: every (pose pair) block is the ordered sum of per-chunk partial blocks.
+    for (int o = tid; o < P.n_obs; o += NT) {                         // Y_o = Hpl_o * Hinv_l
+        const int l = P.obs_point[o];
+        if (P.pidx[P.obs_pose[o]] < 0 || (P.point_fixed && P.point_fixed[l])) continue;
+        const double *W = P.Hpl + 18 * (size_t)o, *h = P.Hinv + 6 * (size_t)l;
+        const double Hm[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
+        double *Yo = P.Y + 18 * (size_t)o;
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Hm[c] + Wa[3 * r + 1] * Hm[3 + c] + Wa[3 * r + 2] * Hm[6 + c];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) atomicAdd(&prhs[rb + r], Y[3 * r] * bl[0] + Y[3 * r + 1] * bl[1] + Y[3 * r + 2] * bl[2]);
-                for (int jj = P.pt_start[l]; jj < P.pt_start[l + 1]; ++jj) {
-                    const int b = P.pt_obs[jj], fb = P.pidx[P.obs_pose[b]];
-                    if (fb < 0 || fb > fa) continue;                       // lower triangle only
-                    const double *Wb = P.Hpl + 18 * (size_t)b;
-                    double wb[18];
-#pragma unroll
-                    for (int q = 0; q < 18; ++q) wb[q] = Wb[q];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int c = 0; c < 6; ++c)
-                            atomicAdd(&panel[(size_t)(rb + r) * n + 6 * fb + c], Y[3 * r] * wb[3 * c] + Y[3 * r + 1] * wb[3 * c + 1] + Y[3 * r + 2] * wb[3 * c + 2]);
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < rows * n; i += NT) {
-                const int r = i / n, c = i - r * n, gr = p0 * 6 + r;
-                if (c / 6 <= gr / 6) P.S[(size_t)gr * n + c] = P.Hpp[(size_t)gr * n + c] + (c == gr ? lambda : 0.0) - panel[i];
-            }
-            for (int i = tid; i < rows; i += NT) P.y[p0 * 6 + i] = P.bp[p0 * 6 + i] - prhs[i];
-            __syncthreads();
+            for (int c = 0; c < 3; ++c) Yo[3 * r + c] = W[3 * r] * Hm[c] + W[3 * r + 1] * Hm[3 + c] + W[3 * r + 2] * Hm[6 + c];
+    }
+    {   // S = Hpp + lambda I on the lower block triangle: thread = (row, 64-column strip), 4 loads in flight
+        const double *__restrict__ Hp = P.Hpp;
+        double *__restrict__ Sp0 = P.S;
+        const int strips = (n + 63) / 64;
+        for (int w = tid >> 6; w < n * strips; w += NW) {
+            const int r = w / strips, c = (w - r * strips) * 64 + (tid & 63);
+            if (c < n && c / 6 <= r / 6) Sp0[(size_t)r * n + c] = Hp[(size_t)r * n + c] + (c == r ? lambda : 0.0);
         }
     }
+    __syncthreads();
+    cyc[5] += clock64() - t0;
+    for (int fp = wave; fp < P.np_free; fp += NW) {                   // rhs: fixed-order wave reduction per pose
+        double gsum[6] = {0, 0, 0, 0, 0, 0};
+        for (int ii = P.fstart[fp] + lane; ii < P.fstart[fp + 1]; ii += 64) {
+            const int o = P.fobs[ii], l = P.obs_point[o];
+            if (P.point_fixed && P.point_fixed[l]) continue;
+            const double *Yo = P.Y + 18 * (size_t)o, *bl = P.bl + 3 * (size_t)l;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) gsum[r] += Yo[3 * r] * bl[0] + Yo[3 * r + 1] * bl[1] + Yo[3 * r + 2] * bl[2];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) gsum[r] = wave_sum_d(gsum[r]);
+        if (lane < 6) P.y[6 * fp + lane] = P.bp[6 * fp + lane] - gsum[lane];
+    }
+    __syncthreads();
+    cyc[6] += clock64() - t0;
+    // One wave per pose-pair segment.  Per chunk of 32 items the wave stages the 32 Y_a and 32 Hpl_b records
+    // (144 B each) into its private LDS slab with coalesced 16-byte pieces (9 lanes per record), then lane
+    // (t = lane/2, half = lane%2) multiplies item t's record pair into 18 of the 36 block entries and keeps the
+    // running sum in registers across the segment's chunks; one fixed-order butterfly over t ends the segment.
+    {
+        double *stage = lds + (size_t)wave * (CH * 36);              // [32 items][18 Y | 18 W]
+        const int32_t *chunk_items = P.chunk_items;
+        const double *Yp = P.Y, *Hplp = P.Hpl;
+        double *Sp = P.S;
+        for (int seg = wave; seg < P.n_seg; seg += NW) {
+            double acc[18];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) acc[q] = 0;
+            const int t = lane >> 1, half = lane & 1;
+            // software pipeline: the 9 record pieces of chunk ch+1 are in flight while chunk ch is multiplied
+            const int ch_end = P.seg_start[seg + 1];
+            double2 cur[9], nxt[9];
+            schur_fetch(chunk_items, Yp, Hplp, P.seg_start[seg], lane, cur);
+            for (int ch = P.seg_start[seg]; ch < ch_end; ++ch) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) reinterpret_cast<double2 *>(stage)[lane + 64 * k] = cur[k];
+                if (ch + 1 < ch_end) schur_fetch(chunk_items, Yp, Hplp, ch + 1, lane, nxt);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const double *rec = stage + t * 36;
+                double ya[9], wb[18];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) ya[q] = rec[9 * half + q];           // rows 3*half .. 3*half+2 of Y
+#pragma unroll
+                for (int q = 0; q < 18; ++q) wb[q] = rec[18 + q];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) acc[6 * r + c] += ya[3 * r] * wb[3 * c] + ya[3 * r + 1] * wb[3 * c + 1] + ya[3 * r + 2] * wb[3 * c + 2];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
+            }
+#pragma unroll
+            for (int q = 0; q < 18; ++q) {
+#pragma unroll
+                for (int off = 2; off < 64; off <<= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+            }
+            if (lane < 2) {                                           // lane = half: rows 3*half .. 3*half+2 of the block
+                const int fa = P.seg_pair[seg] >> 16, fb = P.seg_pair[seg] & 0xFFFF;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Sp[(size_t)(6 * fa + 3 * half + r) * n + 6 * fb + c] -= acc[6 * r + c];
+            }
+        }
+    }
+    __syncthreads();
+    { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
     // blocked left-looking Cholesky of S (lower), rhs y carried as row n
     {
         double *pan = lds;                              // [(n+1)][NB]
-        double *Lc = lds + (size_t)(n + 1) * NB;        // [NB][KC+1]
-        double *tvec = Lc + NB * (KC + 1);              // [NB]
+        double *tvec = lds + (size_t)(n + 1) * NB;      // [NB]
+        typedef double d4_t __attribute__((ext_vector_type(4)));
         for (int c0 = 0; c0 < n; c0 += NB) {
             const int nb = min(NB, n - c0), m = n - c0 + 1, cnt = m * NB;
-            double acc[TMAX];
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t) acc[t] = 0;
-            for (int kk = 0; kk < c0; kk += KC) {
-                const int kc = min(KC, c0 - kk);
-                __syncthreads();
-                for (int i = tid; i < NB * KC; i += NT) { const int j = i / KC, k = i - j * KC; Lc[j * (KC + 1) + k] = (j < nb && k < kc) ? P.S[(size_t)(c0 + j) * n + kk + k] : 0.0; }
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < TMAX; ++t) {
-                    const int idx = tid + t * NT;
-                    if (idx < cnt) {
-                        const int i = idx / NB, j = idx - i * NB;
-                        const double *rowp = (c0 + i < n) ? P.S + (size_t)(c0 + i) * n + kk : P.y + kk;
-                        const double *lc = Lc + j * (KC + 1);
-                        double s = 0;
-                        for (int k = 0; k < kc; ++k) s += rowp[k] * lc[k];
-                        acc[t] += s;
-                    }
+            // left-looking update of the 16-column panel with the finished columns [0, c0): a dense
+            // (m x c0)(c0 x 16) product -> v_mfma_f64_16x16x4_f64, one 16-row tile per wave, operands straight
+            // from L2 (each lane streams 4 consecutive doubles of its A row and of its B row per 16-k chunk;
+            // the k order inside a chunk is permuted identically for A and B, which leaves the sum unchanged)
+            for (int rt = wave; rt * 16 < m; rt += NW) {
+                const int ia = rt * 16 + (lane & 15), q = lane >> 4, jb = lane & 15;
+                // rows beyond the matrix / columns beyond the panel read a zero row, so the loads need no guards and
+                // four k-chunks (16 double2 loads) can be in flight per MFMA group
+                const double *arow = (c0 + ia < n) ? P.S + (size_t)(c0 + ia) * n : (c0 + ia == n ? P.y : P.zrow);
+                const double *brow = (jb < nb) ? P.S + (size_t)(c0 + jb) * n : P.zrow;
+                const double2 *ap = reinterpret_cast<const double2 *>(arow + 4 * q), *bp2 = reinterpret_cast<const double2 *>(brow + 4 * q);
+                d4_t acc = {0, 0, 0, 0};
+                for (int kk = 0; kk < c0; kk += 16) {
+                    const double2 a01 = ap[kk / 2], a23 = ap[kk / 2 + 1], b01 = bp2[kk / 2], b23 = bp2[kk / 2 + 1];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc, 0, 0, 0);
                 }
-            }
-            __syncthreads();
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) {
-                const int idx = tid + t * NT;
-                if (idx < cnt) {
-                    const int i = idx / NB, j = idx - i * NB;
-                    const double v = (j < nb) ? ((c0 + i < n) ? P.S[(size_t)(c0 + i) * n + c0 + j] : P.y[c0 + j]) : 0.0;
-                    pan[idx] = v - acc[t];
+                for (int reg = 0; reg < 4; ++reg) {       // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg, col = lane&15
+                    const int ii = rt * 16 + (lane >> 4) + 4 * reg, j = lane & 15;
+                    if (ii < m) {
+                        const double v = (j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
+                        pan[ii * NB + j] = v - acc[reg];
+                    }
                 }
             }
             __syncthreads();
@@ -535,6 +596,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, int *s_f
             __syncthreads();
         }
     }
+    { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
     const bool ok = *s_flag != 0;
     __syncthreads();
     if (!ok) return false;
@@ -558,6 +620,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, int *s_f
         d[2] = h[2] * r[0] + h[4] * r[1] + h[5] * r[2];
     }
     __syncthreads();
+    cyc[4] += clock64() - t0;
     return true;
 }
 
@@ -566,7 +629,7 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
     __shared__ double s_red[NW];
     __shared__ int s_flag;
     __shared__ double s_ctl[4];
-    const BaProb P = probs[blockIdx.x];
+    const BaProb &P = probs[blockIdx.x];      // fields stay in constant memory: uniform scalar loads, no private copy
     const int tid = threadIdx.x, n6 = P.n6;
     // restart from the initial estimates
     for (int i = tid; i < 7 * P.n_pose; i += NT) P.pose[i] = P.pose0[i];
@@ -574,10 +637,15 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
     __syncthreads();
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, stop = 0;
+    long long cyc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = clock64();
     const double chi2_init = eval_chi2(P, s_red, false);
     for (it = 0; it < P.max_iters; ++it) {
+        long long tt = clock64();
         double current = eval_chi2(P, s_red, false), temp = current;
+        { const long long t1 = clock64(); cyc[0] += t1 - tt; tt = t1; }
         build_system(P);
+        cyc[1] += clock64() - tt;
         if (it == 0) {                                   // computeLambdaInit
             double md = 0;
             for (int i = tid; i < n6; i += NT) md = fmax(md, fabs(P.Hpp[(size_t)i * n6 + i]));
@@ -591,7 +659,8 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
             for (int i = tid; i < 7 * P.n_pose; i += NT) P.pose_bk[i] = P.pose[i];          // push()
             for (int i = tid; i < 3 * P.n_point; i += NT) P.point_bk[i] = P.point[i];
             __syncthreads();
-            const bool ok2 = solve_step(P, lambda, lds, &s_flag);
+            const bool ok2 = solve_step(P, lambda, lds, &s_flag, cyc);
+            tt = clock64();
             if (ok2) {
                 for (int fp = tid; fp < P.np_free; fp += NT) {
                     const int pi = P.free2pose[fp];
@@ -603,7 +672,9 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
                 for (int i = tid; i < 3 * P.n_point; i += NT) P.point[i] += P.dl[i];
                 __syncthreads();
             }
+            cyc[4] += clock64() - tt; tt = clock64();
             temp = ok2 ? eval_chi2(P, s_red, false) : DBL_MAX;
+            cyc[0] += clock64() - tt;
             double sc = 0;
             if (ok2) {
                 for (int i = tid; i < n6; i += NT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
@@ -631,6 +702,8 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
     if (tid == 0) {
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = chi2_final;
         P.stats[6] = isfinite(chi2_final) ? 1 : 0; P.stats[7] = 0;
+        for (int k = 0; k < 5; ++k) P.stats[8 + k] = (double)cyc[k];
+        P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5]; P.stats[15] = (double)cyc[6];
     }
     (void)s_ctl;
 }
@@ -657,12 +730,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs; int np_free = 0; };
+    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair; int np_free = 0, n_chunks = 0, n_seg = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow; };
     std::vector<Off> off(n);
     for (int p = 0; p < n; ++p) {
         const ms_ba_problem &Q = problems[p];
@@ -672,7 +745,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         Prep &R = prep[p];
         R.pidx.assign(Q.n_pose, -1);
         for (int i = 0; i < Q.n_pose; ++i) if (!Q.pose_fixed[i]) { R.pidx[i] = R.np_free++; R.free2pose.push_back(i); }
-        if (R.np_free > kMaxFreePoses) return ms_fail(c, MS_ERR_CAPACITY, "ms_ba_create: %d free poses (max %d in this version)", R.np_free, kMaxFreePoses);
+        if (R.np_free > kMaxFreePoses || R.np_free > 65535) return ms_fail(c, MS_ERR_CAPACITY, "ms_ba_create: %d free poses (max %d in this version)", R.np_free, kMaxFreePoses);
         for (int o = 0; o < Q.n_obs; ++o)
             if (Q.obs_pose[o] < 0 || Q.obs_pose[o] >= Q.n_pose || Q.obs_point[o] < 0 || Q.obs_point[o] >= Q.n_point)
                 return ms_fail(c, MS_ERR_INVALID, "ms_ba_create: observation %d of problem %d indexes outside the problem", o, p);
@@ -689,6 +762,46 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int f = 0; f < R.np_free; ++f) R.fstart[f + 1] += R.fstart[f];
         R.fobs.resize(R.fstart[R.np_free]);
         { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
+        {   // Schur work list: for every free point, every ordered pair (a, b) of its observations with free poses fb <= fa,
+            // counting-sorted by (fa, fb), then cut into chunks of CH items of one pose pair
+            const int np = R.np_free;
+            std::vector<int32_t> count((size_t)np * np + 1, 0);
+            auto for_items = [&](auto &&fn) {
+                for (int l = 0; l < Q.n_point; ++l) {
+                    if (Q.point_fixed && Q.point_fixed[l]) continue;
+                    for (int ia = R.pt_start[l]; ia < R.pt_start[l + 1]; ++ia) {
+                        const int a = R.pt_obs[ia], fa = R.pidx[Q.obs_pose[a]];
+                        if (fa < 0) continue;
+                        for (int ib = R.pt_start[l]; ib < R.pt_start[l + 1]; ++ib) {
+                            const int b = R.pt_obs[ib], fb = R.pidx[Q.obs_pose[b]];
+                            if (fb < 0 || fb > fa) continue;
+                            fn(fa * np + fb, a, b);
+                        }
+                    }
+                }
+            };
+            for_items([&](int key, int, int) { count[key + 1]++; });
+            std::vector<int32_t> kstart(count);
+            for (size_t k = 1; k < kstart.size(); ++k) kstart[k] += kstart[k - 1];
+            std::vector<int32_t> sorted(2 * (size_t)kstart.back()), cur(kstart.begin(), kstart.end() - 1);
+            for_items([&](int key, int a, int b) { const int pos = cur[key]++; sorted[2 * (size_t)pos] = a; sorted[2 * (size_t)pos + 1] = b; });
+            R.seg_start.push_back(0);
+            for (int key = 0; key < np * np; ++key) {
+                const int lo = kstart[key], hi = kstart[key + 1];
+                if (hi == lo) continue;
+                for (int i = lo; i < hi; i += CH) {
+                    for (int t = 0; t < CH; ++t) {
+                        const bool in = i + t < hi;
+                        R.chunk_items.push_back(in ? sorted[2 * (size_t)(i + t)] : -1);
+                        R.chunk_items.push_back(in ? sorted[2 * (size_t)(i + t) + 1] : -1);
+                    }
+                    ++R.n_chunks;
+                }
+                R.seg_pair.push_back(((key / np) << 16) | (key % np));
+                R.seg_start.push_back(R.n_chunks);
+                ++R.n_seg;
+            }
+        }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.pose0 = bump(7 * Q.n_pose * D);
@@ -700,7 +813,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.edge_meas = bump(7 * Q.n_pose_edge * D); O.edge_info = bump(36 * Q.n_pose_edge * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
         O.Hll = bump(6 * Q.n_point * D); O.bl = bump(3 * Q.n_point * D); O.Hinv = bump(6 * Q.n_point * D); O.Hpl = bump(18 * Q.n_obs * D);
-        O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(8 * D);
+        O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(16 * D);
+        O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
+        O.Y = bump(18 * Q.n_obs * D); O.zrow = bump((n6 + 16) * D);
     }
     ms_ba *B = new ms_ba();
     B->ctx = c; B->n = n; B->arena_bytes = total;
@@ -719,6 +834,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.obs_pose, Q.obs_pose, 4 * Q.n_obs); up(O.obs_point, Q.obs_point, 4 * Q.n_obs); up(O.obs_uv, Q.obs_uv, 2 * Q.n_obs * D); up(O.obs_info, Q.obs_info, Q.n_obs * D);
         up(O.pt_start, R.pt_start.data(), 4 * (Q.n_point + 1)); up(O.pt_obs, R.pt_obs.data(), 4 * Q.n_obs);
         up(O.fstart, R.fstart.data(), 4 * (R.np_free + 1)); up(O.fobs, R.fobs.data(), 4 * R.fobs.size()); up(O.free2pose, R.free2pose.data(), 4 * R.np_free);
+        up(O.chunk_items, R.chunk_items.data(), 4 * R.chunk_items.size()); up(O.seg_start, R.seg_start.data(), 4 * R.seg_start.size()); up(O.seg_pair, R.seg_pair.data(), 4 * R.seg_pair.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
         (void)hipStreamSynchronize(c->stream);      // the Prep vectors / caller arrays may be pageable: finish before they go away
         BaProb &H = B->host[p];
@@ -735,6 +851,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.Hpp = PTR(double, Hpp); H.S = PTR(double, S); H.bp = PTR(double, bp); H.dp = PTR(double, dp); H.y = PTR(double, y);
         H.Hll = PTR(double, Hll); H.bl = PTR(double, bl); H.Hinv = PTR(double, Hinv); H.Hpl = PTR(double, Hpl); H.dl = PTR(double, dl);
         H.chi2_obs = PTR(double, chi2); H.stats = PTR(double, stats);
+        H.n_chunks = R.n_chunks; H.n_seg = R.n_seg; H.chunk_items = PTR(int32_t, chunk_items); H.seg_start = PTR(int32_t, seg_start); H.seg_pair = PTR(int32_t, seg_pair);
+        H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
 #undef PTR
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
@@ -773,8 +891,9 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
     if (point && H.n_point) MS_HIP(c, hipMemcpy(point, H.point, 3 * (size_t)H.n_point * sizeof(double), hipMemcpyDeviceToHost));
     if (chi2_per_obs && H.n_obs) MS_HIP(c, hipMemcpy(chi2_per_obs, H.chi2_obs, (size_t)H.n_obs * sizeof(double), hipMemcpyDeviceToHost));
     if (res) {
-        double st[8];
+        double st[16];
         MS_HIP(c, hipMemcpy(st, H.stats, sizeof(st), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; ++k) res->phase_cycles[k] = st[8 + k];
         res->iterations = (int)st[0]; res->trials = (int)st[1]; res->stopped_early = (int)st[2]; res->final_lambda = st[3];
         res->chi2_initial = st[4]; res->chi2_final = st[5];
         if (st[6] == 0) return ms_fail(c, MS_ERR_NUMERIC, "ms_ba_download: problem %d ended in a non-finite state", i);

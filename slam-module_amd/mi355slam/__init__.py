@@ -398,7 +398,7 @@ class BaProblemC(C.Structure):
 
 class BaResultC(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("stopped_early", C.c_int32), ("final_lambda", C.c_double),
-                ("chi2_initial", C.c_double), ("chi2_final", C.c_double)]
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("phase_cycles", C.c_double * 8)]
 
 
 def _ba_struct(prob, max_iters):
@@ -438,7 +438,8 @@ class BundleAdjuster:
         r = BaResultC()
         self.ctx.check(lib().ms_ba_download(self._h, i, _vp(pose), _vp(point), _vp(chi2), C.byref(r)), "ms_ba_download")
         return dict(pose=pose, point=point, chi2=chi2,
-                    stats=dict(iters=r.iterations, trials=r.trials, stop=r.stopped_early, lam=r.final_lambda, chi2_init=r.chi2_initial, chi2_final=r.chi2_final))
+                    stats=dict(iters=r.iterations, trials=r.trials, stop=r.stopped_early, lam=r.final_lambda, chi2_init=r.chi2_initial, chi2_final=r.chi2_final,
+                               phase_cycles=dict(zip(("eval", "linearise", "schur", "cholesky", "points_update", "total", "schur_prep", "schur_prep_rhs"), list(r.phase_cycles)))))
 
     def close(self):
         if self._h and self.ctx._h:
