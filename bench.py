@@ -108,26 +108,21 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    # ---- timed region: exactly K steps, production configuration (k_blur overlaps detection on a second stream) ----
+    # ---- timed region: exactly K steps; per-kernel HIP events ride along on the context stream ----
+    ex.set_profiling(True)
+    stage_sum = {}
+    match_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(profile_match=True)
+        for k, v in ex.stage_ms().items():          # reading the events waits for this step (steps are serial anyway)
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+        match_ms += ctx.event_elapsed_ms(0, 1)
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    # ---- per-kernel durations: the same K steps again with the stages serialised and bracketed by HIP events on the
-    #      context stream (a kernel's own duration is only defined when nothing else shares the chip) ----
-    ex.set_profiling(True)
-    stage_sum = {}
-    match_ms = 0.0
-    for _ in range(args.steps):
-        step(profile_match=True)
-        for k, v in ex.stage_ms().items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-        match_ms += ctx.event_elapsed_ms(0, 1)
-    ex.set_profiling(False)
     from mi355slam import shard
     frames_total, dt = shard.aggregate(dist if world > 1 else None, torch, BATCH * args.steps, dt, device="cuda")
 

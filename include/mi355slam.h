@@ -177,6 +177,21 @@ int ms_hamming_best2_sets(ms_ctx *ctx, const uint32_t *q_pool, int q_stride, con
 int ms_ratio_test(ms_ctx *ctx, const int32_t *best_idx, const uint16_t *best_dist, const uint16_t *second_dist,
                   int n, float lowe_ratio, int max_dist, int32_t *match);
 
+/* Scoring core of the projection-guided matchers searchByProjection / replaceDuplication / findMatchesTranformedMps
+ * (keyframe_matcher.cpp:349-378, :479-494, :600-623): query i (a map point's descriptor) against ITS OWN candidate list
+ * cand_idx[cand_start[i] .. cand_start[i+1]) (keypoint indices from the radius query, Keyframe::getFeaturesAround).
+ * t_skip marks targets to ignore (already bound features, :358-360); t_octave gives KeyPoint::octave so the caller can apply
+ * the same-level ratio rule (:382-386).  Outputs follow the reference's sequential scan exactly: best = first minimum,
+ * second = next smallest; *_octave are -1 when absent.  All pointers are device memory. */
+int ms_hamming_candidates(ms_ctx *ctx, const uint32_t *q_desc, int nq, const uint32_t *t_desc,
+                          const int32_t *cand_start, const int32_t *cand_idx, const uint8_t *t_skip, const int32_t *t_octave,
+                          int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave);
+
+/* Rotation-consistency histogram (openvslam/match_angle_checker.h:60-134), host arithmetic: 30 bins of
+ * cvRound(delta/30), everything outside the 3 fullest bins is invalid (ties between bins go to the lower bin).
+ * Writes the ids of invalid entries (bin order, then insertion order) and returns their count. */
+int ms_angle_check(const float *delta_angle, const int32_t *ids, int n, int32_t *invalid_ids);
+
 /* Bag-of-words buckets of one keyframe in CSR form (DBoW2::FeatureVector is an ordered std::map
  * node id -> keypoint indices; keyframe_matcher.cpp:65-76).  Arrays are DEVICE pointers. */
 typedef struct {

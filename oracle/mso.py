@@ -229,6 +229,17 @@ def angle_check(delta, ids):
     return inv[:m].copy()
 
 
+def best2_candidates(qdesc, tdesc, cand, skip=None, t_octave=None):
+    q = np.ascontiguousarray(qdesc, np.uint32); t = np.ascontiguousarray(tdesc, np.uint32).reshape(-1, 8)
+    c = np.ascontiguousarray(cand, np.int32)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    oc = None if t_octave is None else np.ascontiguousarray(t_octave, np.int32)
+    best, second, bo, so = C.c_uint(), C.c_uint(), C.c_int(), C.c_int()
+    bi = lib().mso_best2_candidates(_p(q, u32p), _p(t, u32p), _p(c, i32p), len(c), _p(sk, u8p), _p(oc, i32p),
+                                    C.byref(best), C.byref(second), C.byref(bo), C.byref(so))
+    return bi, best.value, second.value, bo.value, so.value
+
+
 def make_bow(bucket_of_kp):
     """CSR over ascending node ids; keypoints of a node in ascending keypoint index (DBoW2 insertion order)."""
     bucket_of_kp = np.asarray(bucket_of_kp, np.int32)

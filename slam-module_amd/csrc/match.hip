@@ -14,6 +14,7 @@
 // (distance<<20 | index) keys (min / max / min).
 #include "ms_internal.h"
 #include <cmath>
+#include <vector>
 
 namespace {
 
@@ -102,6 +103,45 @@ __global__ __launch_bounds__(256) void k_ratio_test(const int32_t *__restrict__ 
     bool ok = bi[i] >= 0 && b <= (unsigned)max_dist;                 // keyframe_matcher.cpp:115
     if (ok && __fmul_rn(ratio, (float)s) < (float)b) ok = false;     // keyframe_matcher.cpp:120
     match[i] = ok ? bi[i] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One wavefront per query: lanes scan the query's own candidate list, butterfly merge of (best, second) keys.
+__global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__restrict__ qd, int nq, const uint32_t *__restrict__ td,
+                                                            const int32_t *__restrict__ cstart, const int32_t *__restrict__ cidx,
+                                                            const uint8_t *__restrict__ skip, const int32_t *__restrict__ toct,
+                                                            int32_t *__restrict__ bi, uint16_t *__restrict__ bd, uint16_t *__restrict__ sd,
+                                                            int32_t *__restrict__ bo, int32_t *__restrict__ so) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const uint4 qa = reinterpret_cast<const uint4 *>(qd)[2 * i], qb = reinterpret_cast<const uint4 *>(qd)[2 * i + 1];
+    const uint32_t qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const int s = cstart[i], e = cstart[i + 1];
+    uint32_t best = kNone, second = kNone;
+    for (int r = s + lane; r < e; r += 64) {
+        const int j = cidx[r];
+        if (skip && skip[j]) continue;
+        const uint4 ta = reinterpret_cast<const uint4 *>(td)[2 * j], tb = reinterpret_cast<const uint4 *>(td)[2 * j + 1];
+        const uint32_t key = (hamming8(qr, ta, tb) << 20) | (uint32_t)(r - s);
+        const uint32_t lo = min(best, key), hi = max(best, key);
+        second = min(second, hi);
+        best = lo;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t ob = __shfl_xor(best, off, 64), os = __shfl_xor(second, off, 64);
+        const uint32_t lo = min(best, ob), hi = max(best, ob);
+        second = min(min(second, os), hi);
+        best = lo;
+    }
+    if (lane == 0) {
+        const int jb = best == kNone ? -1 : cidx[s + (int)(best & 0xFFFFFu)], js = second == kNone ? -1 : cidx[s + (int)(second & 0xFFFFFu)];
+        bi[i] = jb;
+        bd[i] = best == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(best >> 20);
+        sd[i] = second == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(second >> 20);
+        if (bo) bo[i] = (jb >= 0 && toct) ? toct[jb] : -1;
+        if (so) so[i] = (js >= 0 && toct) ? toct[js] : -1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,6 +322,44 @@ int ms_hamming_best2_sets(ms_ctx *c, const uint32_t *q_pool, int q_stride, const
     A.q_count = q_count; A.t_count = t_count; A.pair_q = pair_q; A.pair_t = pair_t;
     A.best_idx = best_idx; A.best_dist = best_dist; A.second_dist = second_dist;
     return launch_hamming(c, A, n_pairs);
+}
+
+int ms_hamming_candidates(ms_ctx *c, const uint32_t *q_desc, int nq, const uint32_t *t_desc, const int32_t *cand_start, const int32_t *cand_idx,
+                          const uint8_t *t_skip, const int32_t *t_octave, int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist,
+                          int32_t *best_octave, int32_t *second_octave) {
+    if (!c || !q_desc || !t_desc || !cand_start || !cand_idx || !best_idx || !best_dist || !second_dist || nq < 0) return MS_ERR_INVALID;
+    if (nq == 0) return MS_OK;
+    if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_candidates: descriptors must be 16-byte aligned");
+    MS_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_hamming_candidates, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, q_desc, nq, t_desc, cand_start, cand_idx, t_skip, t_octave,
+                       best_idx, best_dist, second_dist, best_octave, second_octave);
+    MS_KERNEL_CHECK(c, "k_hamming_candidates");
+    return MS_OK;
+}
+
+int ms_angle_check(const float *delta_angle, const int32_t *ids, int n, int32_t *invalid_ids) {
+    if (n < 0 || (n && (!delta_angle || !ids || !invalid_ids))) return MS_ERR_INVALID;
+    std::vector<int> bin(n);
+    int count[30] = {0};
+    for (int i = 0; i < n; ++i) {                       // match_angle_checker.h:72-83
+        float d = delta_angle[i];
+        if (d < 0.0) d = (float)((double)d + 360.0);
+        if (360.0 <= d) d = (float)((double)d - 360.0);
+        int b = (int)std::lrintf(d * (1.0f / 30));
+        bin[i] = (b < 0 || b >= 30) ? 29 : b;
+        count[bin[i]]++;
+    }
+    int top[3] = {-1, -1, -1};
+    for (int r = 0; r < 3; ++r) {
+        int bc = -1;
+        for (int k = 0; k < 30; ++k) if (k != top[0] && k != top[1] && count[k] > bc) { bc = count[k]; top[r] = k; }
+    }
+    int m = 0;
+    for (int b = 0; b < 30; ++b) {
+        if (b == top[0] || b == top[1] || b == top[2]) continue;
+        for (int i = 0; i < n; ++i) if (bin[i] == b) invalid_ids[m++] = ids[i];
+    }
+    return m;
 }
 
 int ms_ratio_test(ms_ctx *c, const int32_t *best_idx, const uint16_t *best_dist, const uint16_t *second_dist,

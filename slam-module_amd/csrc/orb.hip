@@ -667,9 +667,6 @@ struct ms_orb {
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
     bool wide[MS_MAX_LEVELS] = {false};
-    // second stream: k_blur runs beside k_fast/k_select/k_tracks (both only read the pyramid levels)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_levels = nullptr, ev_blur = nullptr;
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
     hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
@@ -773,8 +770,6 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         };
         up(&o->d_xtab[l], xt); up(&o->d_ytab[l], yt);
     }
-    if (rc == MS_OK && (hipStreamCreateWithFlags(&o->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&o->ev_levels, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&o->ev_blur, hipEventDisableTiming) != hipSuccess)) rc = MS_ERR_HIP;
     if (rc == MS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
     if (rc != MS_OK) { ms_orb_destroy(o); return ms_fail(ctx, rc, "ms_orb_create: device allocation failed"); }
     *out = o;
@@ -790,9 +785,7 @@ void ms_orb_destroy(ms_orb *o) {
                     o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
-    if (o->aux) { (void)hipStreamSynchronize(o->aux); (void)hipStreamDestroy(o->aux); }
-    if (o->ev_levels) (void)hipEventDestroy(o->ev_levels);
-    if (o->ev_blur) (void)hipEventDestroy(o->ev_blur);
+
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
         if (o->d_xtab[l]) (void)hipFree(o->d_xtab[l]);
         if (o->d_ytab[l]) (void)hipFree(o->d_ytab[l]);
@@ -881,13 +874,10 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         MS_KERNEL_CHECK(c, "k_resize");
     }
     MS_STAGE_MARK();
-    // With profiling on, the kernels run back to back on the context stream so every stage has its own duration;
-    // otherwise k_blur goes to the auxiliary stream and overlaps detection (it is only needed by k_describe).
-    hipStream_t blur_stream = o->profiling ? st : o->aux;
-    if (!o->profiling) { MS_HIP(c, hipEventRecord(o->ev_levels, st)); MS_HIP(c, hipStreamWaitEvent(o->aux, o->ev_levels, 0)); }
-    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, blur_stream, src, o->d_geom);
+    // (k_blur was tried on a second stream beside k_fast: no gain -- the detection kernel already fills the chip -- and
+    // overlapped launches have no well-defined per-kernel duration, so everything stays on the context stream.)
+    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->d_geom);
     MS_KERNEL_CHECK(c, "k_blur");
-    if (!o->profiling) MS_HIP(c, hipEventRecord(o->ev_blur, o->aux));
     MS_STAGE_MARK();
     hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count);
     MS_KERNEL_CHECK(c, "k_fast");
@@ -901,7 +891,6 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
                        o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
     MS_KERNEL_CHECK(c, "k_tracks");
     MS_STAGE_MARK();
-    if (!o->profiling) MS_HIP(c, hipStreamWaitEvent(st, o->ev_blur, 0));
     hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
                        o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count);

@@ -334,6 +334,31 @@ def ratio_test(ctx, best_idx, best_dist, second_dist, lowe_ratio, max_dist=50):
     return m.download(np.int32, (n,))
 
 
+def hamming_candidates(ctx, q_desc, t_desc, cand_lists, t_skip=None, t_octave=None):
+    """cand_lists: list (per query) of keypoint index arrays.  Returns (best_idx, best_dist, second_dist, best_oct, second_oct)."""
+    q = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8); t = np.ascontiguousarray(t_desc, np.uint32).reshape(-1, 8)
+    nq = len(q)
+    start = np.zeros(nq + 1, np.int32)
+    start[1:] = np.cumsum([len(c) for c in cand_lists])
+    idx = np.concatenate([np.asarray(c, np.int32) for c in cand_lists] + [np.zeros(0, np.int32)]).astype(np.int32)
+    dq, dt, ds, di = ctx.upload(q), ctx.upload(t if len(t) else np.zeros((1, 8), np.uint32)), ctx.upload(start), ctx.upload(idx if len(idx) else np.zeros(1, np.int32))
+    dsk = ctx.upload(np.asarray(t_skip, np.uint8)) if t_skip is not None else None
+    doc = ctx.upload(np.asarray(t_octave, np.int32)) if t_octave is not None else None
+    outs = [ctx.alloc(4 * nq + 16), ctx.alloc(2 * nq + 16), ctx.alloc(2 * nq + 16), ctx.alloc(4 * nq + 16), ctx.alloc(4 * nq + 16)]
+    ctx.check(lib().ms_hamming_candidates(ctx._h, _vp(dq), nq, _vp(dt), _vp(ds), _vp(di), _vp(dsk), _vp(doc), *[_vp(o) for o in outs]), "ms_hamming_candidates")
+    ctx.sync()
+    return (outs[0].download(np.int32, (nq,)), outs[1].download(np.uint16, (nq,)), outs[2].download(np.uint16, (nq,)),
+            outs[3].download(np.int32, (nq,)), outs[4].download(np.int32, (nq,)))
+
+
+def angle_check(delta, ids):
+    delta = np.ascontiguousarray(delta, np.float32); ids = np.ascontiguousarray(ids, np.int32)
+    inv = np.zeros(max(len(ids), 1), np.int32)
+    m = lib().ms_angle_check(delta.ctypes.data_as(f32p), ids.ctypes.data_as(i32p), len(ids), inv.ctypes.data_as(i32p))
+    assert m >= 0
+    return inv[:m].copy()
+
+
 class FrameOnDevice:
     """Uploads one keyframe's matcher inputs and builds the ms_match_frame struct."""
 

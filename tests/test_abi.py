@@ -54,3 +54,13 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "mso.h" not in txt and "import mso" not in txt and "libmso" not in txt, os.path.join(dirpath, fn)
+
+
+def test_angle_check_host_function(oracle):
+    """A1 (match_angle_checker.h:60-134) is host arithmetic in the product too: compare with the oracle on the CPU."""
+    import mi355slam
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 50, 2000):
+        d = np.concatenate([rng.normal(40, 10, n // 2), rng.uniform(-360, 720, n - n // 2)]).astype(np.float32)
+        ids = rng.permutation(n).astype(np.int32)
+        assert np.array_equal(mi355slam.angle_check(d, ids), oracle.angle_check(d, ids))

@@ -131,3 +131,21 @@ def test_match_triangulation_exact_greedy(oracle, ctx):
     counts, matched = mi355slam.match_triangulation(ctx, f1s, f2s, np.stack(Es), sf, 2.0, True)
     for i, (wn, wm) in enumerate(wants):
         assert counts[i] == wn and np.array_equal(matched[i], wm), i
+
+
+def test_hamming_candidates_projection_core(oracle, ctx):
+    """Scoring core of searchByProjection / replaceDuplication: each map point against its own radius-query candidates."""
+    import mi355slam
+    rng = np.random.default_rng(21)
+    q, t = make_pair(33, 500, 1800, 400)
+    t_oct = rng.integers(0, 8, 1800).astype(np.int32)
+    skip = (rng.random(1800) < 0.2).astype(np.uint8)
+    cands = [rng.choice(1800, size=int(k), replace=False).astype(np.int32) for k in rng.integers(0, 130, 500)]
+    cands[3] = np.zeros(0, np.int32)
+    t2 = t.copy(); t2[cands[5][:3]] = q[5]                     # exact ties: first in list order must win, the next is the second
+    for sk in (None, skip):
+        bi, bd, sd, bo, so = mi355slam.hamming_candidates(ctx, q, t2, cands, t_skip=sk, t_octave=t_oct)
+        for i in range(500):
+            w = oracle.best2_candidates(q[i], t2, cands[i], skip=sk, t_octave=t_oct)
+            assert (bi[i], bd[i], sd[i], bo[i], so[i]) == w, i
+    assert bi[3] == -1 and bd[3] == 256
