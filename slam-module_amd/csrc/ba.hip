@@ -64,6 +64,13 @@ struct BaProb {
                                              //       8 eval, 9 linearise, 10 Schur, 11 Cholesky+backsub, 12 points+update, 13 total
 };
 
+// Out-of-line device functions see plain pointers as generic (flat) pointers; flat loads count on BOTH memory counters, so
+// every LDS wait would also wait for prefetched global data.  The hot loops therefore use explicitly address-space-typed pointers.
+#define MS_GLOBAL __attribute__((address_space(1)))
+#define MS_LDS __attribute__((address_space(3)))
+typedef double d2_t __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space (HIP's double2 struct is not)
+typedef int i2_t __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------- SE3 helpers (g2o / Eigen conventions)
 __device__ __forceinline__ void q_normalize(double *q) {
     if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
@@ -396,17 +403,18 @@ __device__ __noinline__ void build_system(const BaProb &P_) {
     __syncthreads();
 }
 
-__device__ __forceinline__ void schur_fetch(const int32_t *chunk_items, const double *Y, const double *Hpl, int ch, int lane, double2 (&v)[9]) {
-    const int2 *items = reinterpret_cast<const int2 *>(chunk_items) + (size_t)ch * CH;
-    int2 ab[9];
+__device__ __forceinline__ void schur_fetch(const MS_GLOBAL int32_t *chunk_items, const MS_GLOBAL double *Y, const MS_GLOBAL double *Hpl, int ch, int lane,
+                                            d2_t (&v)[9]) {
+    const MS_GLOBAL i2_t *items = reinterpret_cast<const MS_GLOBAL i2_t *>(chunk_items) + (size_t)ch * CH;
+    i2_t ab[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) ab[k] = items[(lane + 64 * k) / 18];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int piece = (lane + 64 * k) % 18;
-        v[k] = double2{0.0, 0.0};
-        if (ab[k].x >= 0) v[k] = piece < 9 ? reinterpret_cast<const double2 *>(Y + 18 * (size_t)ab[k].x)[piece]
-                                           : reinterpret_cast<const double2 *>(Hpl + 18 * (size_t)ab[k].y)[piece - 9];
+        v[k] = d2_t{0.0, 0.0};
+        if (ab[k].x >= 0) v[k] = piece < 9 ? reinterpret_cast<const MS_GLOBAL d2_t *>(Y + 18 * (size_t)ab[k].x)[piece]
+                                           : reinterpret_cast<const MS_GLOBAL d2_t *>(Hpl + 18 * (size_t)ab[k].y)[piece - 9];
     }
 }
 
@@ -486,26 +494,28 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
     // (t = lane/2, half = lane%2) multiplies item t's record pair into 18 of the 36 block entries and keeps the
     // running sum in registers across the segment's chunks; one fixed-order butterfly over t ends the segment.
     {
-        double *stage = lds + (size_t)wave * (CH * 36);              // [32 items][18 Y | 18 W]
-        const int32_t *chunk_items = P.chunk_items;
-        const double *Yp = P.Y, *Hplp = P.Hpl;
-        double *Sp = P.S;
-        for (int seg = wave; seg < P.n_seg; seg += NW) {
+        MS_LDS double *stage = (MS_LDS double *)lds + (size_t)wave * (CH * 36);      // [32 items][18 Y | 18 W]
+        const MS_GLOBAL int32_t *chunk_items = (const MS_GLOBAL int32_t *)P.chunk_items, *seg_start = (const MS_GLOBAL int32_t *)P.seg_start,
+                                *seg_pair = (const MS_GLOBAL int32_t *)P.seg_pair;
+        const MS_GLOBAL double *Yp = (const MS_GLOBAL double *)P.Y, *Hplp = (const MS_GLOBAL double *)P.Hpl;
+        MS_GLOBAL double *Sp = (MS_GLOBAL double *)P.S;
+        const int n_seg = P.n_seg;
+        for (int seg = wave; seg < n_seg; seg += NW) {
             double acc[18];
 #pragma unroll
             for (int q = 0; q < 18; ++q) acc[q] = 0;
             const int t = lane >> 1, half = lane & 1;
             // software pipeline: the 9 record pieces of chunk ch+1 are in flight while chunk ch is multiplied
-            const int ch_end = P.seg_start[seg + 1];
-            double2 cur[9], nxt[9];
-            schur_fetch(chunk_items, Yp, Hplp, P.seg_start[seg], lane, cur);
-            for (int ch = P.seg_start[seg]; ch < ch_end; ++ch) {
+            const int ch_begin = seg_start[seg], ch_end = seg_start[seg + 1];
+            d2_t cur[9], nxt[9];
+            schur_fetch(chunk_items, Yp, Hplp, ch_begin, lane, cur);
+            for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) reinterpret_cast<double2 *>(stage)[lane + 64 * k] = cur[k];
+                for (int k = 0; k < 9; ++k) reinterpret_cast<MS_LDS d2_t *>(stage)[lane + 64 * k] = cur[k];
                 if (ch + 1 < ch_end) schur_fetch(chunk_items, Yp, Hplp, ch + 1, lane, nxt);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const double *rec = stage + t * 36;
+                const MS_LDS double *rec = stage + t * 36;
                 double ya[9], wb[18];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) ya[q] = rec[9 * half + q];           // rows 3*half .. 3*half+2 of Y
@@ -526,7 +536,7 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
                 for (int off = 2; off < 64; off <<= 1) acc[q] += __shfl_xor(acc[q], off, 64);
             }
             if (lane < 2) {                                           // lane = half: rows 3*half .. 3*half+2 of the block
-                const int fa = P.seg_pair[seg] >> 16, fb = P.seg_pair[seg] & 0xFFFF;
+                const int fa = seg_pair[seg] >> 16, fb = seg_pair[seg] & 0xFFFF;
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -554,27 +564,49 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_, int 
             // (m x c0)(c0 x 16) product -> v_mfma_f64_16x16x4_f64, one 16-row tile per wave, operands straight
             // from L2 (each lane streams 4 consecutive doubles of its A row and of its B row per 16-k chunk;
             // the k order inside a chunk is permuted identically for A and B, which leaves the sum unchanged)
-            for (int rt = wave; rt * 16 < m; rt += NW) {
-                const int ia = rt * 16 + (lane & 15), q = lane >> 4, jb = lane & 15;
-                // rows beyond the matrix / columns beyond the panel read a zero row, so the loads need no guards and
-                // four k-chunks (16 double2 loads) can be in flight per MFMA group
-                const double *arow = (c0 + ia < n) ? P.S + (size_t)(c0 + ia) * n : (c0 + ia == n ? P.y : P.zrow);
-                const double *brow = (jb < nb) ? P.S + (size_t)(c0 + jb) * n : P.zrow;
-                const double2 *ap = reinterpret_cast<const double2 *>(arow + 4 * q), *bp2 = reinterpret_cast<const double2 *>(brow + 4 * q);
-                d4_t acc = {0, 0, 0, 0};
-                for (int kk = 0; kk < c0; kk += 16) {
-                    const double2 a01 = ap[kk / 2], a23 = ap[kk / 2 + 1], b01 = bp2[kk / 2], b23 = bp2[kk / 2 + 1];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc, 0, 0, 0);
+            // Each wave works on TWO row tiles at once (independent accumulators) and two k-chunks per trip, so 16 double2
+            // loads are in flight per group of 16 MFMAs instead of 4 per 4.
+            const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S, *yg = (const MS_GLOBAL double *)P.y, *zg = (const MS_GLOBAL double *)P.zrow;
+            const int q = lane >> 4, jb = lane & 15;
+            const MS_GLOBAL d2_t *bp2 = reinterpret_cast<const MS_GLOBAL d2_t *>(((jb < nb) ? Sg + (size_t)(c0 + jb) * n : zg) + 4 * q);
+            for (int rt = wave; rt * 16 < m; rt += 2 * NW) {
+                const int rt2 = rt + NW;
+                const int ia = rt * 16 + (lane & 15), ib = rt2 * 16 + (lane & 15);
+                const MS_GLOBAL double *arow = (c0 + ia < n) ? Sg + (size_t)(c0 + ia) * n : (c0 + ia == n ? yg : zg);
+                const MS_GLOBAL double *brow2 = (c0 + ib < n) ? Sg + (size_t)(c0 + ib) * n : (c0 + ib == n ? yg : zg);
+                const MS_GLOBAL d2_t *ap = reinterpret_cast<const MS_GLOBAL d2_t *>(arow + 4 * q), *ap2 = reinterpret_cast<const MS_GLOBAL d2_t *>(brow2 + 4 * q);
+                d4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+                int kk = 0;
+                for (; kk + 32 <= c0; kk += 32) {
+                    const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], a2 = ap[kk / 2 + 8], a3 = ap[kk / 2 + 9];
+                    const d2_t e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], e2 = ap2[kk / 2 + 8], e3 = ap2[kk / 2 + 9];
+                    const d2_t b0 = bp2[kk / 2], b1 = bp2[kk / 2 + 1], b2 = bp2[kk / 2 + 8], b3 = bp2[kk / 2 + 9];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.x, b0.x, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.y, b0.y, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.x, b1.x, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.y, b1.y, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2.x, b2.x, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2.y, b2.y, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3.x, b3.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3.x, b3.x, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3.y, b3.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3.y, b3.y, acc2, 0, 0, 0);
+                }
+                for (; kk < c0; kk += 16) {
+                    const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], b0 = bp2[kk / 2], b1 = bp2[kk / 2 + 1];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.x, b0.x, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.y, b0.y, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.x, b1.x, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.y, b1.y, acc2, 0, 0, 0);
                 }
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {       // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg, col = lane&15
-                    const int ii = rt * 16 + (lane >> 4) + 4 * reg, j = lane & 15;
-                    if (ii < m) {
-                        const double v = (j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
-                        pan[ii * NB + j] = v - acc[reg];
+                    const int j = lane & 15;
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg;
+                        if (ii < m) {
+                            const double v = (j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
+                            pan[ii * NB + j] = v - (which ? acc2[reg] : acc[reg]);
+                        }
                     }
                 }
             }
@@ -618,28 +650,35 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_, int 
             }
             __syncthreads();
         }
-        // back substitution L^T x = y, panels in reverse
+        // back substitution L^T x = y, panels in reverse.  x lives in LDS; the 16x16 triangular solve of a panel is a
+        // wave-level recurrence (lane k owns x_k, one shuffle per step) -- not a serial loop over global memory.
+        double *xs = tvec + NB;                                    // [n]
         const int last = ((n - 1) / NB) * NB;
         for (int c0 = last; c0 >= 0; c0 -= NB) {
             const int nb = min(NB, n - c0), m = n - c0;            // rows c0..n-1
             for (int idx = tid; idx < m * NB; idx += NT) { const int i = idx / NB, j = idx - i * NB; pan[idx] = j < nb ? P.S[(size_t)(c0 + i) * n + c0 + j] : 0.0; }
             __syncthreads();
             for (int c = wave; c < nb; c += NW) {
-                double s = 0;
-                for (int i = nb + lane; i < m; i += 64) s += pan[i * NB + c] * P.dp[c0 + i];
-                s = wave_sum_d(s);
-                if (lane == 0) tvec[c] = s;
+                double sacc = 0;
+                for (int i = nb + lane; i < m; i += 64) sacc += pan[i * NB + c] * xs[c0 + i];
+                sacc = wave_sum_d(sacc);
+                if (lane == 0) tvec[c] = sacc;
             }
             __syncthreads();
-            if (tid == 0) {
+            if (wave == 0) {
+                double r = (lane < nb) ? P.y[c0 + lane] - tvec[lane] : 0.0;
+                double xk = 0;
                 for (int j = nb - 1; j >= 0; --j) {
-                    double s = P.y[c0 + j] - tvec[j];
-                    for (int k = j + 1; k < nb; ++k) s -= pan[k * NB + j] * P.dp[c0 + k];
-                    P.dp[c0 + j] = s / pan[j * NB + j];
+                    const double xj = __shfl(r, j, 64) / pan[j * NB + j];
+                    if (lane == j) xk = xj;
+                    if (lane < j) r -= pan[j * NB + lane] * xj;          // L[c0+j][c0+lane]
                 }
+                if (lane < nb) xs[c0 + lane] = xk;
             }
             __syncthreads();
         }
+        for (int i = tid; i < n; i += NT) P.dp[i] = xs[i];
+        __syncthreads();
     }
 }
 
