@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
 // Lanes 0 and 63 only provide halo (248 outputs per 256 loaded pixels); REFLECT_101 is applied when the
 // bytes are loaded, which commutes with the vertical pass.
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+typedef short s2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int reflect101(int i, int n) {
     i = i < 0 ? -i : i;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g) {
 // D1: FAST-9/16 corners + score + 3x3 strict NMS (this build's detector behind
 // feature_detector.cpp:89-98).  One launch covers every level of every frame.
 // Tile = 248 x 14 outputs; 256 x 16 score positions (1 px NMS halo, rounded to dwords): small tiles keep
-// the LDS footprint at 12 KB so 8 workgroups (32 waves) share a CU -- the kernel is latency-bound (dependent loads,
+// the LDS footprint at 20 KB so 8 workgroups (32 waves) share a CU -- the kernel is latency-bound (dependent loads,
 // five barriers, one returning atomic per tile), not ALU-bound, and needs the occupancy.
 //   phase A1  compass pre-test on EVERY position, in registers, two pixels per instruction: a lane owns
 //             one dword (4 pixels) of a row, the even/odd bytes are two 16-bit lanes; the sign bits of
@@ -221,10 +222,10 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g) {
 //             An arc of 9 contiguous ring pixels always covers two of those four, so a pixel with fewer
 //             than two brighter AND fewer than two darker compass pixels cannot be a corner (exact
 //             reject).  Survivors are compacted into an LDS list.
-//   phase A2  dense over the survivors: full 16-pixel ring test with two 16-bit masks built by
-//             v_alignbit from sign bits, 9-contiguous test by shift-and; corners are scored in place
-//             (sliding min / max of 9 over the circular ring) into the LDS score tile
-//   phase C   3x3 strict-maximum NMS on the LDS score tile; survivors leave as 32-bit keys
+//   phase A2  dense over the survivors: the FAST score itself (max over the 16 arcs of 9 of min(c-r) / min(r-c)) on packed
+//             16-bit lanes (two ring pixels per v_pk_min/max_i16), ring bytes through the vector cache; a pixel is a
+//             corner iff score > threshold, so no separate mask test is needed; scores go to the LDS score tile
+//   phase C   3x3 strict-maximum NMS, dense over the corner list, against the LDS score tile; survivors leave as 32-bit keys
 //             ((255-score)<<24 | y*w+x) with ONE global atomic per tile
 constexpr int kFastSeg = 248, kFastRows = 14, kFastPosRows = kFastRows + 2, kFastRowsPerWave = kFastPosRows / 4;
 
@@ -260,7 +261,8 @@ __device__ __forceinline__ void compass_add(Compass &M, uint32_t W, uint32_t hie
 __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
     __shared__ uint8_t s_sc[kFastPosRows][264];
     __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPosRows * 256];   // compass survivors; reused as the NMS output buffer
-    __shared__ int s_np, s_m, s_base;
+    __shared__ uint16_t s_cl[kFastPosRows * 256];                                 // corners (position ids)
+    __shared__ int s_np, s_nc, s_m, s_base;
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2048 keys >= 124*7 possible NMS survivors
     const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_np = 0; s_m = 0; }
+    if (tid == 0) { s_np = 0; s_nc = 0; s_m = 0; }
     for (int i = tid; i < kFastPosRows * 264 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
     __syncthreads();
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
@@ -315,53 +317,55 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
         }
     }
     __syncthreads();
-    // ---- phase A2 + B: full ring test on the survivors; corners are scored in place (the 16 ring differences
-    //      are already in registers, and a second pass would cost another memory round trip + barrier)
+    // ---- phase A2 + B: the survivors are SCORED directly (corner <=> score > threshold), on packed 16-bit lanes:
+    //      P[k] = (d[k], d[k+8]) with d = centre - ring pixel; the sliding min / max of 9 over the circular ring is four
+    //      v_pk_min_i16 / v_pk_max_i16 levels (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
     const int np = s_np;
     for (int i = tid; i < np; i += 256) {
         const int e = s_pre[i], pr = e >> 8, c = e & 255;
         const uint8_t *p = img + (uint64_t)(Y0 - 1 + pr) * pitch + (X0 - 4 + c);
-        const int cv = p[0];
-        int d[16];
-        uint32_t mb = 0, md = 0;
+        const uint32_t cc = (uint32_t)p[0] * 0x00010001u;
+        s2_t P[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            d[k] = cv - (int)p[rdy[k] * pitch + rdx[k]];
-            mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(d[k] + thr), 31);   // ring brighter: d < -t  -> sign of d + t
-            md = __builtin_amdgcn_alignbit(md, (uint32_t)(thr - d[k]), 31);   // ring darker:   d >  t  -> sign of t - d
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t rp = (uint32_t)p[rdy[k] * pitch + rdx[k]] | ((uint32_t)p[rdy[k + 8] * pitch + rdx[k + 8]] << 16);
+            P[k] = __builtin_bit_cast(s2_t, pk_sub(cc, rp));
         }
-        if (contig9(mb & 0xFFFFu) || contig9(md & 0xFFFFu)) {
-            int mn[16], mx[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-            int mn4[16], mx4[16];
+        for (int k = 0; k < 8; ++k) P[k + 8] = P[k].yx;                       // (d[k+8], d[k]): the ring is circular
+        s2_t mn[12], mx[12];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
-            int best = 0;
+        for (int k = 0; k < 8; ++k) { mn[k] = __builtin_elementwise_min(P[k], P[k + 1]); mx[k] = __builtin_elementwise_max(P[k], P[k + 1]); }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-                const int x9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-                best = max(best, max(m9, -x9));
-            }
-            s_sc[pr][c] = (uint8_t)best;          // a corner at threshold t has score > t by construction
+        for (int k = 0; k < 2; ++k) { mn[8 + k] = mn[k].yx; mx[8 + k] = mx[k].yx; }
+        s2_t mn4[12], mx4[12];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mn4[k] = __builtin_elementwise_min(mn[k], mn[k + 2]); mx4[k] = __builtin_elementwise_max(mx[k], mx[k + 2]); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mn4[8 + k] = mn4[k].yx; mx4[8 + k] = mx4[k].yx; }
+        s2_t bright = {-32768, -32768}, dark = {32767, 32767};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const s2_t m9 = __builtin_elementwise_min(__builtin_elementwise_min(mn4[k], mn4[k + 4]), P[k + 8]);   // arcs starting at k and k+8
+            const s2_t x9 = __builtin_elementwise_max(__builtin_elementwise_max(mx4[k], mx4[k + 4]), P[k + 8]);
+            bright = __builtin_elementwise_max(bright, m9);
+            dark = __builtin_elementwise_min(dark, x9);
         }
+        const int best = max(max((int)bright.x, (int)bright.y), -min((int)dark.x, (int)dark.y));
+        if (best > thr) { s_sc[pr][c] = (uint8_t)best; s_cl[atomicAdd(&s_nc, 1)] = (uint16_t)e; }
     }
     __syncthreads();
-    // ---- phase C: NMS over outputs px X0..X0+247 (columns 4..251), rows Y0..Y0+29 (position rows 1..30)
-    for (int item = tid; item < kFastRows * 62; item += 256) {
-        const int pr = 1 + item / 62, c4 = 4 + 4 * (item % 62);
-        const uint32_t sd = *reinterpret_cast<const uint32_t *>(&s_sc[pr][c4]);
-        if (sd == 0) continue;
-        const int y = Y0 - 1 + pr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sc = (sd >> (8 * i)) & 255, c = c4 + i, px = X0 - 4 + c;
-            if (sc == 0 || px >= w || y >= h) continue;
-            const bool keep = sc > s_sc[pr - 1][c - 1] && sc > s_sc[pr - 1][c] && sc > s_sc[pr - 1][c + 1] && sc > s_sc[pr][c - 1] &&
-                              sc > s_sc[pr][c + 1] && sc > s_sc[pr + 1][c - 1] && sc > s_sc[pr + 1][c] && sc > s_sc[pr + 1][c + 1];
-            if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - sc) << 24) | (uint32_t)(y * w + px);
-        }
+    // ---- phase C: 3x3 strict-maximum NMS, dense over the corner list (only outputs: px X0..X0+247 = columns 4..251,
+    //      rows Y0..Y0+13 = position rows 1..14; the halo corners only serve as neighbours)
+    const int nc = s_nc;
+    for (int i = tid; i < nc; i += 256) {
+        const int e = s_cl[i], pr = e >> 8, c = e & 255;
+        const int px = X0 - 4 + c, y = Y0 - 1 + pr;
+        if (pr < 1 || pr > kFastRows || c < 4 || c > 251 || px >= w || y >= h) continue;
+        const int sc = s_sc[pr][c];
+        const bool keep = sc > s_sc[pr - 1][c - 1] && sc > s_sc[pr - 1][c] && sc > s_sc[pr - 1][c + 1] && sc > s_sc[pr][c - 1] &&
+                          sc > s_sc[pr][c + 1] && sc > s_sc[pr + 1][c - 1] && sc > s_sc[pr + 1][c] && sc > s_sc[pr + 1][c + 1];
+        if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - sc) << 24) | (uint32_t)(y * w + px);
     }
     __syncthreads();
     const int m = s_m;
