@@ -11,16 +11,17 @@
 // per iteration), so throughput comes from batching windows and from never returning to the host inside
 // a solve -- not from spreading one window over the chip (hard part 5).
 //   linearise   per point (thread = point): Hll (3x3), bl, and Hpl (6x3) per observation
-//               per pose  (wave = pose)   : Hpp (6x6), bp by a fixed-order wave reduction
-//   Schur       S = Hpp + lambda I - sum_p Hpl (Hll + lambda I)^-1 Hpl^T, built panel-by-panel in LDS
-//               (row panels of S, ds_add_f64), lower triangle only
-//   solve       blocked left-looking Cholesky (16-column panels staged in LDS, rhs carried as an extra
-//               row), back substitution, point back-substitution, SE3 exponential update
+//               per pose  (wave = pose)   : Hpp (6x6), bp by a fixed-order wave reduction; SE3 edges one thread each
+//   Schur       S = Hpp + lambda I - sum_p Hpl (Hll + lambda I)^-1 Hpl^T as ordered sums of 6x6 block products: the
+//               host sorts the observation pairs of every point by pose pair once; a wave per pose pair stages the
+//               144-byte records of 32 pairs into LDS (coalesced 16-byte pieces) and multiplies them from there
+//   solve       blocked left-looking Cholesky (16-column panels, v_mfma_f64_16x16x4_f64 update from L2, rhs carried as
+//               an extra row), wave-level back substitution in LDS, point back-substitution, SE3 exponential update
 //   LM          g2o's schedule: lambda0 = 1e-5 max diag, rho = dF / (dx.(lambda dx + b) + 1e-3),
 //               lambda *= max(1/3, min(2/3, 1-(2 rho-1)^3)) or lambda *= nu, nu *= 2, <= 10 trials
-// No MFMA: this is sparse block work (6x6 / 6x3 / 3x3), not a dense contraction.  fp64 throughout.
-// The LDS accumulation order of the Schur panels is not fixed, so results vary in the last bits
-// run-to-run (observed ~1e-13 relative); parity is judged at 1e-5 on the residuals.
+// The 6x6 / 6x3 / 3x3 block work is plain fp64 VALU (no MFMA: it is sparse block work, not a dense contraction); only the
+// dense Cholesky panel update uses the f64 MFMA.  The Schur sums have a fixed order; the few SE3-edge atomics do not,
+// so results may differ in the last bits run-to-run; parity is judged at 1e-5 on the residuals.
 #include "ms_internal.h"
 #include <algorithm>
 #include <cfloat>
