@@ -185,7 +185,8 @@ int ms_ratio_test(ms_ctx *ctx, const int32_t *best_idx, const uint16_t *best_dis
  * second = next smallest; *_octave are -1 when absent.  All pointers are device memory. */
 int ms_hamming_candidates(ms_ctx *ctx, const uint32_t *q_desc, int nq, const uint32_t *t_desc,
                           const int32_t *cand_start, const int32_t *cand_idx, const uint8_t *t_skip, const int32_t *t_octave,
-                          int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave);
+                          int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave,
+                          int32_t *second_idx /* may be NULL */);
 
 /* Rotation-consistency histogram (openvslam/match_angle_checker.h:60-134), host arithmetic: 30 bins of
  * cvRound(delta/30), everything outside the 3 fullest bins is invalid (ties between bins go to the lower bin).

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__re
                                                             const int32_t *__restrict__ cstart, const int32_t *__restrict__ cidx,
                                                             const uint8_t *__restrict__ skip, const int32_t *__restrict__ toct,
                                                             int32_t *__restrict__ bi, uint16_t *__restrict__ bd, uint16_t *__restrict__ sd,
-                                                            int32_t *__restrict__ bo, int32_t *__restrict__ so) {
+                                                            int32_t *__restrict__ bo, int32_t *__restrict__ so, int32_t *__restrict__ si) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nq) return;
     const uint4 qa = reinterpret_cast<const uint4 *>(qd)[2 * i], qb = reinterpret_cast<const uint4 *>(qd)[2 * i + 1];
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__re
         sd[i] = second == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(second >> 20);
         if (bo) bo[i] = (jb >= 0 && toct) ? toct[jb] : -1;
         if (so) so[i] = (js >= 0 && toct) ? toct[js] : -1;
+        if (si) si[i] = js;
     }
 }
 
@@ -326,13 +327,13 @@ int ms_hamming_best2_sets(ms_ctx *c, const uint32_t *q_pool, int q_stride, const
 
 int ms_hamming_candidates(ms_ctx *c, const uint32_t *q_desc, int nq, const uint32_t *t_desc, const int32_t *cand_start, const int32_t *cand_idx,
                           const uint8_t *t_skip, const int32_t *t_octave, int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist,
-                          int32_t *best_octave, int32_t *second_octave) {
+                          int32_t *best_octave, int32_t *second_octave, int32_t *second_idx) {
     if (!c || !q_desc || !t_desc || !cand_start || !cand_idx || !best_idx || !best_dist || !second_dist || nq < 0) return MS_ERR_INVALID;
     if (nq == 0) return MS_OK;
     if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_candidates: descriptors must be 16-byte aligned");
     MS_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_hamming_candidates, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, q_desc, nq, t_desc, cand_start, cand_idx, t_skip, t_octave,
-                       best_idx, best_dist, second_dist, best_octave, second_octave);
+                       best_idx, best_dist, second_dist, best_octave, second_octave, second_idx);
     MS_KERNEL_CHECK(c, "k_hamming_candidates");
     return MS_OK;
 }

@@ -4,6 +4,7 @@
 // KeyframeFeatures view is built once per keyframe (INTEGRATION.md shows the 15 lines that fill it from
 // kf.shared->keyPoints, kf.mapPoints and kf.shared->bowFeatureVec) and uploaded by DeviceKeyframe.
 #pragma once
+#include <algorithm>
 #include <map>
 #include <utility>
 #include "common.hpp"
@@ -102,6 +103,86 @@ inline std::vector<std::pair<int, int>> matchForTriangulationDBoW(Context &ctx, 
     std::vector<std::pair<int, int>> matches;                               // ascending idx_1 (:279-292)
     for (std::size_t i = 0; i < m.size(); ++i) if (m[i] >= 0) matches.emplace_back((int)i, m[i]);
     return matches;
+}
+
+// ---- projection-guided matchers (M3-M5) ---------------------------------------------------------------------------
+// The caller keeps what touches the map graph: reprojection, distance / viewing-angle gates, predictScaleLevel, the
+// radius query Keyframe::getFeaturesAround and all map mutation.  What it hands over per surviving map point is its
+// descriptor and the candidate keypoint indices; the Hamming scoring runs on the GPU for all map points at once.
+struct ProjectionQuery {
+    KeyPoint::Descriptor descriptor;            // mp.descriptor
+    std::vector<std::int32_t> candidates;       // indices from kf.getFeaturesAround(...) (keyframe_matcher.cpp:340-344, :473, :596)
+};
+
+struct CandidateScores { std::vector<std::int32_t> best, second, bestOctave, secondOctave; std::vector<std::uint16_t> bestDist, secondDist; };
+
+namespace detail {
+inline CandidateScores score_candidates(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &qs,
+                                        const std::vector<std::uint8_t> *skip, std::size_t first = 0, std::size_t count = ~std::size_t(0)) {
+    count = std::min(count, qs.size() - first);
+    CandidateScores out;
+    out.best.assign(count, -1); out.second.assign(count, -1); out.bestOctave.assign(count, -1); out.secondOctave.assign(count, -1);
+    out.bestDist.assign(count, MS_HAMMING_MAX); out.secondDist.assign(count, MS_HAMMING_MAX);
+    if (count == 0) return out;
+    std::vector<std::uint32_t> desc(8 * count);
+    std::vector<std::int32_t> start(count + 1, 0), idx;
+    for (std::size_t i = 0; i < count; ++i) {
+        for (int k = 0; k < 8; ++k) desc[8 * i + k] = qs[first + i].descriptor[k];
+        idx.insert(idx.end(), qs[first + i].candidates.begin(), qs[first + i].candidates.end());
+        start[i + 1] = (std::int32_t)idx.size();
+    }
+    std::vector<void *> bufs;
+    auto up = [&](const void *src, std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d);
+                                                         if (bytes) ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); return d; };
+    auto dn = [&](std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d); return d; };
+    void *dq = up(desc.data(), desc.size() * 4), *ds = up(start.data(), start.size() * 4), *di = up(idx.data(), idx.size() * 4);
+    void *dk = skip ? up(skip->data(), skip->size()) : nullptr;
+    void *b = dn(4 * count), *bd = dn(2 * count), *sd = dn(2 * count), *bo = dn(4 * count), *so = dn(4 * count), *si = dn(4 * count);
+    const ms_match_frame &f = kf.frame();
+    ctx.check(ms_hamming_candidates(ctx.get(), static_cast<const std::uint32_t *>(dq), (int)count, f.desc, static_cast<const std::int32_t *>(ds),
+                                    static_cast<const std::int32_t *>(di), static_cast<const std::uint8_t *>(dk), f.octave, static_cast<std::int32_t *>(b),
+                                    static_cast<std::uint16_t *>(bd), static_cast<std::uint16_t *>(sd), static_cast<std::int32_t *>(bo),
+                                    static_cast<std::int32_t *>(so), static_cast<std::int32_t *>(si)), "ms_hamming_candidates");
+    ctx.check(ms_dev_download(ctx.get(), out.best.data(), b, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.second.data(), si, 4 * count), "download");
+    ctx.check(ms_dev_download(ctx.get(), out.bestDist.data(), bd, 2 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondDist.data(), sd, 2 * count), "download");
+    ctx.check(ms_dev_download(ctx.get(), out.bestOctave.data(), bo, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondOctave.data(), so, 4 * count), "download");
+    for (void *p : bufs) ms_dev_free(ctx.get(), p);
+    return out;
+}
+}  // namespace detail
+
+// Scoring + accept rule of searchByProjection (keyframe_matcher.cpp:349-389).  `bound[k]` != 0 marks keypoints that already
+// carry an observed map point (:358-360); it is updated as matches are accepted, in query order, exactly like the
+// reference's loop: all queries are scored in one launch against the initial mask, and a query whose best or second
+// candidate was taken by an earlier query of this call is re-scored (on the GPU) against the current mask.
+// Returns, per query, the matched keypoint index or -1; the caller performs addObservation (:388-389).
+inline std::vector<int> searchByProjectionCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &queries,
+                                               std::vector<std::uint8_t> &bound) {
+    std::vector<int> match(queries.size(), -1);
+    CandidateScores s = detail::score_candidates(ctx, kf, queries, &bound);
+    std::vector<std::uint8_t> taken(bound.size(), 0);            // bound during this call
+    for (std::size_t i = 0; i < queries.size(); ++i) {
+        int best = s.best[i], bestDist = s.bestDist[i], bestDist2 = s.secondDist[i], bestLevel = s.bestOctave[i], bestLevel2 = s.secondOctave[i];
+        if ((best >= 0 && taken[best]) || (s.second[i] >= 0 && taken[s.second[i]])) {        // greedy state changed under this query
+            CandidateScores r = detail::score_candidates(ctx, kf, queries, &bound, i, 1);
+            best = r.best[0]; bestDist = r.bestDist[0]; bestDist2 = r.secondDist[0]; bestLevel = r.bestOctave[0]; bestLevel2 = r.secondOctave[0];
+        }
+        if (best == -1) continue;                                                          // :380
+        if (bestDist <= (int)HAMMING_DIST_THR_HIGH) {                                        // :382-383
+            if (bestLevel == bestLevel2 && bestDist > 0.8 * bestDist2) continue;             // :385-386
+            match[i] = best; bound[best] = 1; taken[best] = 1;
+        }
+    }
+    return match;
+}
+
+// Scoring of replaceDuplication (keyframe_matcher.cpp:479-499: best only, accept <= 50) and findMatchesTranformedMps
+// (:600-627: accept <= 100; the caller pre-filters candidates by octave, :611).  No greedy state in the scoring itself.
+inline std::vector<int> bestCandidateCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &queries, unsigned maxDist) {
+    CandidateScores s = detail::score_candidates(ctx, kf, queries, nullptr);
+    std::vector<int> match(queries.size(), -1);
+    for (std::size_t i = 0; i < queries.size(); ++i) if (s.best[i] >= 0 && s.bestDist[i] <= maxDist) match[i] = s.best[i];
+    return match;
 }
 
 // create_E_21 (openvslam/essential_solver.cc:157-162), row-major 3x3

@@ -345,7 +345,7 @@ def hamming_candidates(ctx, q_desc, t_desc, cand_lists, t_skip=None, t_octave=No
     dsk = ctx.upload(np.asarray(t_skip, np.uint8)) if t_skip is not None else None
     doc = ctx.upload(np.asarray(t_octave, np.int32)) if t_octave is not None else None
     outs = [ctx.alloc(4 * nq + 16), ctx.alloc(2 * nq + 16), ctx.alloc(2 * nq + 16), ctx.alloc(4 * nq + 16), ctx.alloc(4 * nq + 16)]
-    ctx.check(lib().ms_hamming_candidates(ctx._h, _vp(dq), nq, _vp(dt), _vp(ds), _vp(di), _vp(dsk), _vp(doc), *[_vp(o) for o in outs]), "ms_hamming_candidates")
+    ctx.check(lib().ms_hamming_candidates(ctx._h, _vp(dq), nq, _vp(dt), _vp(ds), _vp(di), _vp(dsk), _vp(doc), *[_vp(o) for o in outs], None), "ms_hamming_candidates")
     ctx.sync()
     return (outs[0].download(np.int32, (nq,)), outs[1].download(np.uint16, (nq,)), outs[2].download(np.uint16, (nq,)),
             outs[3].download(np.int32, (nq,)), outs[4].download(np.int32, (nq,)))

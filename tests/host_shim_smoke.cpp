@@ -1,5 +1,6 @@
 // Compile + link check of the host-side C++ mirrors against libmi355slam.so; when a GPU is present it also runs one
 // extraction, one triangulation match and one two-stage local BA end to end (used by tests/test_host_shims.py).
+#include <algorithm>
 #include <cstdio>
 #include <cmath>
 #include "mi355slam/orb_extractor.hpp"
@@ -32,6 +33,47 @@ int main(int argc, char **argv) {
     double E[9]; create_E_21(R, t2, R, t1, E);
     auto matches = matchForTriangulationDBoW(ctx, d1, d2, E, settings);
     std::printf("triangulation matches %zu\n", matches.size());
+    // searchByProjection scoring: GPU batch + greedy replay vs the reference's sequential loop restated on the CPU
+    {
+        std::vector<ProjectionQuery> qs;
+        unsigned rng = 12345u;
+        auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+        for (int i = 0; i < 400; ++i) {
+            ProjectionQuery q;
+            q.descriptor = kps[rnd() % kps.size()].descriptor;
+            q.descriptor[rnd() % 8] ^= (1u << (rnd() % 32)) | (1u << (rnd() % 32));
+            const int nc = rnd() % 40;                                  // heavy overlap between queries -> greedy conflicts
+            for (int c = 0; c < nc; ++c) q.candidates.push_back((int)(rnd() % std::min<std::size_t>(kps.size(), 120)));
+            std::sort(q.candidates.begin(), q.candidates.end()); q.candidates.erase(std::unique(q.candidates.begin(), q.candidates.end()), q.candidates.end());
+            qs.push_back(q);
+        }
+        std::vector<std::uint8_t> bound(kps.size(), 0), bound_ref;
+        for (std::size_t k = 0; k < bound.size(); k += 7) bound[k] = 1;
+        bound_ref = bound;
+        auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { int d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
+        std::vector<int> want(qs.size(), -1);
+        for (std::size_t i = 0; i < qs.size(); ++i) {                   // keyframe_matcher.cpp:349-389
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int idx : qs[i].candidates) {
+                if (bound_ref[idx]) continue;
+                const int dist = popc(qs[i].descriptor, kps[idx].descriptor), level = kps[idx].octave;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = idx; }
+                else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+            }
+            if (bestIdx == -1) continue;
+            if (bestDist <= 100) { if (bestLevel == bestLevel2 && bestDist > 0.8 * bestDist2) continue; want[i] = bestIdx; bound_ref[bestIdx] = 1; }
+        }
+        std::vector<int> got = searchByProjectionCore(ctx, d1, qs, bound);
+        int nm = 0; for (int m : want) nm += m >= 0;
+        std::printf("searchByProjection: %d matches of %zu queries\n", nm, qs.size());
+        if (got != want || bound != bound_ref || nm < 20) { std::printf("searchByProjectionCore mismatch\n"); return 5; }
+        std::vector<int> dup = bestCandidateCore(ctx, d1, qs, HAMMING_DIST_THR_LOW);
+        for (std::size_t i = 0; i < qs.size(); ++i) {
+            int bd = 256, bi = -1;
+            for (int idx : qs[i].candidates) { const int d = popc(qs[i].descriptor, kps[idx].descriptor); if (d < bd) { bd = d; bi = idx; } }
+            if ((bi >= 0 && bd <= 50 ? bi : -1) != dup[i]) { std::printf("bestCandidateCore mismatch at %zu\n", i); return 6; }
+        }
+    }
     // a tiny two-stage local BA: 3 cameras on a line looking at 30 points
     BaWindow w; w.currentKeyframe = 2;
     for (int i = 0; i < 3; ++i) w.poses.push_back({0, 0, 0, 1, -0.2 * i, 0, 0});
