@@ -89,6 +89,8 @@ typedef struct {
     int32_t fast_threshold;    /* this build's detector: FAST-9/16 threshold (score > threshold) */
     int32_t max_tracks;        /* capacity for tracker features per frame */
     int32_t max_batch;         /* frames per ms_orb_extract call (>= 1) */
+    float min_distance;        /* parameters.tracker.gfttMinDistance (feature_detector.cpp:79-82): keypoints of a level keep
+                                  floor(min_distance * min(w,h)/720 * 0.8 + 0.5) pixels apart; 0 = no suppression */
 } ms_orb_config;
 
 /* Per-frame outputs, structure-of-arrays, `capacity` = max_tracks + max_kpts slots per frame.

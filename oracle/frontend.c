@@ -198,7 +198,13 @@ static int cmp_u32(const void *a, const void *b) {
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
-int mso_detect_level(const uint8_t *img, int w, int h, int stride, int threshold, int quota,
+int mso_level_min_dist(float g, int w, int h) {      /* feature_detector.cpp:79-82 */
+    const int minDim = w < h ? w : h;
+    const double su = minDim / 720.0 * 0.8;
+    return (int)floor(g * su + 0.5);
+}
+
+int mso_detect_level(const uint8_t *img, int w, int h, int stride, int threshold, int quota, int min_dist,
                      int *xs, int *ys, int *scores) {
     if (w < 7 || h < 7 || quota <= 0) return 0;
     uint8_t *sc = (uint8_t *)calloc((size_t)w * h, 1);
@@ -228,6 +234,20 @@ int mso_detect_level(const uint8_t *img, int w, int h, int stride, int threshold
             if (ok && nk < cap) keys[nk++] = ((uint32_t)(255 - s) << 24) | (uint32_t)(y * w + x);
         }
     qsort(keys, nk, sizeof(uint32_t), cmp_u32);
+    if (min_dist >= 2) {            /* greedy minimum-distance walk over the best min(4*quota, 4096) corners */
+        size_t M = (size_t)4 * quota; if (M > 4096) M = 4096; if (M > nk) M = nk;
+        size_t kept = 0;
+        for (size_t i = 0; i < M && kept < (size_t)quota; ++i) {
+            const int idx = (int)(keys[i] & 0xFFFFFFu), x = idx % w, y = idx / w;
+            int ok = 1;
+            for (size_t j = 0; j < kept; ++j) {
+                const int jd = (int)(keys[j] & 0xFFFFFFu), dx = x - jd % w, dy = y - jd / w;
+                if (dx * dx + dy * dy < min_dist * min_dist) { ok = 0; break; }
+            }
+            if (ok) keys[kept++] = keys[i];
+        }
+        nk = kept;
+    }
     if (nk > (size_t)quota) nk = (size_t)quota;     /* maxTracks = quota_l (feature_detector.cpp:39) */
     int n = 0;
     for (size_t i = 0; i < nk; ++i) {
@@ -384,7 +404,8 @@ int mso_orb_extract(const mso_orb_config *cfg, const uint8_t *img, int w, int h,
     for (int l = 0; l < cfg->levels; ++l) if (quota[l] > maxq) maxq = quota[l];
     int *xs = (int *)malloc(sizeof(int) * (maxq + 1)), *ys = (int *)malloc(sizeof(int) * (maxq + 1));
     for (int l = 0; l < cfg->levels; ++l) {
-        const int k = mso_detect_level(P.img[l], P.w[l], P.h[l], P.w[l], cfg->fast_threshold, quota[l], xs, ys, NULL);
+        const int k = mso_detect_level(P.img[l], P.w[l], P.h[l], P.w[l], cfg->fast_threshold, quota[l],
+                                       mso_level_min_dist(cfg->min_distance, P.w[l], P.h[l]), xs, ys, NULL);
         for (int i = 0; i < k && n < capacity; ++i) {
             const float fx = (float)xs[i], fy = (float)ys[i];
             if (!mask_valid(valid_mask, w, h, fx * sf[l], fy * sf[l])) continue;   /* dropInvalidKeypoints :221-237 */

@@ -48,9 +48,14 @@ extern const int mso_gauss7_q8[7];
 int mso_fast_score(const uint8_t *img, int stride, int x, int y);
 /* Detect on one level: FAST score > threshold, 3x3 strict NMS, top-`quota` by
  * key = ((255-score)<<24 | y*w+x) ascending, then the 19 px border filter of
- * feature_detector.cpp:106-123.  Returns count; xs/ys sized >= quota. */
-int mso_detect_level(const uint8_t *img, int w, int h, int stride, int threshold, int quota,
+ * feature_detector.cpp:106-123.  With min_dist >= 2 the best min(4*quota, 4096) corners are walked in key order and a
+ * corner is kept only if no already kept corner lies closer than min_dist (squared distance < min_dist^2), until `quota`
+ * are kept (the maxTracks / minDistance contract of the external detector call, feature_detector.cpp:97-98).
+ * Returns count; xs/ys sized >= quota. */
+int mso_detect_level(const uint8_t *img, int w, int h, int stride, int threshold, int quota, int min_dist,
                      int *xs, int *ys, int *scores);
+/* feature_detector.cpp:79-82: per-level minimum distance from gfttMinDistance */
+int mso_level_min_dist(float gftt_min_distance, int w, int h);
 
 /* ---- O1/O2: orientation + descriptor (orb_extractor.cpp:245-352) ---- */
 float mso_fast_atan2(float y, float x);               /* cv::fastAtan2 restated */
@@ -67,6 +72,7 @@ typedef struct {
     int max_kpts;          /* maxKeypoints */
     int lk_track_level;    /* orbLkTrackLevel */
     int fast_threshold;    /* detector threshold (this build's detector) */
+    float min_distance;    /* tracker.gfttMinDistance (0 = no suppression) */
 } mso_orb_config;
 
 typedef struct {

@@ -23,7 +23,7 @@ f64p = C.POINTER(C.c_double)
 
 class OrbConfig(C.Structure):
     _fields_ = [("levels", C.c_int), ("scale_factor", C.c_float), ("max_kpts", C.c_int),
-                ("lk_track_level", C.c_int), ("fast_threshold", C.c_int)]
+                ("lk_track_level", C.c_int), ("fast_threshold", C.c_int), ("min_distance", C.c_float)]
 
 
 class Keypoints(C.Structure):
@@ -66,8 +66,8 @@ def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
 
 
-def cfg(levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0, fast_threshold=20):
-    return OrbConfig(levels, scale_factor, max_kpts, lk_track_level, fast_threshold)
+def cfg(levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0, fast_threshold=20, min_distance=0.0):
+    return OrbConfig(levels, scale_factor, max_kpts, lk_track_level, fast_threshold, min_distance)
 
 
 # ---- geometry ----
@@ -154,14 +154,18 @@ def fast_score_map(img, threshold=0):
     return out
 
 
-def detect_level(img, threshold, quota):
+def detect_level(img, threshold, quota, min_dist=0):
     img = np.ascontiguousarray(img, np.uint8)
     xs = np.zeros(quota + 1, np.int32)
     ys = np.zeros(quota + 1, np.int32)
     sc = np.zeros(quota + 1, np.int32)
-    n = lib().mso_detect_level(_p(img, u8p), img.shape[1], img.shape[0], img.shape[1], threshold, quota,
+    n = lib().mso_detect_level(_p(img, u8p), img.shape[1], img.shape[0], img.shape[1], threshold, quota, int(min_dist),
                                _p(xs, i32p), _p(ys, i32p), _p(sc, i32p))
     return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def level_min_dist(g, w, h):
+    return int(lib().mso_level_min_dist(C.c_float(g), int(w), int(h)))
 
 
 def ic_angle(img, x, y):

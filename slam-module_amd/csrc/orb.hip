@@ -30,6 +30,7 @@ constexpr int kMaxQuota = 4096;                      // per-level selection capa
 
 struct LevelGeom {
     int32_t w, h, pitch, quota;
+    int32_t min_dist;                 // per-level minimum keypoint distance (0/1 = none), feature_detector.cpp:79-82
     int32_t det_base;                 // first slot of this level in det arrays (prefix of quotas)
     int32_t cand_cap;                 // capacity of this level's candidate list (entries)
     int32_t btiles_x, btile_base;     // k_blur tile table (248x16 tiles)
@@ -384,23 +385,34 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
 // validity mask (dropInvalidKeypoints, orb_extractor.cpp:221-237) with an ORDERED compaction.
 // Radix select (4 x 8 bits, LDS histogram) -> LDS bitonic sort of <= 4096 keys.  Deterministic:
 // the unordered candidate list only feeds order-insensitive steps.
+// With a minimum distance (gfttMinDistance scaled per level, feature_detector.cpp:79-82) the best
+// min(4*quota, 4096) corners are sorted and the sequential "keep a corner unless a kept one is closer than
+// min_dist" walk is solved as a parallel fixed point: corners are hashed into an LDS grid (cell >= min_dist), a
+// corner is rejected as soon as an earlier kept neighbour exists and kept once all its earlier neighbours are
+// decided -- the unique fixed point is exactly the greedy result; the first `quota` kept corners are output.
+constexpr int kGridCells = 8192;
+
+template <bool SPACED>   // SPACED: some level has a minimum keypoint distance (uses 66 KB more LDS for the grid)
 __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t *__restrict__ cand, const int32_t *__restrict__ cand_count,
                                                 const uint8_t *__restrict__ valid_mask,
                                                 int16_t *__restrict__ det_x, int16_t *__restrict__ det_y, uint8_t *__restrict__ det_score,
                                                 int32_t *__restrict__ det_count) {
     __shared__ uint32_t s_key[kMaxQuota];
     __shared__ int s_hist[256];
-    __shared__ int s_cnt, s_digit, s_k, s_run;
-    __shared__ int s_scan[256];
+    __shared__ int s_cnt, s_digit, s_k, s_run, s_kept, s_open;
+    __shared__ int s_scan[256], s_scan2[256];
+    __shared__ uint8_t s_state[SPACED ? kMaxQuota : 1];          // 0 undecided, 1 kept, 2 rejected
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom &G = g->L[l];
     const uint32_t *keys = cand + (uint64_t)f * g->cand_stride + G.cand_off;
     const int n = min(cand_count[f * g->levels + l], G.cand_cap);
-    const int quota = G.quota;
+    const int quota = G.quota, min_dist = G.min_dist;
+    const bool spaced = SPACED && min_dist >= 2;
+    const int want = spaced ? min(4 * quota, kMaxQuota) : quota;      // how many of the strongest corners are sorted
     uint32_t kth = 0xFFFFFFFFu;
-    if (n > quota && quota > 0) {
+    if (n > want && want > 0) {
         uint32_t prefix = 0, mask = 0;
-        if (tid == 0) s_k = quota;
+        if (tid == 0) s_k = want;
         for (int shift = 24; shift >= 0; shift -= 8) {
             s_hist[tid] = 0;
             __syncthreads();
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    if (quota > 0)
+    if (want > 0)
         for (int i = tid; i < n; i += 256) {
             const uint32_t k = keys[i];
             if (k <= kth) { const int p = atomicAdd(&s_cnt, 1); if (p < kMaxQuota) s_key[p] = k; }
@@ -446,17 +458,75 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
             }
             __syncthreads();
         }
-    // ordered compaction of the survivors of the border / validity filter
-    if (tid == 0) s_run = 0;
+    // minimum-distance walk as a fixed point
+    if constexpr (SPACED) if (spaced) {
+        __shared__ int16_t s_x[kMaxQuota], s_y[kMaxQuota], s_next[kMaxQuota];
+        __shared__ int s_head[kGridCells];
+        int cell = min_dist;
+        while (((G.w + cell - 1) / cell) * ((G.h + cell - 1) / cell) > kGridCells) ++cell;
+        const int gw = (G.w + cell - 1) / cell, gh = (G.h + cell - 1) / cell;
+        for (int i = tid; i < gw * gh; i += 256) s_head[i] = -1;
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) {
+            const int idx = (int)(s_key[i] & 0xFFFFFFu), y = idx / G.w, x = idx - y * G.w;
+            s_x[i] = (int16_t)x; s_y[i] = (int16_t)y; s_state[i] = 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < m; i += 256)                      // cell lists (their internal order does not matter)
+            s_next[i] = (int16_t)atomicExch(&s_head[(s_y[i] / cell) * gw + s_x[i] / cell], i);
+        __syncthreads();
+        const int d2 = min_dist * min_dist;
+        for (int round = 0; round < kMaxQuota; ++round) {
+            if (tid == 0) s_open = 0;
+            __syncthreads();
+            for (int i = tid; i < m; i += 256) {
+                if (s_state[i]) continue;
+                const int x = s_x[i], y = s_y[i], cx = x / cell, cy = y / cell;
+                bool rejected = false, waiting = false;
+                for (int yy = max(cy - 1, 0); yy <= min(cy + 1, gh - 1) && !rejected; ++yy)
+                    for (int xx = max(cx - 1, 0); xx <= min(cx + 1, gw - 1) && !rejected; ++xx)
+                        for (int j = s_head[yy * gw + xx]; j >= 0; j = s_next[j]) {
+                            if (j >= i) continue;                       // only corners earlier in key order matter
+                            const int dx = x - s_x[j], dy = y - s_y[j];
+                            if (dx * dx + dy * dy >= d2) continue;
+                            const int st = s_state[j];
+                            if (st == 1) { rejected = true; break; }
+                            if (st == 0) waiting = true;
+                        }
+                if (rejected) s_state[i] = 2;
+                else if (!waiting) s_state[i] = 1;
+                else s_open = 1;
+            }
+            __syncthreads();
+            const int open = s_open;
+            __syncthreads();
+            if (!open) break;
+        }
+    }
+    // ordered compaction: first `quota` kept corners, then the border / validity filter
+    if (tid == 0) { s_run = 0; s_kept = 0; }
     __syncthreads();
     const int W0 = g->width, H0 = g->height;
     for (int base = 0; base < m; base += 256) {
         const int i = base + tid;
-        int x = 0, y = 0, sc = 0, ok = 0;
+        int x = 0, y = 0, sc = 0, keep = 0;
         if (i < m) {
             const uint32_t k = s_key[i];
             const int idx = (int)(k & 0xFFFFFFu);
             y = idx / G.w; x = idx - y * G.w; sc = 255 - (int)(k >> 24);
+            keep = spaced ? (s_state[i] == 1) : 1;
+        }
+        s_scan2[tid] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? s_scan2[tid - off] : 0;
+            __syncthreads();
+            s_scan2[tid] += v;
+            __syncthreads();
+        }
+        const int kept_before = s_kept;
+        int ok = keep && (kept_before + s_scan2[tid] - 1 < quota);        // maxTracks = quota_l
+        if (ok) {
             ok = x >= kPatchRadius && y >= kPatchRadius && x < G.w - kPatchRadius && y < G.h - kPatchRadius;
             if (ok && valid_mask) {
                 const int mx = __float2int_rn(__fmul_rn((float)x, G.scale)), my = __float2int_rn(__fmul_rn((float)y, G.scale));
@@ -477,7 +547,7 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
             det_x[slot] = (int16_t)x; det_y[slot] = (int16_t)y; det_score[slot] = (uint8_t)sc;
         }
         __syncthreads();
-        if (tid == 255) s_run = run + s_scan[255];
+        if (tid == 255) { s_run = run + s_scan[255]; s_kept = kept_before + s_scan2[255]; }
         __syncthreads();
     }
     if (tid == 0) det_count[f * g->levels + l] = s_run;
@@ -697,7 +767,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     *out = nullptr;
     if (cfg->levels < 1 || cfg->levels > MS_MAX_LEVELS || cfg->max_kpts < 1 || cfg->max_batch < 1 || cfg->max_tracks < 0 ||
         cfg->lk_track_level < 0 || cfg->lk_track_level >= cfg->levels || cfg->fast_threshold < 1 || cfg->fast_threshold > 254 ||
-        !(cfg->scale_factor > 1.0f) || cfg->width > 32767 || cfg->height > 32767 ||
+        !(cfg->scale_factor > 1.0f) || !(cfg->min_distance >= 0.f) || cfg->width > 32767 || cfg->height > 32767 ||
         (int64_t)cfg->width * cfg->height >= (1 << 24))
         return ms_fail(ctx, MS_ERR_INVALID, "ms_orb_create: unsupported configuration");
     MS_HIP(ctx, hipSetDevice(ctx->device));
@@ -723,6 +793,10 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         }
         LevelGeom &L = G.L[l];
         L.w = w[l]; L.h = h[l]; L.pitch = (int)ms_align_up(w[l], 64); L.quota = quota[l]; L.scale = sf[l];
+        {   // feature_detector.cpp:79-82: minDist = floor(gfttMinDistance * (min(w,h) / 720 * 0.8) + 0.5)
+            const double su = std::min(w[l], h[l]) / 720.0 * 0.8;
+            L.min_dist = (int)std::floor(cfg->min_distance * su + 0.5);
+        }
         L.det_base = det_base; det_base += quota[l];
         L.img_off = off; off += (uint64_t)L.pitch * L.h;
         L.blur_off = off; off += (uint64_t)L.pitch * L.h;
@@ -886,8 +960,12 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
-    hipLaunchKernelGGL(k_select, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
-                       o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+    if (o->cfg.min_distance > 0.f)
+        hipLaunchKernelGGL(k_select<true>, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
+                           o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+    else
+        hipLaunchKernelGGL(k_select<false>, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
+                           o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
     MS_KERNEL_CHECK(c, "k_select");
     MS_STAGE_MARK();
     hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,

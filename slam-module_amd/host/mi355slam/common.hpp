@@ -23,6 +23,7 @@ struct Parameters {
     unsigned orbLkTrackLevel = 0;
     int fastThreshold = 20;                       // this build's detector (feature_detector.cpp:89-98 is external)
     unsigned maxTracks = 512;
+    float gfttMinDistance = 0.f;                  // tracker.gfttMinDistance (feature_detector.cpp:79-82); 0 = off
     float loopClosureFeatureMatchLoweRatio = 0.75f;
     bool requireTringulationForLoopClosures = true;
     float epipolarCheckThresholdDegrees = 2.0f;

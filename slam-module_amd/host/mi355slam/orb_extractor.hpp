@@ -35,7 +35,7 @@ public:
         const auto &p = settings_.parameters;
         if (!orb_) {                                                     // lazily built on the first frame (:80-81)
             ms_orb_config c{img.width, img.height, (int)p.orbScaleLevels, p.orbScaleFactor, (int)p.maxKeypoints,
-                            (int)p.orbLkTrackLevel, p.fastThreshold, (int)p.maxTracks, 1};
+                            (int)p.orbLkTrackLevel, p.fastThreshold, (int)p.maxTracks, 1, p.gfttMinDistance};
             ctx_.check(ms_orb_create(ctx_.get(), &c, &orb_), "ms_orb_create");
             cap_ = ms_orb_capacity(orb_);
             x_.resize(cap_); y_.resize(cap_); a_.resize(cap_); o_.resize(cap_); t_.resize(cap_); d_.resize(8 * (std::size_t)cap_);

@@ -29,7 +29,7 @@ class MsError(RuntimeError):
 class OrbConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("levels", C.c_int32), ("scale_factor", C.c_float),
                 ("max_kpts", C.c_int32), ("lk_track_level", C.c_int32), ("fast_threshold", C.c_int32),
-                ("max_tracks", C.c_int32), ("max_batch", C.c_int32)]
+                ("max_tracks", C.c_int32), ("max_batch", C.c_int32), ("min_distance", C.c_float)]
 
 
 class KeypointsView(C.Structure):
@@ -200,9 +200,9 @@ class OrbExtractor:
     """Mirror of slam::OrbExtractor (orb_extractor.hpp:11-30) over the C ABI, batched."""
 
     def __init__(self, ctx, width, height, levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0,
-                 fast_threshold=20, max_tracks=0, max_batch=1):
+                 fast_threshold=20, max_tracks=0, max_batch=1, min_distance=0.0):
         self.ctx = ctx
-        self.cfg = OrbConfig(width, height, levels, scale_factor, max_kpts, lk_track_level, fast_threshold, max_tracks, max_batch)
+        self.cfg = OrbConfig(width, height, levels, scale_factor, max_kpts, lk_track_level, fast_threshold, max_tracks, max_batch, min_distance)
         self._h = C.c_void_p()
         ctx.check(lib().ms_orb_create(ctx._h, C.byref(self.cfg), C.byref(self._h)), "ms_orb_create")
         ctx._children.append(weakref.ref(self))

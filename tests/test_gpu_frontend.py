@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _cfg(oracle, **kw):
-    d = dict(levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0, fast_threshold=20)
+    d = dict(levels=8, scale_factor=1.2, max_kpts=2000, lk_track_level=0, fast_threshold=20, min_distance=0.0)
     d.update(kw)
     return oracle.cfg(**d), d
 
@@ -20,7 +20,7 @@ def _extract_both(oracle, ctx, imgs, mask=None, tracks=None, track_ids=None, max
     n, h, w = imgs.shape
     ex = mi355slam.OrbExtractor(ctx, w, h, levels=d["levels"], scale_factor=d["scale_factor"], max_kpts=d["max_kpts"],
                                 lk_track_level=d["lk_track_level"], fast_threshold=d["fast_threshold"],
-                                max_tracks=max_tracks, max_batch=n)
+                                max_tracks=max_tracks, max_batch=n, min_distance=d["min_distance"])
     if mask is not None:
         ex.set_valid_mask(mask)
     ex.extract(imgs, track_xy=tracks, track_id=track_ids)
@@ -140,3 +140,24 @@ def test_extract_is_deterministic_across_runs(oracle, ctx):
     b = [ex.download(f) for f in range(4)]
     for f in range(4):
         _assert_same_keypoints(a[f], b[f])
+
+
+def test_min_distance_suppression(oracle, ctx):
+    """gfttMinDistance (feature_detector.cpp:79-82): greedy spacing in key order, solved as a parallel fixed point on the GPU."""
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    for img, kw in [(oracle.synth_frame(1280, 720, 1005), dict(min_distance=12.0)),
+                    (oracle.synth_frame(640, 480, 1006), dict(min_distance=30.0)),
+                    (noise, dict(min_distance=20.0, levels=4, max_kpts=1200)),          # saturated levels: long dependency chains
+                    (oracle.synth_frame(640, 480, 1007), dict(min_distance=3.0))]:     # tiny distance: coarser grid cells than min_dist
+        ex, got, want = _extract_both(oracle, ctx, img[None], **kw)
+        _assert_same_keypoints(got[0], want[0])
+        # the spacing really holds per level, in level coordinates
+        cfgd = dict(levels=8, scale_factor=1.2); cfgd.update({k: v for k, v in kw.items() if k in ("levels", "scale_factor")})
+        for l in range(cfgd["levels"]):
+            x, y, _ = ex.download_detections(0, l)
+            w, h = ex.level_size(l)
+            md = oracle.level_min_dist(kw["min_distance"], w, h)
+            if md >= 2 and len(x) > 1:
+                d2 = (x[:, None] - x[None, :]) ** 2 + (y[:, None] - y[None, :]) ** 2 + np.eye(len(x), dtype=np.int64) * 10**9
+                assert d2.min() >= md * md, (l, md)

@@ -177,3 +177,19 @@ def test_extractor_order_and_empty_output(oracle):
     yy, xx = np.mgrid[0:480, 0:640]
     ramp = ((xx * 96) // 639 + (yy * 64) // 479).astype(np.uint8)
     assert len(oracle.orb_extract(oracle.cfg(), ramp)["x"]) == 0
+
+
+def test_min_distance_rule(oracle):
+    """feature_detector.cpp:79-82 scaling + the greedy spacing walk of the detector."""
+    assert oracle.level_min_dist(10.0, 1280, 720) == 8 and oracle.level_min_dist(10.0, 357, 201) == 2 and oracle.level_min_dist(0.0, 1280, 720) == 0
+    img = np.zeros((120, 160), np.uint8)
+    pts = [(40, 40, 220), (46, 40, 200), (40, 47, 180), (90, 60, 150), (93, 62, 140)]     # (x, y, value): isolated dots = corners with that score
+    for x, y, v in pts:
+        img[y, x] = v
+    xs, ys, sc = oracle.detect_level(img, 20, 10, min_dist=0)
+    assert sorted(sc.tolist(), reverse=True) == [220, 200, 180, 150, 140]
+    xs, ys, sc = oracle.detect_level(img, 20, 10, min_dist=8)
+    # 200 is 6 px from 220 -> dropped; 180 is 7 px from 220 -> dropped; 140 is ~3.6 px from 150 -> dropped
+    assert list(zip(xs.tolist(), ys.tolist(), sc.tolist())) == [(40, 40, 220), (90, 60, 150)]
+    xs, ys, sc = oracle.detect_level(img, 20, 10, min_dist=7)      # 180 at distance exactly 7 survives (strict <)
+    assert sc.tolist() == [220, 180, 150]
