@@ -844,6 +844,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
                  free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow; };
     std::vector<Off> off(n);
+    std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
         const ms_ba_problem &Q = problems[p];
         if (Q.n_pose < 1 || Q.n_point < 0 || Q.n_obs < 0 || Q.n_pose_edge < 0 || !Q.pose || !Q.pose_fixed || (Q.n_point && !Q.point) ||
@@ -911,17 +912,20 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
-        O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.pose0 = bump(7 * Q.n_pose * D);
-        O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D); O.point0 = bump(3 * Q.n_point * D);
+        // inputs first, contiguous: they go up in ONE host->device copy per problem
+        in_lo[p] = total;
+        O.pose0 = bump(7 * Q.n_pose * D); O.point0 = bump(3 * Q.n_point * D);
         O.pidx = bump(4 * Q.n_pose); O.pfix = bump(Q.n_point);
         O.obs_pose = bump(4 * Q.n_obs); O.obs_point = bump(4 * Q.n_obs); O.obs_uv = bump(2 * Q.n_obs * D); O.obs_info = bump(Q.n_obs * D);
         O.pt_start = bump(4 * (Q.n_point + 1)); O.pt_obs = bump(4 * Q.n_obs); O.fstart = bump(4 * (R.np_free + 1)); O.fobs = bump(4 * R.fobs.size());
         O.free2pose = bump(4 * R.np_free); O.edge_i = bump(4 * Q.n_pose_edge); O.edge_j = bump(4 * Q.n_pose_edge);
         O.edge_meas = bump(7 * Q.n_pose_edge * D); O.edge_info = bump(36 * Q.n_pose_edge * D);
+        O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
+        in_hi[p] = total;
+        O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
         O.Hll = bump(6 * Q.n_point * D); O.bl = bump(3 * Q.n_point * D); O.Hinv = bump(6 * Q.n_point * D); O.Hpl = bump(18 * ((size_t)Q.n_obs + 1) * D);
         O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(16 * D);
-        O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
         O.Y = bump(18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
     }
     ms_ba *B = new ms_ba();
@@ -933,9 +937,11 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     }
     (void)hipMemsetAsync(B->d_arena, 0, total, c->stream);
     B->host.resize(n); B->dims.assign(problems, problems + n);
-    auto up = [&](size_t o, const void *src, size_t bytes) { if (bytes) (void)hipMemcpyAsync(B->d_arena + o, src, bytes, hipMemcpyHostToDevice, c->stream); };
+    std::vector<char> stage;
     for (int p = 0; p < n; ++p) {
         const ms_ba_problem &Q = problems[p]; const Prep &R = prep[p]; const Off &O = off[p]; const size_t D = sizeof(double);
+        stage.assign(in_hi[p] - in_lo[p], 0);
+        auto up = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(stage.data() + (o - in_lo[p]), src, bytes); };
         up(O.pose0, Q.pose, 7 * Q.n_pose * D); up(O.point0, Q.point, 3 * Q.n_point * D);
         up(O.pidx, R.pidx.data(), 4 * Q.n_pose); if (Q.point_fixed) up(O.pfix, Q.point_fixed, Q.n_point);
         up(O.obs_pose, Q.obs_pose, 4 * Q.n_obs); up(O.obs_point, Q.obs_point, 4 * Q.n_obs); up(O.obs_uv, Q.obs_uv, 2 * Q.n_obs * D); up(O.obs_info, Q.obs_info, Q.n_obs * D);
@@ -943,7 +949,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.fstart, R.fstart.data(), 4 * (R.np_free + 1)); up(O.fobs, R.fobs.data(), 4 * R.fobs.size()); up(O.free2pose, R.free2pose.data(), 4 * R.np_free);
         up(O.chunk_items, R.chunk_items.data(), 4 * R.chunk_items.size()); up(O.seg_start, R.seg_start.data(), 4 * R.seg_start.size()); up(O.seg_pair, R.seg_pair.data(), 4 * R.seg_pair.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
-        (void)hipStreamSynchronize(c->stream);      // the Prep vectors / caller arrays may be pageable: finish before they go away
+        if (hipMemcpyAsync(B->d_arena + in_lo[p], stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
         BaProb &H = B->host[p];
         char *a = B->d_arena;
         H.n_pose = Q.n_pose; H.n_point = Q.n_point; H.n_obs = Q.n_obs; H.n_edge = Q.n_pose_edge; H.np_free = R.np_free; H.n6 = 6 * R.np_free;
