@@ -34,8 +34,8 @@ constexpr int NT = 512;          // threads per problem
 constexpr int NW = NT / 64;      // waves
 constexpr int NB = 16;           // Cholesky panel width
 constexpr int CH = 32;           // Schur work items (pairs of observations of one point) per chunk
-constexpr int kMaxFreePoses = 96;
-constexpr size_t kLdsBytes = 80 * 1024;   // Cholesky panel: (6*96+1) rows x 16 doubles + scratch
+constexpr int kMaxFreePoses = 176;   // Cholesky panel (6*176+1) x 16 doubles + solution vector must fit the LDS budget
+constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
 
 struct BaProb {
     int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters, pad_;

@@ -59,7 +59,7 @@ def make_problem(n_pose=50, n_point=2000, run=10, seed=42, noise=1.0 / 500, pert
     gt_pose = []
     for i in range(n_pose):
         c = np.array([0.2 * i - 0.1 * (n_pose - 1), 0.05 * np.sin(0.3 * i), 0.02 * i])
-        R = _rotvec(np.array([0.0, 0.004 * (i - n_pose / 2), 0.0])) @ _rotvec(np.array([0.01 * np.sin(i), 0, 0]))
+        R = _rotvec(np.array([0.0, (0.004 if n_pose <= 50 else 0.2 / n_pose) * (i - n_pose / 2), 0.0])) @ _rotvec(np.array([0.01 * np.sin(i), 0, 0]))
         gt_pose.append(_pose(R, -R @ c))                      # world->camera
     gt_pose = np.array(gt_pose)
     half = 0.1 * (n_pose - 1)

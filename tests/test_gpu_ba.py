@@ -96,3 +96,11 @@ def test_batch_of_c4_problems_runs_in_parallel(oracle, ctx):
     ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=10); ba.solve()
     for i in (0, 2):
         _check(probs[i], ba.download(i), oracle.ba_solve(probs[i], 10, False))
+
+
+def test_global_ba_sized_window(oracle, ctx):
+    """globalBundleAdjust-sized problem (bundle_adjuster.cpp:493-604): 150 keyframes, current one fixed (:515), 12 LM iterations."""
+    import mi355slam
+    p = ba_synth.make_problem(150, 1500, 12, seed=77, fix_first=True)
+    ba = mi355slam.BundleAdjuster(ctx, [p], max_iters=12); ba.solve()
+    _check(p, ba.download(0), oracle.ba_solve(p, 12, False))

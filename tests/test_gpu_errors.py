@@ -54,14 +54,14 @@ def test_hamming_argument_checks(ctx):
 
 def test_ba_capacity_and_index_checks(ctx):
     import mi355slam
-    big = ba_synth.make_problem(100, 50, 5, seed=1)                          # 100 free poses > 96
+    big = ba_synth.make_problem(180, 50, 5, seed=1)                          # 180 free poses > 176
     with pytest.raises(mi355slam.MsError, match="free poses"):
         mi355slam.BundleAdjuster(ctx, [big])
     bad = ba_synth.make_problem(5, 20, 3, seed=2)
     bad["obs_point"] = bad["obs_point"].copy(); bad["obs_point"][3] = 999
     with pytest.raises(mi355slam.MsError, match="outside"):
         mi355slam.BundleAdjuster(ctx, [bad])
-    ok = ba_synth.make_problem(96, 300, 8, seed=3)                           # exactly at the limit works
+    ok = ba_synth.make_problem(176, 400, 8, seed=3)                          # exactly at the limit works
     ba = mi355slam.BundleAdjuster(ctx, [ok], max_iters=3); ba.solve()
     out = ba.download(0)
     assert out["stats"]["chi2_final"] < out["stats"]["chi2_init"]
