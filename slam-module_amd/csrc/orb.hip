@@ -48,6 +48,16 @@ struct PyrGeom {
     LevelGeom L[MS_MAX_LEVELS];
 };
 
+// first tile id of every level, passed BY VALUE (kernel-argument SGPRs): finding a block's level must not be a chain of
+// dependent loads from the geometry table (that chain was a third of k_fast's wave time)
+struct TileMap { int32_t base[MS_MAX_LEVELS + 1]; };
+__device__ __forceinline__ int tile_level(const TileMap &tm, int levels, int t) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < MS_MAX_LEVELS; ++k) l += (k < levels && t >= tm.base[k]) ? 1 : 0;
+    return l;
+}
+
 struct FrameSrc {          // where pyramid level 0 lives for this call
     const uint8_t *lvl0;
     uint64_t lvl0_frame_stride;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
 // ------------------------------------------------------------------------------------------------
 // P2: cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8U fixed point (image_pyramid.cpp:84).
 // One launch covers every level of every frame (tile table in PyrGeom).  No LDS: a lane owns one dword
-// (4 pixels) of a row; a wave owns a 256-pixel row segment and walks 4 output rows.
+// (4 pixels) of a row; a wave owns a 256-pixel row segment and walks 8 output rows.
 //   vertical pass   on the raw bytes, two pixels per instruction: even/odd bytes of the dword are two
 //                   16-bit lanes (sums stay < 2^16 because the 8.8 taps add up to 256) -> v_pk_mad_u16
 //   horizontal pass on the 16-bit column sums of the lane and its two neighbours (ds_bpermute shuffles),
@@ -175,29 +185,41 @@ __device__ __forceinline__ uint32_t dot2(uint32_t a, unsigned lo, unsigned hi, u
 }
 
 constexpr int kBlurSeg = 248;   // outputs per wave row segment
+constexpr int kBlurRows = 8;    // output rows per wave (kBlurRows + 6 input rows are loaded: 1.75x read amplification through L1)
 
-__global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g) {
-    int t = blockIdx.x, l = 0;
-    while (l + 1 < g->levels && t >= g->L[l + 1].btile_base) ++l;
-    t -= g->L[l].btile_base;
+__global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, TileMap tm, int levels) {
+    int t = blockIdx.x;
+    const int l = tile_level(tm, levels, t);
+    t -= tm.base[l];
     const LevelGeom &G = g->L[l];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (t % G.btiles_x) * kBlurSeg - 4 + lane * 4;
-    const int y0 = (t / G.btiles_x) * 16 + wave * 4;
+    const int y0 = (t / G.btiles_x) * (4 * kBlurRows) + wave * kBlurRows;
     const int f = blockIdx.y, w = G.w, h = G.h;
     if (y0 >= h) return;
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
-    uint32_t e[10], o[10];
+    uint32_t e[kBlurRows + 6], o[kBlurRows + 6];
+    // the column test is the same for every row of a lane: ONE wave-uniform branch picks the plain-dword path for whole waves
+    // (per-load branches cost scalar instructions, and the scalar unit is shared by the CU's four SIMDs)
+    if (__ballot(!(x >= 0 && x + 3 < w)) == 0) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t d = load4_reflect(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch, x, w);
-        e[r] = d & 0x00FF00FFu;
-        o[r] = (d >> 8) & 0x00FF00FFu;
+        for (int r = 0; r < kBlurRows + 6; ++r) {
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch + x);
+            e[r] = d & 0x00FF00FFu;
+            o[r] = (d >> 8) & 0x00FF00FFu;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kBlurRows + 6; ++r) {
+            const uint32_t d = load4_reflect(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch, x, w);
+            e[r] = d & 0x00FF00FFu;
+            o[r] = (d >> 8) & 0x00FF00FFu;
+        }
     }
     uint8_t *dst = blur_ptr(src, g, f, l);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kBlurRows; ++j) {
         const uint32_t Ce = vsum7(e + j), Co = vsum7(o + j);            // columns (x, x+2) and (x+1, x+3)
         const uint32_t Le = __shfl_up(Ce, 1, 64), Lo = __shfl_up(Co, 1, 64);
         const uint32_t Re = __shfl_down(Ce, 1, 64), Ro = __shfl_down(Co, 1, 64);
@@ -251,25 +273,36 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
 }
 
-// counts of brighter / darker compass pixels, packed 16-bit lanes (pixels 0,2 in E, pixels 1,3 in O)
+// counts of brighter / darker compass pixels, packed 16-bit lanes (pixels 0,2 in E, pixels 1,3 in O).
+// One v_perm_b32 both shifts the 4-byte window out of a dword pair and zero-extends two of its bytes to 16-bit lanes;
+// the sign of a packed 16-bit difference becomes a 0/1 count with v_pk_lshrrev_b16 + v_pk_add_u16.
 struct Compass { uint32_t be, de, bo, dox; };
-__device__ __forceinline__ void compass_add(Compass &M, uint32_t W, uint32_t hie, uint32_t loe, uint32_t hio, uint32_t loo) {
-    const uint32_t re = W & 0x00FF00FFu, ro = (W >> 8) & 0x00FF00FFu;
-    M.be += (pk_sub(hie, re) >> 15) & 0x00010001u; M.de += (pk_sub(re, loe) >> 15) & 0x00010001u;
-    M.bo += (pk_sub(hio, ro) >> 15) & 0x00010001u; M.dox += (pk_sub(ro, loo) >> 15) & 0x00010001u;
+__device__ __forceinline__ uint32_t sign_count(uint32_t cnt, uint32_t a, uint32_t b) {     // cnt += (a - b < 0) per 16-bit lane
+    const us2_t d = __builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b);
+    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, cnt) + (d >> (unsigned short)15)));
+}
+template <uint32_t SEL_E, uint32_t SEL_O>
+__device__ __forceinline__ void compass_add(Compass &M, uint32_t hi_dword, uint32_t lo_dword, uint32_t hie, uint32_t loe, uint32_t hio, uint32_t loo) {
+    const uint32_t re = __builtin_amdgcn_perm(hi_dword, lo_dword, SEL_E), ro = __builtin_amdgcn_perm(hi_dword, lo_dword, SEL_O);
+    M.be = sign_count(M.be, hie, re); M.de = sign_count(M.de, re, loe);
+    M.bo = sign_count(M.bo, hio, ro); M.dox = sign_count(M.dox, ro, loo);
 }
 
-__global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
+template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
+__global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
+                                              unsigned long long *__restrict__ stamps, TileMap tm, int levels) {
+    long long t_prev = STAMP ? clock64() : 0;
+    auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
     __shared__ uint8_t s_sc[kFastPosRows][264];
-    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPosRows * 256];   // compass survivors; reused as the NMS output buffer
+    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPosRows * 256 + 8];   // compass survivors (+ dump slot); reused as the NMS output buffer
     __shared__ uint16_t s_cl[kFastPosRows * 256];                                 // corners (position ids)
     __shared__ int s_np, s_nc, s_m, s_base;
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2048 keys >= 124*7 possible NMS survivors
     const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-    int t = blockIdx.x, l = 0;
-    while (l + 1 < g->levels && t >= g->L[l + 1].ftile_base) ++l;
-    t -= g->L[l].ftile_base;
+    int t = blockIdx.x;
+    const int l = tile_level(tm, levels, t);
+    t -= tm.base[l];
     const LevelGeom &G = g->L[l];
     const int X0 = (t % G.ftiles_x) * kFastSeg, Y0 = (t / G.ftiles_x) * kFastRows;
     const int f = blockIdx.y, w = G.w, h = G.h, thr = g->fast_threshold;
@@ -279,6 +312,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     if (tid == 0) { s_np = 0; s_nc = 0; s_m = 0; }
     for (int i = tid; i < kFastPosRows * 264 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
     __syncthreads();
+    stamp(0);      // setup + LDS clear
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
     {
         const int x = X0 - 4 + 4 * lane;
@@ -286,8 +320,19 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
         // rows y-3 .. y+3+3 of the wave's 4 position rows: 10 loads issued together
         uint32_t rows[kFastRowsPerWave + 6];
         const int yw = Y0 - 1 + wave * kFastRowsPerWave;
+        if (__ballot(!(x >= 0 && x + 3 < w)) == 0) {     // whole wave inside the row: plain dword loads, one uniform branch
 #pragma unroll
-        for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
+            for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = *reinterpret_cast<const uint32_t *>(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch + x);
+        } else {
+#pragma unroll
+            for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
+        }
+        uint32_t vmask = 0;                              // which of the lane's 4 pixels are valid positions (same for every row)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * lane + i, px = x + i;
+            vmask |= (uint32_t)(c >= 3 && c <= 252 && px >= 3 && px < w - 3) << i;
+        }
 #pragma unroll
         for (int r = 0; r < kFastRowsPerWave; ++r) {
             const int pr = wave * kFastRowsPerWave + r, y = Y0 - 1 + pr;
@@ -297,27 +342,27 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
             const uint32_t ce = C & 0x00FF00FFu, co = (C >> 8) & 0x00FF00FFu;
             const uint32_t hie = ce + T2, hio = co + T2, loe = pk_sub(ce, T2), loo = pk_sub(co, T2);
             Compass M = {0, 0, 0, 0};
-            compass_add(M, Cn, hie, loe, hio, loo);                                       // (0,+3)
-            compass_add(M, Cs, hie, loe, hio, loo);                                       // (0,-3)
-            compass_add(M, __builtin_amdgcn_alignbyte(Rw, C, 3), hie, loe, hio, loo);     // (+3,0)
-            compass_add(M, __builtin_amdgcn_alignbyte(C, Lw, 1), hie, loe, hio, loo);     // (-3,0)
+            // byte selectors: 0-3 = bytes of the low dword, 4-7 = bytes of the high dword, 0x0C = zero
+            compass_add<0x0C020C00u, 0x0C030C01u>(M, 0u, Cn, hie, loe, hio, loo);          // (0,+3): bytes 0,2 / 1,3 of Cn
+            compass_add<0x0C020C00u, 0x0C030C01u>(M, 0u, Cs, hie, loe, hio, loo);          // (0,-3)
+            compass_add<0x0C050C03u, 0x0C060C04u>(M, Rw, C, hie, loe, hio, loo);           // (+3,0): pixels x+3..x+6 of {Rw,C}
+            compass_add<0x0C030C01u, 0x0C040C02u>(M, C, Lw, hie, loe, hio, loo);           // (-3,0): pixels x-3..x   of {C,Lw}
             const uint32_t pe = ((M.be + 0x7FFE7FFEu) | (M.de + 0x7FFE7FFEu)) & 0x80008000u;   // count >= 2 -> bit 15 of the lane
             const uint32_t po = ((M.bo + 0x7FFE7FFEu) | (M.dox + 0x7FFE7FFEu)) & 0x80008000u;
-            uint32_t flags = ((pe >> 15) & 1u) | ((po >> 14) & 2u) | ((pe >> 29) & 4u) | ((po >> 28) & 8u);   // pixel i -> bit i
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = 4 * lane + i, px = x + i;
-                if (!(c >= 3 && c <= 252 && px >= 3 && px < w - 3)) flags &= ~(1u << i);
-            }
+            const uint32_t flags = (((pe >> 15) & 1u) | ((po >> 14) & 2u) | ((pe >> 29) & 4u) | ((po >> 28) & 8u)) & vmask;   // pixel i -> bit i
             if (flags) {
-                int pos = atomicAdd(&s_np, __popc(flags));
+                const int pos = atomicAdd(&s_np, __popc(flags));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (flags & (1u << i)) s_pre[pos++] = (uint16_t)((pr << 8) | (4 * lane + i));
+                for (int i = 0; i < 4; ++i) {           // predicated by index: unset pixels write the dump slot (no exec-mask branches)
+                    const int at = (flags >> i) & 1u ? pos + __popc(flags & ((1u << i) - 1u)) : kFastPosRows * 256;
+                    s_pre[at] = (uint16_t)((pr << 8) | (4 * lane + i));
+                }
             }
         }
     }
+    stamp(1);      // A1 own work
     __syncthreads();
+    stamp(2);      // A1 barrier wait
     // ---- phase A2 + B: the survivors are SCORED directly (corner <=> score > threshold), on packed 16-bit lanes:
     //      P[k] = (d[k], d[k+8]) with d = centre - ring pixel; the sliding min / max of 9 over the circular ring is four
     //      v_pk_min_i16 / v_pk_max_i16 levels (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
@@ -355,7 +400,9 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
         const int best = max(max((int)bright.x, (int)bright.y), -min((int)dark.x, (int)dark.y));
         if (best > thr) { s_sc[pr][c] = (uint8_t)best; s_cl[atomicAdd(&s_nc, 1)] = (uint16_t)e; }
     }
+    stamp(3);      // A2 own work
     __syncthreads();
+    stamp(4);      // A2 barrier wait
     // ---- phase C: 3x3 strict-maximum NMS, dense over the corner list (only outputs: px X0..X0+247 = columns 4..251,
     //      rows Y0..Y0+13 = position rows 1..14; the halo corners only serve as neighbours)
     const int nc = s_nc;
@@ -368,11 +415,14 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
                           sc > s_sc[pr][c + 1] && sc > s_sc[pr + 1][c - 1] && sc > s_sc[pr + 1][c] && sc > s_sc[pr + 1][c + 1];
         if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - sc) << 24) | (uint32_t)(y * w + px);
     }
+    stamp(5);      // NMS own work
     __syncthreads();
+    stamp(6);      // NMS barrier wait
     const int m = s_m;
     if (m == 0) return;
     if (tid == 0) s_base = atomicAdd(&cand_count[f * g->levels + l], m);
     __syncthreads();
+    stamp(7);      // global atomic + barrier
     for (int i = tid; i < m; i += 256) {
         const int pos = s_base + i;
         if (pos < G.cand_cap) cand[(uint64_t)f * g->cand_stride + G.cand_off + pos] = s_out[i];
@@ -727,6 +777,7 @@ struct ms_orb {
     ms_orb_config cfg{};
     PyrGeom geom{};
     PyrGeom *d_geom = nullptr;
+    TileMap blur_tiles{}, fast_tiles{};
     uint8_t *d_slab = nullptr;
     uint32_t *d_cand = nullptr;
     int32_t *d_cand_count = nullptr, *d_det_count = nullptr, *d_trk_count = nullptr;
@@ -741,6 +792,7 @@ struct ms_orb {
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
     bool wide[MS_MAX_LEVELS] = {false};
+    unsigned long long *d_stamps = nullptr;   // diagnostic: per-phase cycle sums of k_fast (ms_orb_fast_phase_cycles)
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
     hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
@@ -802,10 +854,14 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         L.blur_off = off; off += (uint64_t)L.pitch * L.h;
         L.cand_cap = ((w[l] + 1) / 2) * ((h[l] + 1) / 2) + 256;   // strict 3x3 maxima: <= one per 2x2 block
         L.cand_off = coff; coff += L.cand_cap;
-        L.btiles_x = ms_div_up(w[l], kBlurSeg); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 16);
+        L.btiles_x = ms_div_up(w[l], kBlurSeg); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 4 * kBlurRows);
         L.ftiles_x = ms_div_up(w[l], kFastSeg); L.ftile_base = ft; ft += L.ftiles_x * ms_div_up(h[l], kFastRows);
     }
     G.btiles_total = bt; G.ftiles_total = ft;
+    for (int l = 0; l <= MS_MAX_LEVELS; ++l) {
+        o->blur_tiles.base[l] = l < cfg->levels ? G.L[l].btile_base : bt;
+        o->fast_tiles.base[l] = l < cfg->levels ? G.L[l].ftile_base : ft;
+    }
     G.slab_stride = ms_align_up(off, 256); G.cand_stride = coff;
     o->lvl0_off = G.L[0].img_off; o->lvl0_pitch = G.L[0].pitch;
     const size_t B = cfg->max_batch, cap = G.capacity;
@@ -862,6 +918,7 @@ void ms_orb_destroy(ms_orb *o) {
                     o->d_det_score, o->d_mask, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_track_xy,
                     o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (o->d_stamps) (void)hipFree(o->d_stamps);
     for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
 
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
@@ -879,6 +936,21 @@ int ms_orb_set_profiling(ms_orb *o, int enable) {
     if (enable && !o->ev[0])
         for (int i = 0; i <= MS_ORB_STAGES; ++i) MS_HIP(c, hipEventCreate(&o->ev[i]));
     o->profiling = enable != 0;
+    return MS_OK;
+}
+
+int ms_orb_fast_phase_cycles(ms_orb *o, int enable, double *cycles) {
+    if (!o) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    if (enable && !o->d_stamps) { MS_HIP(c, hipMalloc(reinterpret_cast<void **>(&o->d_stamps), 8 * sizeof(unsigned long long))); MS_HIP(c, hipMemset(o->d_stamps, 0, 64)); }
+    if (cycles && o->d_stamps) {
+        unsigned long long h[8];
+        MS_HIP(c, hipMemcpy(h, o->d_stamps, sizeof(h), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) cycles[i] = (double)h[i];
+        MS_HIP(c, hipMemset(o->d_stamps, 0, 64));
+    }
+    if (!enable && o->d_stamps) { MS_HIP(c, hipFree(o->d_stamps)); o->d_stamps = nullptr; }
     return MS_OK;
 }
 
@@ -954,10 +1026,11 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     MS_STAGE_MARK();
     // (k_blur was tried on a second stream beside k_fast: no gain -- the detection kernel already fills the chip -- and
     // overlapped launches have no well-defined per-kernel duration, so everything stays on the context stream.)
-    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->d_geom);
+    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->blur_tiles, G.levels);
     MS_KERNEL_CHECK(c, "k_blur");
     MS_STAGE_MARK();
-    hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count);
+    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->fast_tiles, G.levels);
+    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->fast_tiles, G.levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
     if (o->cfg.min_distance > 0.f)
