@@ -309,24 +309,24 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The wave's 10 image rows are requested FIRST, so their latency runs under the LDS clear and the barrier.
+    const int x = X0 - 4 + 4 * lane;
+    uint32_t rows[kFastRowsPerWave + 6];
+    const int yw = Y0 - 1 + wave * kFastRowsPerWave;
+    if (__ballot(!(x >= 0 && x + 3 < w)) == 0) {     // whole wave inside the row: plain dword loads, one uniform branch
+#pragma unroll
+        for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = *reinterpret_cast<const uint32_t *>(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch + x);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
+    }
     if (tid == 0) { s_np = 0; s_nc = 0; s_m = 0; }
     for (int i = tid; i < kFastPosRows * 264 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
     __syncthreads();
     stamp(0);      // setup + LDS clear
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
     {
-        const int x = X0 - 4 + 4 * lane;
         const uint32_t T2 = (uint32_t)thr * 0x00010001u;
-        // rows y-3 .. y+3+3 of the wave's 4 position rows: 10 loads issued together
-        uint32_t rows[kFastRowsPerWave + 6];
-        const int yw = Y0 - 1 + wave * kFastRowsPerWave;
-        if (__ballot(!(x >= 0 && x + 3 < w)) == 0) {     // whole wave inside the row: plain dword loads, one uniform branch
-#pragma unroll
-            for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = *reinterpret_cast<const uint32_t *>(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch + x);
-        } else {
-#pragma unroll
-            for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
-        }
         uint32_t vmask = 0;                              // which of the lane's 4 pixels are valid positions (same for every row)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
