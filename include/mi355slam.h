@@ -194,6 +194,17 @@ int ms_hamming_candidates(ms_ctx *ctx, const uint32_t *q_desc, int nq, const uin
                           int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave,
                           int32_t *second_idx /* may be NULL */);
 
+/* Representative descriptor of many map points at once (MapPoint::updateDescriptor, map_point.cpp:75-116): for map point p
+ * with observations obs_idx[obs_start[p] .. obs_start[p+1]) (indices into desc_pool, 8 words each), the observation whose
+ * median Hamming distance to all of the point's observations is smallest (median = sorted[(n-1)/2], self distance 0
+ * included; lowest index wins ties; only a median < 256 replaces index 0).  best_local[p] = position in the point's list,
+ * best_pool[p] = the pool index (either may be NULL); both -1 for a point without observations (the reference returns
+ * early, :86).  max_obs >= the longest list, at most MS_MEDOID_MAX_OBS (a longer list yields -2
+ * for that point).  All pointers are device memory. */
+#define MS_MEDOID_MAX_OBS 256
+int ms_descriptor_medoid(ms_ctx *ctx, const uint32_t *desc_pool, const int32_t *obs_start, const int32_t *obs_idx, int n_points,
+                         int max_obs, int32_t *best_local, int32_t *best_pool);
+
 /* Rotation-consistency histogram (openvslam/match_angle_checker.h:60-134), host arithmetic: 30 bins of
  * cvRound(delta/30), everything outside the 3 fullest bins is invalid (ties between bins go to the lower bin).
  * Writes the ids of invalid entries (bin order, then insertion order) and returns their count. */

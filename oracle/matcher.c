@@ -207,3 +207,25 @@ int mso_best2_candidates(const uint32_t *qdesc, const uint32_t *tdesc, const int
     *best = b; *second = s; *best_oct = bl; *second_oct = sl;
     return bi;
 }
+
+/* N4: MapPoint::updateDescriptor (map_point.cpp:75-116): the observation whose MEDIAN Hamming distance to all
+ * observations (itself included, distance 0) is smallest; median = sorted[(unsigned)(0.5*(n-1))]; first index wins
+ * ties; an index is accepted only when its median is < MAX_HAMMING_DIST, otherwise index 0 stays. -1 when n == 0. */
+static int cmp_u(const void *a, const void *b) { unsigned x = *(const unsigned *)a, y = *(const unsigned *)b; return (x > y) - (x < y); }
+int mso_descriptor_medoid(const uint32_t *desc, int n) {
+    if (n <= 0) return -1;
+    unsigned *m = (unsigned *)malloc(sizeof(unsigned) * (size_t)n * n), *row = (unsigned *)malloc(sizeof(unsigned) * n);
+    for (int i = 0; i < n; ++i) {
+        m[(size_t)i * n + i] = 0;
+        for (int j = i + 1; j < n; ++j) m[(size_t)i * n + j] = m[(size_t)j * n + i] = mso_hamming256(desc + 8 * (size_t)i, desc + 8 * (size_t)j);
+    }
+    unsigned best = MAX_DIST; int best_idx = 0;
+    for (int i = 0; i < n; ++i) {
+        memcpy(row, m + (size_t)i * n, sizeof(unsigned) * n);
+        qsort(row, n, sizeof(unsigned), cmp_u);
+        const unsigned med = row[(unsigned)(0.5 * (n - 1))];
+        if (med < best) { best = med; best_idx = i; }
+    }
+    free(m); free(row);
+    return best_idx;
+}

@@ -147,6 +147,9 @@ int mso_best2_candidates(const uint32_t *qdesc, const uint32_t *tdesc, const int
                          const uint8_t *skip, const int32_t *t_octave,
                          unsigned *best, unsigned *second, int *best_oct, int *second_oct);
 
+/* ---- N4: MapPoint::updateDescriptor (map_point.cpp:75-116): index of the median-Hamming medoid, -1 when n == 0 ---- */
+int mso_descriptor_medoid(const uint32_t *desc /* [n][8] */, int n);
+
 /* ---- B1-B6: bundle adjustment (bundle_adjuster.cpp:43-111, :141-394; g2o semantics restated in ba.c) ---- */
 typedef struct {
     int n_pose, n_point, n_obs, n_edge;

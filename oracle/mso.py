@@ -244,6 +244,12 @@ def best2_candidates(qdesc, tdesc, cand, skip=None, t_octave=None):
     return bi, best.value, second.value, bo.value, so.value
 
 
+def descriptor_medoid(desc):
+    d = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+    lib().mso_descriptor_medoid.restype = C.c_int
+    return lib().mso_descriptor_medoid(_p(d, u32p), len(d))
+
+
 def make_bow(bucket_of_kp):
     """CSR over ascending node ids; keypoints of a node in ascending keypoint index (DBoW2 insertion order)."""
     bucket_of_kp = np.asarray(bucket_of_kp, np.int32)

@@ -106,6 +106,56 @@ __global__ __launch_bounds__(256) void k_ratio_test(const int32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Representative descriptor of a map point (MapPoint::updateDescriptor, map_point.cpp:75-116): one workgroup per map
+// point.  The observations' descriptors are staged in LDS (9-dword pitch), the n x n distance matrix is built in LDS
+// (odd halfword pitch), then each row finds its median by bisection on the value range (9 counting passes) and the
+// workgroup takes the (median, index) minimum -- the first index wins ties, exactly as the reference's ascending scan.
+__global__ __launch_bounds__(256) void k_descriptor_medoid(const uint32_t *__restrict__ pool, const int32_t *__restrict__ start,
+                                                           const int32_t *__restrict__ idx, int cap,
+                                                           int32_t *__restrict__ best_local, int32_t *__restrict__ best_pool) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_best;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int s0 = start[p], n = start[p + 1] - s0;
+    if (n <= 0 || n > cap) {                                              // a list longer than the LDS was sized for: -2
+        const int code = n <= 0 ? -1 : -2;
+        if (tid == 0) { if (best_local) best_local[p] = code; if (best_pool) best_pool[p] = code; }
+        return;
+    }
+    uint32_t *s_desc = s_dyn;                                              // [n][9]
+    const int pitch = n | 1;
+    uint16_t *s_mat = reinterpret_cast<uint16_t *>(s_dyn + 9 * n);         // [n][pitch]
+    for (int e = tid; e < 8 * n; e += 256) s_desc[9 * (e >> 3) + (e & 7)] = pool[8 * (size_t)idx[s0 + (e >> 3)] + (e & 7)];
+    if (tid == 0) s_best = 0xffffffffu;
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int j = e / n, i = e - j * n;                                // i varies across lanes, j is (nearly) uniform
+        unsigned d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(s_desc[9 * i + k] ^ s_desc[9 * j + k]);
+        s_mat[i * pitch + j] = (uint16_t)d;
+    }
+    __syncthreads();
+    const int kth = (n - 1) >> 1;                                          // (unsigned)(0.5 * (n - 1)), map_point.cpp:106
+    for (int i = tid; i < n; i += 256) {
+        int lo = 0, hi = 256;
+        while (lo < hi) {                                                  // smallest v with #(row <= v) > kth
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < n; ++j) cnt += s_mat[i * pitch + j] <= mid;
+            if (cnt > kth) hi = mid; else lo = mid + 1;
+        }
+        atomicMin(&s_best, ((uint32_t)lo << 16) | (uint32_t)i);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int b = (s_best >> 16) < 256u ? (int)(s_best & 0xffffu) : 0;  // accepted only below MAX_HAMMING_DIST (:109)
+        if (best_local) best_local[p] = b;
+        if (best_pool) best_pool[p] = idx[s0 + b];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One wavefront per query: lanes scan the query's own candidate list, butterfly merge of (best, second) keys.
 __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__restrict__ qd, int nq, const uint32_t *__restrict__ td,
                                                             const int32_t *__restrict__ cstart, const int32_t *__restrict__ cidx,
@@ -370,6 +420,24 @@ int ms_ratio_test(ms_ctx *c, const int32_t *best_idx, const uint16_t *best_dist,
     MS_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_ratio_test, dim3(ms_div_up(n, 256)), dim3(256), 0, c->stream, best_idx, best_dist, second_dist, n, lowe_ratio, max_dist, match);
     MS_KERNEL_CHECK(c, "k_ratio_test");
+    return MS_OK;
+}
+
+int ms_descriptor_medoid(ms_ctx *c, const uint32_t *desc_pool, const int32_t *obs_start, const int32_t *obs_idx, int n_points,
+                         int max_obs, int32_t *best_local, int32_t *best_pool) {
+    if (!c || !desc_pool || !obs_start || !obs_idx || n_points < 0 || max_obs < 0 || (!best_local && !best_pool)) return MS_ERR_INVALID;
+    if (n_points == 0) return MS_OK;
+    if (max_obs > MS_MEDOID_MAX_OBS) return ms_fail(c, MS_ERR_CAPACITY, "descriptor medoid: %d observations (max %d)", max_obs, MS_MEDOID_MAX_OBS);
+    MS_HIP(c, hipSetDevice(c->device));
+    const int n = max_obs > 0 ? max_obs : 1;
+    const size_t lds = sizeof(uint32_t) * 9 * (size_t)n + sizeof(uint16_t) * (size_t)n * (n | 1) + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_descriptor_medoid), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_descriptor_medoid, dim3(n_points), dim3(256), lds, c->stream, desc_pool, obs_start, obs_idx, n, best_local, best_pool);
+    MS_KERNEL_CHECK(c, "k_descriptor_medoid");
     return MS_OK;
 }
 

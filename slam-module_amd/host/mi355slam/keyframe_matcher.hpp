@@ -133,7 +133,8 @@ inline CandidateScores score_candidates(Context &ctx, const DeviceKeyframe &kf, 
     }
     std::vector<void *> bufs;
     auto up = [&](const void *src, std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d);
-                                                         if (bytes) ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); return d; };
+                                                         if (bytes) { ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); }
+                                                         return d; };
     auto dn = [&](std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d); return d; };
     void *dq = up(desc.data(), desc.size() * 4), *ds = up(start.data(), start.size() * 4), *di = up(idx.data(), idx.size() * 4);
     void *dk = skip ? up(skip->data(), skip->size()) : nullptr;
@@ -183,6 +184,36 @@ inline std::vector<int> bestCandidateCore(Context &ctx, const DeviceKeyframe &kf
     std::vector<int> match(queries.size(), -1);
     for (std::size_t i = 0; i < queries.size(); ++i) if (s.best[i] >= 0 && s.bestDist[i] <= maxDist) match[i] = s.best[i];
     return match;
+}
+
+// MapPoint::updateDescriptor (map_point.cpp:75-116) for many map points in one launch.  observations[p] lists, for map
+// point p, the descriptors of its observing keypoints (the caller gathers kf.shared->keyPoints.at(obs.second.v).descriptor
+// for keyframes with hasFeatureDescriptors(), :78-84, in the order of the observations map).  Returns the position of the
+// chosen descriptor in that list, or -1 for an empty list (the reference then leaves `descriptor` untouched, :86).
+inline std::vector<int> updateDescriptors(Context &ctx, const std::vector<std::vector<KeyPoint::Descriptor>> &observations) {
+    const std::size_t n = observations.size();
+    std::vector<int> best(n, -1);
+    if (n == 0) return best;
+    std::vector<std::uint32_t> pool;
+    std::vector<std::int32_t> start(n + 1, 0), idx;
+    std::size_t longest = 0;
+    for (std::size_t p = 0; p < n; ++p) {
+        for (const KeyPoint::Descriptor &d : observations[p]) { idx.push_back((std::int32_t)(pool.size() / 8)); pool.insert(pool.end(), d.begin(), d.end()); }
+        start[p + 1] = (std::int32_t)idx.size();
+        longest = std::max(longest, observations[p].size());
+    }
+    std::vector<void *> bufs;
+    auto up = [&](const void *src, std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 32, &d), "ms_dev_alloc"); bufs.push_back(d);
+                                                         if (bytes && src) { ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); }
+                                                         return d; };
+    void *dp = up(pool.data(), pool.size() * 4), *ds = up(start.data(), start.size() * 4), *di = up(idx.data(), idx.size() * 4);
+    void *out = up(nullptr, 4 * n);
+    const int rc = ms_descriptor_medoid(ctx.get(), static_cast<const std::uint32_t *>(dp), static_cast<const std::int32_t *>(ds),
+                                        static_cast<const std::int32_t *>(di), (int)n, (int)longest, static_cast<std::int32_t *>(out), nullptr);
+    if (rc == MS_OK) ctx.check(ms_dev_download(ctx.get(), best.data(), out, 4 * n), "download");
+    for (void *p : bufs) ms_dev_free(ctx.get(), p);
+    ctx.check(rc, "ms_descriptor_medoid");
+    return best;
 }
 
 // create_E_21 (openvslam/essential_solver.cc:157-162), row-major 3x3

@@ -334,6 +334,21 @@ def ratio_test(ctx, best_idx, best_dist, second_dist, lowe_ratio, max_dist=50):
     return m.download(np.int32, (n,))
 
 
+def descriptor_medoid(ctx, desc_pool, obs_lists):
+    """MapPoint::updateDescriptor for many map points: obs_lists[p] = indices into desc_pool.  Returns (best_local, best_pool)."""
+    pool = np.ascontiguousarray(desc_pool, np.uint32).reshape(-1, 8)
+    n = len(obs_lists)
+    start = np.zeros(n + 1, np.int32)
+    start[1:] = np.cumsum([len(o) for o in obs_lists])
+    idx = np.concatenate([np.asarray(o, np.int32) for o in obs_lists] + [np.zeros(0, np.int32)]).astype(np.int32)
+    dp, ds, di = ctx.upload(pool if len(pool) else np.zeros((1, 8), np.uint32)), ctx.upload(start), ctx.upload(idx if len(idx) else np.zeros(1, np.int32))
+    bl, bp = ctx.alloc(4 * n + 16), ctx.alloc(4 * n + 16)
+    ctx.check(lib().ms_descriptor_medoid(ctx._h, _vp(dp), _vp(ds), _vp(di), n, max([len(o) for o in obs_lists] + [0]), _vp(bl), _vp(bp)),
+              "ms_descriptor_medoid")
+    ctx.sync()
+    return bl.download(np.int32, (n,)), bp.download(np.int32, (n,))
+
+
 def hamming_candidates(ctx, q_desc, t_desc, cand_lists, t_skip=None, t_octave=None):
     """cand_lists: list (per query) of keypoint index arrays.  Returns (best_idx, best_dist, second_dist, best_oct, second_oct)."""
     q = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8); t = np.ascontiguousarray(t_desc, np.uint32).reshape(-1, 8)

@@ -74,6 +74,24 @@ int main(int argc, char **argv) {
             if ((bi >= 0 && bd <= 50 ? bi : -1) != dup[i]) { std::printf("bestCandidateCore mismatch at %zu\n", i); return 6; }
         }
     }
+    {   auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { unsigned d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
+        // updateDescriptor for a batch of map points vs the plain median-of-row rule (map_point.cpp:75-116)
+        std::vector<std::vector<KeyPoint::Descriptor>> obs(40);
+        for (std::size_t p = 0; p < obs.size(); ++p)
+            for (std::size_t k = 0; k < p % 9; ++k) obs[p].push_back(kps[(7 * p + 13 * k) % kps.size()].descriptor);
+        std::vector<int> got = updateDescriptors(ctx, obs);
+        for (std::size_t p = 0; p < obs.size(); ++p) {
+            int want = -1; unsigned bestMed = 256; const std::size_t n = obs[p].size();
+            if (n) want = 0;
+            for (std::size_t i = 0; i < n; ++i) {
+                std::vector<unsigned> row; for (std::size_t j = 0; j < n; ++j) row.push_back(popc(obs[p][i], obs[p][j]));
+                std::sort(row.begin(), row.end());
+                const unsigned med = row[(unsigned)(0.5 * (n - 1))];
+                if (med < bestMed) { bestMed = med; want = (int)i; }
+            }
+            if (got[p] != want) { std::printf("updateDescriptors mismatch at %zu: %d vs %d\n", p, got[p], want); return 7; }
+        }
+    }
     // a tiny two-stage local BA: 3 cameras on a line looking at 30 points
     BaWindow w; w.currentKeyframe = 2;
     for (int i = 0; i < 3; ++i) w.poses.push_back({0, 0, 0, 1, -0.2 * i, 0, 0});

@@ -149,3 +149,32 @@ def test_hamming_candidates_projection_core(oracle, ctx):
             w = oracle.best2_candidates(q[i], t2, cands[i], skip=sk, t_octave=t_oct)
             assert (bi[i], bd[i], sd[i], bo[i], so[i]) == w, i
     assert bi[3] == -1 and bd[3] == 256
+
+
+def test_descriptor_medoid_equals_update_descriptor(oracle, ctx):
+    """MapPoint::updateDescriptor (map_point.cpp:75-116) for a batch of map points: median-Hamming medoid, first index on ties."""
+    import mi355slam
+    rng = np.random.default_rng(77)
+    pool = rng.integers(0, 2**32, (6000, 8), dtype=np.uint64).astype(np.uint32)
+    # observations of one map point look alike: a base descriptor with a few flipped bits, so ties and small medians occur
+    for b in range(0, 6000, 12):
+        base = pool[b].copy()
+        for k in range(12):
+            d = base.copy()
+            for bit in rng.integers(0, 256, rng.integers(0, 20)): d[bit >> 5] ^= np.uint32(1 << (bit & 31))
+            pool[b + k] = d
+    sizes = list(rng.integers(1, 40, 700)) + [0, 1, 2, 3, 64, 65, 129, 256]
+    lists = []
+    for n in sizes:
+        if n <= 12 and n > 0:
+            b = 12 * int(rng.integers(0, 500)); lists.append((b + rng.permutation(12)[:n]).astype(np.int32))
+        else:
+            lists.append(rng.choice(6000, size=int(n), replace=False).astype(np.int32))
+    lists[5] = np.array([7, 7, 7, 7], np.int32)                    # identical observations: index 0
+    bl, bp = mi355slam.descriptor_medoid(ctx, pool, lists)
+    for p, obs in enumerate(lists):
+        want = oracle.descriptor_medoid(pool[obs]) if len(obs) else -1
+        assert bl[p] == want, (p, len(obs))
+        assert bp[p] == (obs[want] if want >= 0 else -1), p
+    with pytest.raises(mi355slam.MsError):
+        mi355slam.descriptor_medoid(ctx, pool, [np.arange(257, dtype=np.int32)])

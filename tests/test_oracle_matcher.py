@@ -130,3 +130,16 @@ def test_match_triangulation_last_wins_ties(oracle):
     n, m = oracle.match_triangulation(d1, a, np.zeros(1, np.int32), be1, np.ones(1, np.uint8), np.zeros(1, np.int32),
                                       d2, a2, be2b, np.ones(3, np.uint8), np.zeros(3, np.int32), E, sf, 1.0, False)
     assert n == 0 and m[0] == -1
+
+
+def test_descriptor_medoid_follows_update_descriptor(oracle):
+    """map_point.cpp:75-116 in numpy: sort each row of the distance matrix, take element (n-1)//2, first strict minimum."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 4, 7, 16, 33):
+        d = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+        d[n // 2] = d[0]                                            # a duplicate, so medians tie
+        bits = np.unpackbits(d.view(np.uint8), axis=1).astype(np.int32)
+        mat = (bits[:, None, :] != bits[None, :, :]).sum(-1)
+        med = np.sort(mat, axis=1)[:, int(0.5 * (n - 1))]
+        assert oracle.descriptor_medoid(d) == int(np.argmin(med)), n
+    assert oracle.descriptor_medoid(np.zeros((0, 8), np.uint32)) == -1
