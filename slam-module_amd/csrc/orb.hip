@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, Ti
 //   phase C   3x3 strict-maximum NMS, dense over the corner list, against the LDS score tile; survivors leave as 32-bit keys
 //             ((255-score)<<24 | y*w+x) with ONE global atomic per tile
 constexpr int kFastSeg = 248, kFastRows = 14, kFastPosRows = kFastRows + 2, kFastRowsPerWave = kFastPosRows / 4;
+constexpr int kFastPositions = kFastPosRows * (kFastSeg + 2);   // scored positions of a tile: columns 3..252 of 16 rows.  Keeps LDS at 20 256 B = 8 workgroups per CU
 
 __device__ __forceinline__ bool contig9(uint32_t m) {
     m |= m << 16;
@@ -294,10 +295,10 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     long long t_prev = STAMP ? clock64() : 0;
     auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
     __shared__ uint8_t s_sc[kFastPosRows][264];
-    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPosRows * 256 + 8];   // compass survivors (+ dump slot); reused as the NMS output buffer
-    __shared__ uint16_t s_cl[kFastPosRows * 256];                                 // corners (position ids)
+    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPositions + 8];   // compass survivors (+ dump slot); reused as the NMS output buffer
+    __shared__ uint16_t s_cl[kFastPositions];                                // corners (position ids)
     __shared__ int s_np, s_nc, s_m, s_base;
-    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2048 keys >= 124*7 possible NMS survivors
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2004 keys >= 124*7 possible NMS survivors
     const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     int t = blockIdx.x;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
                 const int pos = atomicAdd(&s_np, __popc(flags));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {           // predicated by index: unset pixels write the dump slot (no exec-mask branches)
-                    const int at = (flags >> i) & 1u ? pos + __popc(flags & ((1u << i) - 1u)) : kFastPosRows * 256;
+                    const int at = (flags >> i) & 1u ? pos + __popc(flags & ((1u << i) - 1u)) : kFastPositions;
                     s_pre[at] = (uint16_t)((pr << 8) | (4 * lane + i));
                 }
             }
