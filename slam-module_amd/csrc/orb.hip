@@ -184,6 +184,10 @@ __device__ __forceinline__ uint32_t dot2(uint32_t a, unsigned lo, unsigned hi, u
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), k, acc, false);
 }
 
+// lane i <- lane i-1 / lane i+1 of the 64-wide wave in one VALU op (gfx9 DPP wave shifts); the end lane's value is unspecified
+__device__ __forceinline__ uint32_t wave_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
+
 constexpr int kBlurSeg = 248;   // outputs per wave row segment
 constexpr int kBlurRows = 8;    // output rows per wave (kBlurRows + 6 input rows are loaded: 1.75x read amplification through L1)
 
@@ -221,8 +225,9 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, Ti
 #pragma unroll
     for (int j = 0; j < kBlurRows; ++j) {
         const uint32_t Ce = vsum7(e + j), Co = vsum7(o + j);            // columns (x, x+2) and (x+1, x+3)
-        const uint32_t Le = __shfl_up(Ce, 1, 64), Lo = __shfl_up(Co, 1, 64);
-        const uint32_t Re = __shfl_down(Ce, 1, 64), Ro = __shfl_down(Co, 1, 64);
+        // neighbour lanes by DPP wave shifts (VALU, no LDS round trip); lanes 0 and 63 receive a don't-care and store nothing
+        const uint32_t Le = wave_from_prev(Ce), Lo = wave_from_prev(Co);
+        const uint32_t Re = wave_from_next(Ce), Ro = wave_from_next(Co);
         uint32_t o0 = dot2(Lo, 18, 48, 32768u); o0 = dot2(Le, 0, 34, o0); o0 = dot2(Ce, 56, 34, o0); o0 = dot2(Co, 48, 18, o0);
         uint32_t o1 = dot2(Le, 0, 18, 32768u); o1 = dot2(Lo, 0, 34, o1); o1 = dot2(Ce, 48, 48, o1); o1 = dot2(Co, 56, 34, o1); o1 = dot2(Re, 18, 0, o1);
         uint32_t o2 = dot2(Lo, 0, 18, 32768u); o2 = dot2(Ce, 34, 56, o2); o2 = dot2(Co, 48, 48, o2); o2 = dot2(Re, 34, 0, o2); o2 = dot2(Ro, 18, 0, o2);
@@ -339,7 +344,8 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
             const int pr = wave * kFastRowsPerWave + r, y = Y0 - 1 + pr;
             if (y < 3 || y >= h - 3) continue;                           // wave-uniform
             const uint32_t C = rows[r + 3], Cn = rows[r + 6], Cs = rows[r];
-            const uint32_t Lw = __shfl_up(C, 1, 64), Rw = __shfl_down(C, 1, 64);
+            // neighbours' dwords by DPP wave shifts (one VALU op each); lanes 0 / 63 get a don't-care: their edge pixels are masked by vmask
+            const uint32_t Lw = wave_from_prev(C), Rw = wave_from_next(C);
             const uint32_t ce = C & 0x00FF00FFu, co = (C >> 8) & 0x00FF00FFu;
             const uint32_t hie = ce + T2, hio = co + T2, loe = pk_sub(ce, T2), loo = pk_sub(co, T2);
             Compass M = {0, 0, 0, 0};
