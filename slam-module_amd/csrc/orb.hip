@@ -294,6 +294,66 @@ __device__ __forceinline__ void compass_add(Compass &M, uint32_t hi_dword, uint3
     M.bo = sign_count(M.bo, hio, ro); M.dox = sign_count(M.dox, ro, loo);
 }
 
+// Ring of one FAST candidate: R[8] = centre, R[k] = ring pixels k and k+8 in the two 16-bit lanes.
+__device__ __forceinline__ void fast_ring_load(const uint8_t *p, int pitch, uint32_t R[9]) {
+    const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    R[8] = p[0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) R[k] = (uint32_t)p[rdy[k] * pitch + rdx[k]] | ((uint32_t)p[rdy[k + 8] * pitch + rdx[k + 8]] << 16);
+}
+
+// The same ring from 7 loads: rows +-3 as one dword at x-1, rows +-2 as a dwordx2 at x-2, rows 0 and +-1 as a dwordx2 at x-3
+// (global memory takes unaligned dword accesses); one v_perm_b32 per opposite pixel pair builds R[k].
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
+__device__ __forceinline__ void fast_ring_load_wide(const uint8_t *p, int pitch, uint32_t R[9]) {
+    const uint32_t a3 = reinterpret_cast<const U32u *>(p + 3 * pitch - 1)->v, am3 = reinterpret_cast<const U32u *>(p - 3 * pitch - 1)->v;
+    const U64u b2 = *reinterpret_cast<const U64u *>(p + 2 * pitch - 2), bm2 = *reinterpret_cast<const U64u *>(p - 2 * pitch - 2);
+    const U64u c1 = *reinterpret_cast<const U64u *>(p + pitch - 3), cm1 = *reinterpret_cast<const U64u *>(p - pitch - 3);
+    const U64u c0 = *reinterpret_cast<const U64u *>(p - 3);
+    R[0] = __builtin_amdgcn_perm(am3, a3, 0x0C050C01u);          // ( 0,+3) | ( 0,-3)
+    R[1] = __builtin_amdgcn_perm(am3, a3, 0x0C040C02u);          // (+1,+3) | (-1,-3)
+    R[2] = __builtin_amdgcn_perm(bm2.lo, b2.hi, 0x0C040C00u);    // (+2,+2) | (-2,-2)
+    R[3] = __builtin_amdgcn_perm(cm1.lo, c1.hi, 0x0C040C02u);    // (+3,+1) | (-3,-1)
+    R[4] = __builtin_amdgcn_perm(c0.lo, c0.hi, 0x0C040C02u);     // (+3, 0) | (-3, 0)
+    R[5] = __builtin_amdgcn_perm(c1.lo, cm1.hi, 0x0C040C02u);    // (+3,-1) | (-3,+1)
+    R[6] = __builtin_amdgcn_perm(b2.lo, bm2.hi, 0x0C040C00u);    // (+2,-2) | (-2,+2)
+    R[7] = __builtin_amdgcn_perm(a3, am3, 0x0C040C02u);          // (+1,-3) | (-1,+3)
+    R[8] = c0.lo >> 24;
+}
+
+// FAST score = max over the 16 arcs of 9 of min(c - r) and of min(r - c), on packed 16-bit lanes: P[k] = (d[k], d[k+8]) with
+// d = centre - ring pixel; the sliding min / max of 9 over the circular ring is four v_pk_min_i16 / v_pk_max_i16 levels
+// (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
+__device__ __forceinline__ int fast_ring_score(const uint32_t R[9]) {
+    const uint32_t cc = R[8] * 0x00010001u;
+    s2_t P[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k] = __builtin_bit_cast(s2_t, pk_sub(cc, R[k]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k + 8] = P[k].yx;                       // (d[k+8], d[k]): the ring is circular
+    s2_t mn[12], mx[12];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mn[k] = __builtin_elementwise_min(P[k], P[k + 1]); mx[k] = __builtin_elementwise_max(P[k], P[k + 1]); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { mn[8 + k] = mn[k].yx; mx[8 + k] = mx[k].yx; }
+    s2_t mn4[12], mx4[12];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mn4[k] = __builtin_elementwise_min(mn[k], mn[k + 2]); mx4[k] = __builtin_elementwise_max(mx[k], mx[k + 2]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mn4[8 + k] = mn4[k].yx; mx4[8 + k] = mx4[k].yx; }
+    s2_t bright = {-32768, -32768}, dark = {32767, 32767};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const s2_t m9 = __builtin_elementwise_min(__builtin_elementwise_min(mn4[k], mn4[k + 4]), P[k + 8]);   // arcs starting at k and k+8
+        const s2_t x9 = __builtin_elementwise_max(__builtin_elementwise_max(mx4[k], mx4[k + 4]), P[k + 8]);
+        bright = __builtin_elementwise_max(bright, m9);
+        dark = __builtin_elementwise_min(dark, x9);
+    }
+    return max(max((int)bright.x, (int)bright.y), -min((int)dark.x, (int)dark.y));
+}
+
 template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
 __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
                                               unsigned long long *__restrict__ stamps, TileMap tm, int levels) {
@@ -304,8 +364,6 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     __shared__ uint16_t s_cl[kFastPositions];                                // corners (position ids)
     __shared__ int s_np, s_nc, s_m, s_base;
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2004 keys >= 124*7 possible NMS survivors
-    const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     int t = blockIdx.x;
     const int l = tile_level(tm, levels, t);
     t -= tm.base[l];
@@ -376,35 +434,13 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     const int np = s_np;
     for (int i = tid; i < np; i += 256) {
         const int e = s_pre[i], pr = e >> 8, c = e & 255;
-        const uint8_t *p = img + (uint64_t)(Y0 - 1 + pr) * pitch + (X0 - 4 + c);
-        const uint32_t cc = (uint32_t)p[0] * 0x00010001u;
-        s2_t P[16];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t rp = (uint32_t)p[rdy[k] * pitch + rdx[k]] | ((uint32_t)p[rdy[k + 8] * pitch + rdx[k + 8]] << 16);
-            P[k] = __builtin_bit_cast(s2_t, pk_sub(cc, rp));
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) P[k + 8] = P[k].yx;                       // (d[k+8], d[k]): the ring is circular
-        s2_t mn[12], mx[12];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { mn[k] = __builtin_elementwise_min(P[k], P[k + 1]); mx[k] = __builtin_elementwise_max(P[k], P[k + 1]); }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { mn[8 + k] = mn[k].yx; mx[8 + k] = mx[k].yx; }
-        s2_t mn4[12], mx4[12];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { mn4[k] = __builtin_elementwise_min(mn[k], mn[k + 2]); mx4[k] = __builtin_elementwise_max(mx[k], mx[k + 2]); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { mn4[8 + k] = mn4[k].yx; mx4[8 + k] = mx4[k].yx; }
-        s2_t bright = {-32768, -32768}, dark = {32767, 32767};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const s2_t m9 = __builtin_elementwise_min(__builtin_elementwise_min(mn4[k], mn4[k + 4]), P[k + 8]);   // arcs starting at k and k+8
-            const s2_t x9 = __builtin_elementwise_max(__builtin_elementwise_max(mx4[k], mx4[k + 4]), P[k + 8]);
-            bright = __builtin_elementwise_max(bright, m9);
-            dark = __builtin_elementwise_min(dark, x9);
-        }
-        const int best = max(max((int)bright.x, (int)bright.y), -min((int)dark.x, (int)dark.y));
+        const int px = X0 - 4 + c;
+        const uint8_t *p = img + (uint64_t)(Y0 - 1 + pr) * pitch + px;
+        uint32_t R[9];
+        // seven unaligned dword / dwordx2 loads cover the ring when no lane's widest row (x-2 .. x+5) leaves the image row;
+        // waves holding a survivor in the last columns fall back to 17 byte loads
+        if (__ballot(px + 5 >= w) == 0) fast_ring_load_wide(p, pitch, R); else fast_ring_load(p, pitch, R);
+        const int best = fast_ring_score(R);
         if (best > thr) { s_sc[pr][c] = (uint8_t)best; s_cl[atomicAdd(&s_nc, 1)] = (uint16_t)e; }
     }
     stamp(3);      // A2 own work
