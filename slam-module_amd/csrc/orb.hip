@@ -100,13 +100,16 @@ __device__ __forceinline__ int resize_px(uint64_t w0, uint64_t w1, int k, int a0
     return min(max(v, 0), 255);
 }
 
-__device__ __forceinline__ uint64_t window8(const uint8_t *row, int sx0, int last_dword) {
-    const int base = sx0 & ~3, sh = 8 * (sx0 & 3);
-    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(row + min(base, last_dword));
-    const uint32_t d1 = *reinterpret_cast<const uint32_t *>(row + min(base + 4, last_dword));
-    const uint32_t d2 = *reinterpret_cast<const uint32_t *>(row + min(base + 8, last_dword));
-    const uint64_t lo = ((uint64_t)d1 << 32) | d0;
-    return sh ? (lo >> sh) | ((uint64_t)d2 << (64 - sh)) : lo;
+constexpr int kResizeRows = 4;   // destination rows per lane: the table fetch is paid once and 24 source dwords are in flight per lane
+
+struct Window3 { uint32_t d0, d1, d2; };
+__device__ __forceinline__ Window3 window_load(const uint8_t *row, int base, int last_dword) {
+    return {*reinterpret_cast<const uint32_t *>(row + min(base, last_dword)), *reinterpret_cast<const uint32_t *>(row + min(base + 4, last_dword)),
+            *reinterpret_cast<const uint32_t *>(row + min(base + 8, last_dword))};
+}
+__device__ __forceinline__ uint64_t window_shift(const Window3 &W, int sh) {
+    const uint64_t lo = ((uint64_t)W.d1 << 32) | W.d0;
+    return sh ? (lo >> sh) | ((uint64_t)W.d2 << (64 - sh)) : lo;
 }
 
 template <bool WIDE>   // WIDE: tap window of 4 pixels may exceed 8 bytes (scale factor > 2) -> per-tap byte loads
@@ -114,33 +117,49 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
     const LevelGeom &D = g->L[l];
     const int sw = g->L[l - 1].w;
     const int f = blockIdx.z;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kResizeRows;
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (dy >= D.h || dx0 >= D.w) return;
+    if (dy0 >= D.h || dx0 >= D.w) return;
     int spitch;
     const uint8_t *S = level_ptr(src, g, f, l - 1, spitch);
     uint8_t *dst = src.slab + (uint64_t)f * g->slab_stride + D.img_off;
-    const short4 yt = reinterpret_cast<const short4 *>(T.ytab)[dy];
-    const uint8_t *S0 = S + (uint64_t)yt.x * spitch, *S1 = S + (uint64_t)yt.y * spitch;
-    const int b0 = yt.z, b1 = yt.w;
-    short4 xt[4];
+    // both tables are padded to whole groups (last entry repeated), so a lane's four columns are two 16-byte loads
+    const uint4 xa = reinterpret_cast<const uint4 *>(T.xtab)[dx0 >> 1], xb = reinterpret_cast<const uint4 *>(T.xtab)[(dx0 >> 1) + 1];
+    const short4 xt[4] = {__builtin_bit_cast(short4, make_uint2(xa.x, xa.y)), __builtin_bit_cast(short4, make_uint2(xa.z, xa.w)),
+                          __builtin_bit_cast(short4, make_uint2(xb.x, xb.y)), __builtin_bit_cast(short4, make_uint2(xb.z, xb.w))};
+    short4 yt[kResizeRows];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xt[i] = reinterpret_cast<const short4 *>(T.xtab)[min(dx0 + i, D.w - 1)];
-    uint32_t packed = 0;
+    for (int r = 0; r < kResizeRows; ++r) yt[r] = reinterpret_cast<const short4 *>(T.ytab)[dy0 + r];
     if (!WIDE) {
-        const int sx0 = xt[0].x, last = (sw - 1) & ~3;
-        const uint64_t w0 = window8(S0, sx0, last), w1 = window8(S1, sx0, last);
+        const int sx0 = xt[0].x, last = (sw - 1) & ~3, base = sx0 & ~3, sh = 8 * (sx0 & 3);
+        Window3 W0[kResizeRows], W1[kResizeRows];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) packed |= (uint32_t)resize_px(w0, w1, xt[i].x - sx0, xt[i].y, xt[i].z, b0, b1) << (8 * i);
+        for (int r = 0; r < kResizeRows; ++r) {
+            W0[r] = window_load(S + (uint64_t)yt[r].x * spitch, base, last);
+            W1[r] = window_load(S + (uint64_t)yt[r].y * spitch, base, last);
+        }
+#pragma unroll
+        for (int r = 0; r < kResizeRows; ++r) {
+            const uint64_t w0 = window_shift(W0[r], sh), w1 = window_shift(W1[r], sh);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) packed |= (uint32_t)resize_px(w0, w1, xt[i].x - sx0, xt[i].y, xt[i].z, yt[r].z, yt[r].w) << (8 * i);
+            if (dy0 + r < D.h) *reinterpret_cast<uint32_t *>(dst + (uint64_t)(dy0 + r) * D.pitch + dx0) = packed;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sx = xt[i].x, sx1 = min(sx + 1, sw - 1);
-            const uint64_t w0 = (uint64_t)S0[sx] | ((uint64_t)S0[sx1] << 8), w1 = (uint64_t)S1[sx] | ((uint64_t)S1[sx1] << 8);
-            packed |= (uint32_t)resize_px(w0, w1, 0, xt[i].y, xt[i].z, b0, b1) << (8 * i);
+        for (int r = 0; r < kResizeRows; ++r) {
+            const uint8_t *S0 = S + (uint64_t)yt[r].x * spitch, *S1 = S + (uint64_t)yt[r].y * spitch;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sx = xt[i].x, sx1 = min(sx + 1, sw - 1);
+                const uint64_t w0 = (uint64_t)S0[sx] | ((uint64_t)S0[sx1] << 8), w1 = (uint64_t)S1[sx] | ((uint64_t)S1[sx1] << 8);
+                packed |= (uint32_t)resize_px(w0, w1, 0, xt[i].y, xt[i].z, yt[r].z, yt[r].w) << (8 * i);
+            }
+            if (dy0 + r < D.h) *reinterpret_cast<uint32_t *>(dst + (uint64_t)(dy0 + r) * D.pitch + dx0) = packed;
         }
     }
-    *reinterpret_cast<uint32_t *>(dst + (uint64_t)dy * D.pitch + dx0) = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -932,13 +951,16 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         std::vector<int16_t> xo, xc, yo, yc;
         msgeo::resize_tables(w[l - 1], w[l], true, xo, xc);
         msgeo::resize_tables(h[l - 1], h[l], false, yo, yc);
-        std::vector<int16_t> xt(4 * (size_t)w[l]), yt(4 * (size_t)h[l]);
+        const int wpad = ms_div_up(w[l], 4) * 4, hpad = ms_div_up(h[l], kResizeRows) * kResizeRows;     // whole groups, last entry repeated
+        std::vector<int16_t> xt(4 * (size_t)wpad), yt(4 * (size_t)hpad);
         for (int d = 0; d < w[l]; ++d) { xt[4 * d] = xo[d]; xt[4 * d + 1] = xc[2 * d]; xt[4 * d + 2] = xc[2 * d + 1]; xt[4 * d + 3] = 0; }
         for (int d = 0; d < h[l]; ++d) {      // clip(sy, 0, ssize.height) applied to both tap rows
             yt[4 * d] = (int16_t)std::min(std::max((int)yo[d], 0), h[l - 1] - 1);
             yt[4 * d + 1] = (int16_t)std::min(std::max((int)yo[d] + 1, 0), h[l - 1] - 1);
             yt[4 * d + 2] = yc[2 * d]; yt[4 * d + 3] = yc[2 * d + 1];
         }
+        for (int d = w[l]; d < wpad; ++d) for (int k = 0; k < 4; ++k) xt[4 * d + k] = xt[4 * (w[l] - 1) + k];
+        for (int d = h[l]; d < hpad; ++d) for (int k = 0; k < 4; ++k) yt[4 * d + k] = yt[4 * (h[l] - 1) + k];
         for (int d = 0; d + 3 < w[l]; d += 4) if (xo[d + 3] + 1 - xo[d] > 7) o->wide[l] = true;   // taps beyond an 8-byte window
         auto up = [&](int16_t **d, const std::vector<int16_t> &v) {
             if (rc != MS_OK) return;
@@ -1060,7 +1082,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
 #define MS_STAGE_MARK() do { if (o->profiling) MS_HIP(c, hipEventRecord(o->ev[stage++], st)); } while (0)
     MS_STAGE_MARK();
     for (int l = 1; l < G.levels; ++l) {
-        dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4), n_frames);
+        dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4 * kResizeRows), n_frames);
         const ResizeTab T{o->d_xtab[l], o->d_ytab[l]};
         if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, src, o->d_geom, l, T);
         else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, src, o->d_geom, l, T);
