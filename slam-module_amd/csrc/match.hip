@@ -95,6 +95,122 @@ __global__ __launch_bounds__(256) void k_hamming_best2(HamArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The unmasked all-pairs search as an integer matrix product on the matrix cores.  With descriptor bits mapped to
+// +-1 bytes (queries: 0 -> +1, 1 -> -1; targets the opposite sign) the i8 dot product of a query and a target is
+// 2*hamming - 256, exactly, so a 32x32 tile of distances is eight v_mfma_i32_32x32x32_i8 (K = 256 bits).
+//   * a wave owns 64 queries (two 32-wide column tiles) whose operand fragments live in 64 registers for the whole kernel;
+//   * the workgroup (4 waves = 256 queries) expands 128 targets per stage from packed bits into LDS, already in operand
+//     order ([row tile][k step][lane][16 B]), so an A fragment is one conflict-free ds_read_b128;
+//   * accumulator layout: column (= query) on the lane, 16 target rows in the registers, so best / second are tracked per
+//     lane with the same packed (distance<<20 | index) keys and min / max / min as the VALU kernel: 4 VALU ops per pair
+//     instead of 21.  The two lane halves (rows 4h..) of a column are merged once at the end.
+// Which bit sits in which k slot of a fragment is irrelevant as long as queries and targets use the same rule.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+constexpr int kHmStage = 128;      // targets per LDS stage (four 32-row tiles, 32 KB of +-1 bytes)
+
+template <bool NEG>
+__device__ __forceinline__ uint32_t expand4(uint32_t nib) {          // 4 bits -> 4 bytes: bit i -> byte i = +1 / -1
+    const uint32_t x = (nib * 0x00204081u) & 0x01010101u;
+    return ((NEG ? x ^ 0x01010101u : x) * 0xFEu) | 0x01010101u;      // NEG: 0 -> -1, 1 -> +1; else 0 -> +1, 1 -> -1
+}
+template <bool NEG>
+__device__ __forceinline__ v4i_t expand16(uint32_t bits) {
+    return v4i_t{(int)expand4<NEG>(bits & 15u), (int)expand4<NEG>((bits >> 4) & 15u), (int)expand4<NEG>((bits >> 8) & 15u), (int)expand4<NEG>((bits >> 12) & 15u)};
+}
+__device__ __forceinline__ void best2_push(uint32_t &best, uint32_t &second, uint32_t key) {
+    const uint32_t lo = min(best, key), hi = max(best, key);
+    second = min(second, hi);
+    best = lo;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_a[kHmStage * 64];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int qs = A.pair_q ? A.pair_q[p] : p, ts = A.pair_t ? A.pair_t[p] : p;
+    const int nq = A.q_count ? min(A.q_count[qs], A.nq) : A.nq;
+    const int nt = A.t_count ? min(A.t_count[ts], A.nt) : A.nt;
+    if (blockIdx.x * 256 >= nq) {                      // whole block beyond this pair's queries
+        const int qi = blockIdx.x * 256 + tid;
+        const uint64_t o = (uint64_t)p * A.q_stride + qi;
+        if (qi < A.q_stride) { A.best_idx[o] = -1; A.best_dist[o] = MS_HAMMING_MAX; A.second_dist[o] = MS_HAMMING_MAX; }
+        return;
+    }
+    const uint4 *Q = reinterpret_cast<const uint4 *>(A.q + (uint64_t)qs * A.q_stride * 8);
+    const uint4 *T = reinterpret_cast<const uint4 *>(A.t + (uint64_t)ts * A.t_stride * 8);
+    v4i_t bq[2][8];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = blockIdx.x * 256 + wave * 64 + n * 32 + col;
+        uint4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (qi < nq) { lo = Q[2 * qi]; hi = Q[2 * qi + 1]; }
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bq[n][s] = expand16<false>((w[s] >> (16 * h)) & 0xFFFFu);
+    }
+    uint32_t best[2] = {kNone, kNone}, second[2] = {kNone, kNone};
+    for (int base = 0; base < nt; base += kHmStage) {
+        __syncthreads();
+        {   // expand this stage's targets: thread -> target tid & 127, words 4*(tid>>7) .. +3 (one 16-byte load)
+            const int tau = tid & 127, half = tid >> 7, j = base + tau;
+            uint4 v = {0, 0, 0, 0};
+            if (j < nt) v = T[2 * j + half];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    *reinterpret_cast<v4i_t *>(&s_a[((tau >> 5) * 8 + 4 * half + k) * 256 + (hh * 32 + (tau & 31)) * 4]) = expand16<true>((w4[k] >> (16 * hh)) & 0xFFFFu);
+        }
+        __syncthreads();
+        const int mtiles = min(kHmStage / 32, (nt - base + 31) >> 5);
+        for (int m = 0; m < mtiles; ++m) {
+            v16i_t acc[2] = {};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const v4i_t a = *reinterpret_cast<const v4i_t *>(&s_a[(m * 8 + s) * 256 + lane * 4]);
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc[1], 0, 0, 0);
+            }
+            const int row0 = base + m * 32 + 4 * h;                   // this lane's rows: row0 + (reg & 3) + 8 * (reg >> 2)
+            if (base + m * 32 + 32 <= nt) {                           // full tile (uniform)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    uint32_t lb = kNone, ls = kNone;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) best2_push(lb, ls, ((uint32_t)acc[n][r] << 19) + ((256u << 19) + (uint32_t)((r & 3) + 8 * (r >> 2))));
+                    best2_push(best[n], second[n], lb + (uint32_t)row0);
+                    second[n] = min(second[n], ls + (uint32_t)row0);
+                }
+            } else {                                                  // last tile of the set: rows beyond nt do not exist
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2);
+                        const uint32_t key = (((uint32_t)acc[n][r] + 256u) << 19) + (uint32_t)row;
+                        best2_push(best[n], second[n], row < nt ? key : kNone);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {                                     // the other half of the wave holds the other rows of this column
+        const uint32_t ob = __shfl_xor(best[n], 32, 64), os = __shfl_xor(second[n], 32, 64);
+        const uint32_t b = min(best[n], ob), s2 = min(max(best[n], ob), min(second[n], os));
+        const int qi = blockIdx.x * 256 + wave * 64 + n * 32 + col;
+        if (h == 0 && qi < A.q_stride) {
+            const uint64_t o = (uint64_t)p * A.q_stride + qi;
+            const bool live = qi < nq;
+            A.best_idx[o] = (!live || b == kNone) ? -1 : (int32_t)(b & 0xFFFFFu);
+            A.best_dist[o] = (!live || b == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(b >> 20);
+            A.second_dist[o] = (!live || s2 == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(s2 >> 20);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ratio_test(const int32_t *__restrict__ bi, const uint16_t *__restrict__ bd, const uint16_t *__restrict__ sd,
                                                     int n, float ratio, int max_dist, int32_t *__restrict__ match) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -347,7 +463,7 @@ static int launch_hamming(ms_ctx *c, const HamArgs &A, int n_pairs) {
     MS_HIP(c, hipSetDevice(c->device));
     dim3 grid(ms_div_up(A.q_stride, 256), n_pairs);
     if (A.qb || A.tv) hipLaunchKernelGGL(k_hamming_best2<true>, grid, dim3(256), 0, c->stream, A);
-    else hipLaunchKernelGGL(k_hamming_best2<false>, grid, dim3(256), 0, c->stream, A);
+    else hipLaunchKernelGGL(k_hamming_mfma, grid, dim3(256), 0, c->stream, A);
     MS_KERNEL_CHECK(c, "k_hamming_best2");
     return MS_OK;
 }

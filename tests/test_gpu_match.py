@@ -41,6 +41,40 @@ def test_hamming_ties_lowest_index_and_ragged(oracle, ctx):
             assert (bi == -1).all() and (bd == 256).all()
 
 
+def test_hamming_matrix_core_tile_edges_and_extremes(oracle, ctx):
+    """The unmasked search runs as an i8 matrix product (32-row target tiles, 128-target stages, 64 queries per wave):
+    sizes around every tile edge, distance 0 and 256, and per-set counts through the pool API."""
+    import mi355slam
+    rng = np.random.default_rng(9)
+    for nq, nt in [(1, 31), (31, 32), (33, 33), (63, 127), (65, 128), (64, 129), (255, 160), (256, 161), (300, 2), (2, 257)]:
+        q = rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32)
+        t = rng.integers(0, 2**32, (nt, 8), dtype=np.uint64).astype(np.uint32)
+        t[rng.integers(0, nt)] = q[0]                                   # distance 0
+        q[nq - 1] = 0; t[nt - 1] = 0xFFFFFFFF                           # distance 256 between these two
+        if nt > 1: t[0] = q[0] ^ np.uint32(1)                           # a near tie next to the exact copy
+        bi, bd, sd = mi355slam.hamming_best2(ctx, q, t)
+        wi, wd, ws = oracle.hamming_best2(q, t)
+        assert np.array_equal(bi, wi) and np.array_equal(bd, wd) and np.array_equal(sd, ws), (nq, nt)
+    q = np.zeros((5, 8), np.uint32); t = np.full((3, 8), 0xFFFFFFFF, np.uint32)
+    bi, bd, sd = mi355slam.hamming_best2(ctx, q, t)
+    assert (bi == 0).all() and (bd == 256).all() and (sd == 256).all()
+    # pools with per-set counts: 3 sets of stride 200, pair k = (set k) x (set (k+1) % 3)
+    stride, counts = 200, np.array([200, 37, 129], np.int32)
+    pool = rng.integers(0, 2**32, (3 * stride, 8), dtype=np.uint64).astype(np.uint32)
+    pq, pt = np.array([0, 1, 2], np.int32), np.array([1, 2, 0], np.int32)
+    dp, dc, dq, dt = ctx.upload(pool), ctx.upload(counts), ctx.upload(pq), ctx.upload(pt)
+    obi, obd, osd = ctx.alloc(4 * 3 * stride), ctx.alloc(2 * 3 * stride), ctx.alloc(2 * 3 * stride)
+    mi355slam.hamming_best2_sets(ctx, dp, stride, dc, dp, stride, dc, dq, dt, 3, obi, obd, osd)
+    ctx.sync()
+    bi, bd, sd = obi.download(np.int32, (3, stride)), obd.download(np.uint16, (3, stride)), osd.download(np.uint16, (3, stride))
+    for k in range(3):
+        a, b = pq[k], pt[k]
+        wi, wd, ws = oracle.hamming_best2(pool[a * stride:a * stride + counts[a]], pool[b * stride:b * stride + counts[b]])
+        n = counts[a]
+        assert np.array_equal(bi[k, :n], wi) and np.array_equal(bd[k, :n], wd) and np.array_equal(sd[k, :n], ws), k
+        assert (bi[k, n:] == -1).all() and (bd[k, n:] == 256).all()
+
+
 def test_hamming_masks(oracle, ctx):
     import mi355slam
     rng = np.random.default_rng(2)
