@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_hamming_best2(HamArgs A) {
 // Which bit sits in which k slot of a fragment is irrelevant as long as queries and targets use the same rule.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 constexpr int kHmStage = 128;      // targets per LDS stage (four 32-row tiles, 32 KB of +-1 bytes)
 
 template <bool NEG>
@@ -176,13 +177,24 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
             }
             const int row0 = base + m * 32 + 4 * h;                   // this lane's rows: row0 + (reg & 3) + 8 * (reg >> 2)
             if (base + m * 32 + 32 <= nt) {                           // full tile (uniform)
+                // both column tiles at once on packed 16-bit lanes: key16 = (2*distance) * 16 + register index (< 2^14); the
+                // register index orders a lane's rows, so the packed minimum is the lowest row among equal distances
+                us2_t lb = {0xFFFF, 0xFFFF}, ls = {0xFFFF, 0xFFFF};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t both = __builtin_amdgcn_perm((uint32_t)acc[1][r], (uint32_t)acc[0][r], 0x05040100u);   // low halves: (acc0, acc1)
+                    const us2_t sixteen = {16, 16}, bias = {(unsigned short)(4096 + r), (unsigned short)(4096 + r)};
+                    const us2_t key = __builtin_bit_cast(us2_t, both) * sixteen + bias;
+                    const us2_t lo = __builtin_elementwise_min(lb, key), hi = __builtin_elementwise_max(lb, key);
+                    ls = __builtin_elementwise_min(ls, hi);
+                    lb = lo;
+                }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    uint32_t lb = kNone, ls = kNone;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) best2_push(lb, ls, ((uint32_t)acc[n][r] << 19) + ((256u << 19) + (uint32_t)((r & 3) + 8 * (r >> 2))));
-                    best2_push(best[n], second[n], lb + (uint32_t)row0);
-                    second[n] = min(second[n], ls + (uint32_t)row0);
+                    const uint32_t kb = n ? lb.y : lb.x, ks = n ? ls.y : ls.x;      // d * 32 + r
+                    const uint32_t rb = kb & 15u, rs = ks & 15u;
+                    best2_push(best[n], second[n], ((kb >> 5) << 20) + (uint32_t)row0 + (rb & 3u) + 8u * (rb >> 2));
+                    second[n] = min(second[n], ((ks >> 5) << 20) + (uint32_t)row0 + (rs & 3u) + 8u * (rs >> 2));
                 }
             } else {                                                  // last tile of the set: rows beyond nt do not exist
 #pragma unroll

@@ -298,19 +298,17 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
 }
 
-// counts of brighter / darker compass pixels, packed 16-bit lanes (pixels 0,2 in E, pixels 1,3 in O).
-// One v_perm_b32 both shifts the 4-byte window out of a dword pair and zero-extends two of its bytes to 16-bit lanes;
-// the sign of a packed 16-bit difference becomes a 0/1 count with v_pk_lshrrev_b16 + v_pk_add_u16.
-struct Compass { uint32_t be, de, bo, dox; };
-__device__ __forceinline__ uint32_t sign_count(uint32_t cnt, uint32_t a, uint32_t b) {     // cnt += (a - b < 0) per 16-bit lane
-    const us2_t d = __builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b);
-    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, cnt) + (d >> (unsigned short)15)));
-}
-template <uint32_t SEL_E, uint32_t SEL_O>
-__device__ __forceinline__ void compass_add(Compass &M, uint32_t hi_dword, uint32_t lo_dword, uint32_t hie, uint32_t loe, uint32_t hio, uint32_t loo) {
-    const uint32_t re = __builtin_amdgcn_perm(hi_dword, lo_dword, SEL_E), ro = __builtin_amdgcn_perm(hi_dword, lo_dword, SEL_O);
-    M.be = sign_count(M.be, hie, re); M.de = sign_count(M.de, re, loe);
-    M.bo = sign_count(M.bo, hio, ro); M.dox = sign_count(M.dox, ro, loo);
+// Compass pre-test on packed 16-bit lanes (pixels 0,2 of a lane's dword in "E" registers, pixels 1,3 in "O").
+// One v_perm_b32 both shifts a 4-byte window out of a dword pair and zero-extends two of its bytes to 16-bit lanes.
+// "At least two of N,S,E,W brighter than c+t" is "the SECOND LARGEST of the four exceeds c+t" (and likewise the second smallest
+// for darker): two sorted pairs give both order statistics in 8 packed min/max, then one packed subtract each exposes the sign.
+// Returns bit 15 of each 16-bit lane set where the pixel survives.
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b))); }
+__device__ __forceinline__ uint32_t compass_pass(uint32_t n, uint32_t s_, uint32_t e, uint32_t w, uint32_t hi, uint32_t lo) {
+    const uint32_t a = pk_max(n, s_), b = pk_min(n, s_), c = pk_max(e, w), d = pk_min(e, w);
+    const uint32_t p = pk_min(a, c), q = pk_max(b, d);                    // the two middle values of the four
+    return (pk_sub(hi, pk_max(p, q)) | pk_sub(pk_min(p, q), lo)) & 0x80008000u;
 }
 
 // Ring of one FAST candidate: R[8] = centre, R[k] = ring pixels k and k+8 in the two 16-bit lanes.
@@ -391,7 +389,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     const int f = blockIdx.y, w = G.w, h = G.h, thr = g->fast_threshold;
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, in an SGPR: row addresses stay scalar
     // The wave's 10 image rows are requested FIRST, so their latency runs under the LDS clear and the barrier.
     const int x = X0 - 4 + 4 * lane;
     uint32_t rows[kFastRowsPerWave + 6];
@@ -425,14 +423,12 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
             const uint32_t Lw = wave_from_prev(C), Rw = wave_from_next(C);
             const uint32_t ce = C & 0x00FF00FFu, co = (C >> 8) & 0x00FF00FFu;
             const uint32_t hie = ce + T2, hio = co + T2, loe = pk_sub(ce, T2), loo = pk_sub(co, T2);
-            Compass M = {0, 0, 0, 0};
             // byte selectors: 0-3 = bytes of the low dword, 4-7 = bytes of the high dword, 0x0C = zero
-            compass_add<0x0C020C00u, 0x0C030C01u>(M, 0u, Cn, hie, loe, hio, loo);          // (0,+3): bytes 0,2 / 1,3 of Cn
-            compass_add<0x0C020C00u, 0x0C030C01u>(M, 0u, Cs, hie, loe, hio, loo);          // (0,-3)
-            compass_add<0x0C050C03u, 0x0C060C04u>(M, Rw, C, hie, loe, hio, loo);           // (+3,0): pixels x+3..x+6 of {Rw,C}
-            compass_add<0x0C030C01u, 0x0C040C02u>(M, C, Lw, hie, loe, hio, loo);           // (-3,0): pixels x-3..x   of {C,Lw}
-            const uint32_t pe = ((M.be + 0x7FFE7FFEu) | (M.de + 0x7FFE7FFEu)) & 0x80008000u;   // count >= 2 -> bit 15 of the lane
-            const uint32_t po = ((M.bo + 0x7FFE7FFEu) | (M.dox + 0x7FFE7FFEu)) & 0x80008000u;
+            const uint32_t pe = compass_pass(__builtin_amdgcn_perm(0u, Cn, 0x0C020C00u), __builtin_amdgcn_perm(0u, Cs, 0x0C020C00u),     // (0,+3), (0,-3): bytes 0,2
+                                             __builtin_amdgcn_perm(Rw, C, 0x0C050C03u), __builtin_amdgcn_perm(C, Lw, 0x0C030C01u),      // (+3,0): x+3, x+5 of {Rw,C}; (-3,0): x-3, x-1 of {C,Lw}
+                                             hie, loe);
+            const uint32_t po = compass_pass(__builtin_amdgcn_perm(0u, Cn, 0x0C030C01u), __builtin_amdgcn_perm(0u, Cs, 0x0C030C01u),     // bytes 1,3
+                                             __builtin_amdgcn_perm(Rw, C, 0x0C060C04u), __builtin_amdgcn_perm(C, Lw, 0x0C040C02u), hio, loo);
             const uint32_t flags = (((pe >> 15) & 1u) | ((po >> 14) & 2u) | ((pe >> 29) & 4u) | ((po >> 28) & 8u)) & vmask;   // pixel i -> bit i
             if (flags) {
                 const int pos = atomicAdd(&s_np, __popc(flags));
