@@ -703,9 +703,6 @@ __global__ __launch_bounds__(64) void k_tracks(const PyrGeom *g, const float *__
 //   level, 961 candidate offsets strided over the 64 lanes, DPP/shuffle reduction, cv::fastAtan2.
 //   descriptor (orb_extractor.cpp:284-352): lane j evaluates BRIEF tests j, j+64, j+128, j+192 on the
 //   BLURRED level; four 64-bit ballots are the 256 descriptor bits (test t -> word t/32, bit t%32).
-__constant__ int8_t c_pattern[1024] = {
-#include "orb_pattern.inc"
-};
 
 __device__ __forceinline__ float dev_fast_atan2(float y, float x) {   // cv::fastAtan2 (atan_f32), degrees
     const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
@@ -750,7 +747,7 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g,
+__global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
                                                   const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
                                                   const int16_t *__restrict__ trk_x, const int16_t *__restrict__ trk_y, const float *__restrict__ trk_px,
                                                   const float *__restrict__ trk_py, const int32_t *__restrict__ trk_id, const int32_t *__restrict__ trk_count,
@@ -787,17 +784,19 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, oct, pitch);
     const uint8_t *ctr = img + (int64_t)y * pitch + x;
-    // O1: moments
+    // O1: moments.  The 961 offsets of the 31x31 box are strided over the 64 lanes (offset lane + 64 k); the (u, v) of each is a
+    // host-built table entry (two int8, zero outside the radius-15 disc), 32 bytes per lane = two 16-byte loads; the pixel gathers
+    // use the wave-uniform patch centre as scalar base, so an offset costs one multiply-add.
     int m10 = 0, m01 = 0;
     {
+        const uint4 ta = moment_tab[2 * lane], tb = moment_tab[2 * lane + 1];
+        const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         int I[16], uu[16], vv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {                 // 961 offsets of the 31x31 box over 64 lanes: 16 gathers in flight
-            const int i = lane + 64 * k;
-            const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
-            const bool in = i < 31 * 31 && abs(u) <= g->umax[min(abs(v), 15)];
-            uu[k] = in ? u : 0; vv[k] = in ? v : 0;
-            I[k] = ctr[(int64_t)vv[k] * pitch + uu[k]];
+        for (int k = 0; k < 16; ++k) {                 // 16 gathers in flight
+            uu[k] = __builtin_amdgcn_sbfe((int)tw[k >> 1], 16 * (k & 1), 8);
+            vv[k] = __builtin_amdgcn_sbfe((int)tw[k >> 1], 16 * (k & 1) + 8, 8);
+            I[k] = ctr[vv[k] * pitch + uu[k]];
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) { m10 += uu[k] * I[k]; m01 += vv[k] * I[k]; }
@@ -812,13 +811,13 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     unsigned long long bits[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int8_t *p = c_pattern + (q * 64 + lane) * 4;
-        const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+        const float4 pt = pattern_f[q * 64 + lane];             // the test's two points, already float
+        const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
         const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa), __fmul_rn(y2, ca)));
         const int c2 = __float2int_rn(__fsub_rn(__fmul_rn(x2, ca), __fmul_rn(y2, sa)));
-        bits[q] = __ballot(bctr[(int64_t)r1 * bp + c1] < bctr[(int64_t)r2 * bp + c2]);
+        bits[q] = __ballot(bctr[r1 * bp + c1] < bctr[r2 * bp + c2]);
     }
     const uint64_t o = (uint64_t)f * g->capacity + slot;
     if (lane < 8) out_desc[o * 8 + lane] = (uint32_t)(bits[lane >> 1] >> ((lane & 1) * 32));
@@ -850,6 +849,8 @@ struct ms_orb {
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
     bool wide[MS_MAX_LEVELS] = {false};
+    uint4 *d_moment_tab = nullptr;            // k_describe: (u, v) of the 961 patch offsets, [lane][16] int8 pairs
+    float4 *d_pattern_f = nullptr;            // k_describe: the 256 BRIEF point pairs as floats
     unsigned long long *d_stamps = nullptr;   // diagnostic: per-phase cycle sums of k_fast (ms_orb_fast_phase_cycles)
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
@@ -965,6 +966,24 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         };
         up(&o->d_xtab[l], xt); up(&o->d_ytab[l], yt);
     }
+    if (rc == MS_OK) {                                   // k_describe's lane tables
+        static const int8_t pattern[1024] = {
+#include "orb_pattern.inc"
+        };
+        std::vector<uint16_t> mt(64 * 16, 0);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int k = 0; k < 16; ++k) {
+                const int i = lane + 64 * k;
+                if (i >= 31 * 31) continue;
+                const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
+                if (std::abs(u) <= G.umax[std::min(std::abs(v), 15)]) mt[lane * 16 + k] = (uint16_t)((u & 0xFF) | ((v & 0xFF) << 8));
+            }
+        std::vector<float> pf(1024);
+        for (int i = 0; i < 1024; ++i) pf[i] = (float)pattern[i];
+        if (hipMalloc(reinterpret_cast<void **>(&o->d_moment_tab), mt.size() * 2) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&o->d_pattern_f), pf.size() * 4) != hipSuccess ||
+            hipMemcpy(o->d_moment_tab, mt.data(), mt.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(o->d_pattern_f, pf.data(), pf.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = MS_ERR_HIP;
+    }
     if (rc == MS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
     if (rc != MS_OK) { ms_orb_destroy(o); return ms_fail(ctx, rc, "ms_orb_create: device allocation failed"); }
     *out = o;
@@ -980,6 +999,8 @@ void ms_orb_destroy(ms_orb *o) {
                     o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->d_stamps) (void)hipFree(o->d_stamps);
+    if (o->d_moment_tab) (void)hipFree(o->d_moment_tab);
+    if (o->d_pattern_f) (void)hipFree(o->d_pattern_f);
     for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
 
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
@@ -1107,7 +1128,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
                        o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
     MS_KERNEL_CHECK(c, "k_tracks");
     MS_STAGE_MARK();
-    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_det_x, o->d_det_y,
+    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
                        o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count);
     MS_KERNEL_CHECK(c, "k_describe");
