@@ -207,6 +207,17 @@ __device__ __forceinline__ uint32_t dot2(uint32_t a, unsigned lo, unsigned hi, u
 __device__ __forceinline__ uint32_t wave_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t wave_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
 
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then row_bcast 15 / 31 across rows
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+    return v;
+}
+
 constexpr int kBlurSeg = 248;   // outputs per wave row segment
 constexpr int kBlurRows = 8;    // output rows per wave (kBlurRows + 6 input rows are loaded: 1.75x read amplification through L1)
 
@@ -741,10 +752,8 @@ __device__ __forceinline__ float dev_cos(float v) {        // openvslam/trigonom
 }
 __device__ __forceinline__ float dev_sin(float v) { return dev_cos(__fsub_rn(3.14159265358979f / 2.0f, v)); }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+__device__ __forceinline__ int wave_sum(int v) {      // DPP inclusive scan, total broadcast from lane 63
+    return __builtin_amdgcn_readlane(wave_scan_add(v), 63);
 }
 
 __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
