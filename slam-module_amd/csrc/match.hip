@@ -128,7 +128,7 @@ __device__ __forceinline__ void best2_push(uint32_t &best, uint32_t &second, uin
 
 __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
     __shared__ __attribute__((aligned(16))) uint32_t s_a[kHmStage * 64];
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
     const int qs = A.pair_q ? A.pair_q[p] : p, ts = A.pair_t ? A.pair_t[p] : p;
     const int nq = A.q_count ? min(A.q_count[qs], A.nq) : A.nq;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__re
                                                             const uint8_t *__restrict__ skip, const int32_t *__restrict__ toct,
                                                             int32_t *__restrict__ bi, uint16_t *__restrict__ bd, uint16_t *__restrict__ sd,
                                                             int32_t *__restrict__ bo, int32_t *__restrict__ so, int32_t *__restrict__ si) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nq) return;
     const uint4 qa = reinterpret_cast<const uint4 *>(qd)[2 * i], qb = reinterpret_cast<const uint4 *>(qd)[2 * i + 1];
     const uint32_t qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};

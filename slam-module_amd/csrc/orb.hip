@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
     const LevelGeom &D = g->L[l];
     const int sw = g->L[l - 1].w;
     const int f = blockIdx.z;
-    const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kResizeRows;
+    const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kResizeRows;   // wave-uniform (SGPR): row addresses stay scalar
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     if (dy0 >= D.h || dx0 >= D.w) return;
     int spitch;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, Ti
     const int l = tile_level(tm, levels, t);
     t -= tm.base[l];
     const LevelGeom &G = g->L[l];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (SGPR): the 14 row addresses are scalar work
     const int x = (t % G.btiles_x) * kBlurSeg - 4 + lane * 4;
     const int y0 = (t / G.btiles_x) * (4 * kBlurRows) + wave * kBlurRows;
     const int f = blockIdx.y, w = G.w, h = G.h;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
                                                   int32_t *__restrict__ out_octave, uint32_t *__restrict__ out_desc, int32_t *__restrict__ out_track,
                                                   int32_t *__restrict__ out_count) {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // one keypoint per wave: everything derived from it is scalar
     const int levels = g->levels;
     // segment table of this frame: [tracks][level 0][level 1]...
     const int nt = trk_count[f];
