@@ -35,6 +35,7 @@ struct LevelGeom {
     int32_t cand_cap;                 // capacity of this level's candidate list (entries)
     int32_t btiles_x, btile_base;     // k_blur tile table (248x16 tiles)
     int32_t ftiles_x, ftile_base;     // k_fast tile table (248x30 tiles)
+    uint32_t btiles_inv, ftiles_inv;  // ceil(2^32 / tiles_x): row of a tile = mulhi(t, inv), exact for t < 2^16
     uint64_t img_off, blur_off;       // byte offsets inside a frame slab
     uint64_t cand_off;                // entry offset inside a frame's candidate buffer
     float scale;                      // scaleFactors[l] (float32 chain)
@@ -54,7 +55,7 @@ struct TileMap { int32_t base[MS_MAX_LEVELS + 1]; };
 __device__ __forceinline__ int tile_level(const TileMap &tm, int levels, int t) {
     int l = 0;
 #pragma unroll
-    for (int k = 1; k < MS_MAX_LEVELS; ++k) l += (k < levels && t >= tm.base[k]) ? 1 : 0;
+    for (int k = 1; k < MS_MAX_LEVELS; ++k) l += t >= tm.base[k] ? 1 : 0;     // base[k >= levels] = tile total > t: a compare and an add-with-carry per level
     return l;
 }
 
@@ -227,8 +228,9 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, Ti
     t -= tm.base[l];
     const LevelGeom &G = g->L[l];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (SGPR): the 14 row addresses are scalar work
-    const int x = (t % G.btiles_x) * kBlurSeg - 4 + lane * 4;
-    const int y0 = (t / G.btiles_x) * (4 * kBlurRows) + wave * kBlurRows;
+    const int trow = G.btiles_x == 1 ? t : (int)__umulhi((uint32_t)t, G.btiles_inv);     // t / btiles_x without the division sequence (2^32 / 1 does not fit)
+    const int x = (t - trow * G.btiles_x) * kBlurSeg - 4 + lane * 4;
+    const int y0 = trow * (4 * kBlurRows) + wave * kBlurRows;
     const int f = blockIdx.y, w = G.w, h = G.h;
     if (y0 >= h) return;
     int pitch;
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     const int l = tile_level(tm, levels, t);
     t -= tm.base[l];
     const LevelGeom &G = g->L[l];
-    const int X0 = (t % G.ftiles_x) * kFastSeg, Y0 = (t / G.ftiles_x) * kFastRows;
+    const int trow = G.ftiles_x == 1 ? t : (int)__umulhi((uint32_t)t, G.ftiles_inv);     // t / ftiles_x without the division sequence (2^32 / 1 does not fit)
+    const int X0 = (t - trow * G.ftiles_x) * kFastSeg, Y0 = trow * kFastRows;
     const int f = blockIdx.y, w = G.w, h = G.h, thr = g->fast_threshold;
     int pitch;
     const uint8_t *img = level_ptr(src, g, f, l, pitch);
@@ -911,6 +914,10 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
             delete o;
             return ms_fail(ctx, MS_ERR_INVALID, "ms_orb_create: level %d is %dx%d (min 40x40) / quota %d (max %d)", l, w[l], h[l], quota[l], kMaxQuota);
         }
+        if ((int64_t)ms_div_up(w[l], kFastSeg) * ms_div_up(h[l], kFastRows) >= 65536) {      // the kernels' mulhi tile division is exact below 2^16 tiles per level
+            delete o;
+            return ms_fail(ctx, MS_ERR_CAPACITY, "ms_orb_create: level %d (%dx%d) needs more than 65535 detector tiles", l, w[l], h[l]);
+        }
         LevelGeom &L = G.L[l];
         L.w = w[l]; L.h = h[l]; L.pitch = (int)ms_align_up(w[l], 64); L.quota = quota[l]; L.scale = sf[l];
         {   // feature_detector.cpp:79-82: minDist = floor(gfttMinDistance * (min(w,h) / 720 * 0.8) + 0.5)
@@ -924,6 +931,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         L.cand_off = coff; coff += L.cand_cap;
         L.btiles_x = ms_div_up(w[l], kBlurSeg); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 4 * kBlurRows);
         L.ftiles_x = ms_div_up(w[l], kFastSeg); L.ftile_base = ft; ft += L.ftiles_x * ms_div_up(h[l], kFastRows);
+        L.btiles_inv = (uint32_t)(((1ull << 32) + L.btiles_x - 1) / L.btiles_x); L.ftiles_inv = (uint32_t)(((1ull << 32) + L.ftiles_x - 1) / L.ftiles_x);
     }
     G.btiles_total = bt; G.ftiles_total = ft;
     for (int l = 0; l <= MS_MAX_LEVELS; ++l) {
