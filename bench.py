@@ -144,15 +144,21 @@ def main():
     kernels = {k: {"ms_per_launch": round(avg_ms[k], 4), "alg_GBs": round(alg[k] * BATCH / (avg_ms[k] * 1e-3) / 1e9, 1) if avg_ms[k] > 0 else None}
                for k in avg_ms}
     achieved = alg[dom] * BATCH / (avg_ms[dom] * 1e-3) / 1e9
-    traffic = None                                   # HBM bytes per launch from the committed PMC passes (profiles/)
+    # From the committed PMC passes (profiles/r01_pmc_traffic.json, tools/pmc_summary.py): HBM bytes per launch and the
+    # wave-level VALU instruction count.  The front-end kernels are bound by VALU ISSUE, not by HBM: almost all their
+    # instructions are VOP3 / packed forms that issue once per ~4 cycles per SIMD (profiles/r01_e_valu_issue_rates.txt), so
+    # valu_issue_frac = count / 1024 SIMDs x 4 cycles / 2.4 GHz / (measured launch time) is the fraction of that limit in use.
+    traffic = valu = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        kname = {"hamming": "k_hamming_best2"}.get(dom, "k_" + dom)
+        kname = {"hamming": "k_hamming_mfma"}.get(dom, "k_" + dom)
         traffic = pmc[kname]["hbm_bytes_per_step"]
+        valu = pmc[kname]["SQ_INSTS_VALU_per_step"]
     except Exception:
         pass
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "valu_insts": valu, "valu_issue_frac": round(valu / 1024 * 4 / 2.4e9 / (avg_ms[dom] * 1e-3), 3) if valu else None,
                 "whole_step_alg_GBs": round((4 * P + 1821 * K + 72 * K) * BATCH * args.steps / dt / 1e9, 1)}
     out = {
         "metric": "frames/sec ORB extract+match (720p)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
@@ -168,7 +174,7 @@ def main():
         out["local_ba"] = bench_ba(ctx, args, world, rank, dist if world > 1 else None, torch)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_np, 24)
+            out["cpu_baseline"] = cpu_baseline(frames_np, 128)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -214,10 +220,11 @@ def bench_ba(ctx, args, world, rank, dist, torch):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import mso
         t1 = time.perf_counter()
-        for i in range(4):
-            mso.ba_solve(distinct[i], 10, False)
-        res["cpu_baseline"] = {"value": round(4 / (time.perf_counter() - t1), 2), "unit": "solves/s", "cores": 1, "kind": "port",
-                               "sample": "4 C4 windows, oracle/libmso.so (Schur + dense Cholesky), 1 thread"}
+        n_cpu = 48
+        for i in range(n_cpu):
+            mso.ba_solve(distinct[i % 4], 10, False)
+        res["cpu_baseline"] = {"value": round(n_cpu / (time.perf_counter() - t1), 2), "unit": "solves/s", "cores": 1, "kind": "port",
+                               "sample": "%d solves of C4 windows (4 distinct), oracle/libmso.so (Schur + dense Cholesky), 1 thread" % n_cpu}
     ba.close(); one.close()
     return res
 

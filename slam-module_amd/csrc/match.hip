@@ -7,11 +7,11 @@
 //   ms_match_loop_closure   matchForLoopClosures       keyframe_matcher.cpp:50-158
 //   ms_match_triangulation  matchForTriangulationDBoW  keyframe_matcher.cpp:160-293
 //
-// The brute-force kernel is VALU-bound, not HBM-bound (32 distance evaluations per input byte at
-// 2000x2000): each lane keeps one 256-bit query in 8 VGPRs, targets are staged through LDS in tiles
-// of 256 and read back as wave-uniform broadcasts (2 x ds_read_b128 per target), distance is 8 x
-// (v_xor, v_bcnt_u32_b32-accumulate), and best/second are tracked branch-free on packed
-// (distance<<20 | index) keys (min / max / min).
+// The brute-force search is compute-bound, not HBM-bound (32 distance evaluations per input byte at 2000x2000).
+// Unmasked it runs on the matrix cores (k_hamming_mfma: the distance matrix is an i8 product of +-1 bytes).  With bucket /
+// validity masks it stays on the VALU (k_hamming_best2<true>): each lane keeps one 256-bit query in 8 VGPRs, targets are
+// staged through LDS in tiles of 256 and read back as wave-uniform broadcasts (2 x ds_read_b128 per target), distance is
+// 8 x (v_xor, v_bcnt_u32_b32-accumulate), best/second are tracked branch-free on packed (distance<<20 | index) keys.
 #include "ms_internal.h"
 #include <cmath>
 #include <vector>
