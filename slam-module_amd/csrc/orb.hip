@@ -354,32 +354,26 @@ __device__ __forceinline__ void fast_ring_load_wide(const uint8_t *p, int pitch,
 }
 
 // FAST score = max over the 16 arcs of 9 of min(c - r) and of min(r - c), on packed 16-bit lanes: P[k] = (d[k], d[k+8]) with
-// d = centre - ring pixel; the sliding min / max of 9 over the circular ring is four v_pk_min_i16 / v_pk_max_i16 levels
-// (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
+// d = centre - ring pixel.  A 9-arc starting at k < 8 is the suffix d[k..7] of the first half plus the prefix d[8..8+k] of the
+// second, the one starting at k+8 the mirror image, so running prefix / suffix minima of P (7 packed ops each) and one combine
+// per k with the halves swapped (free operand select) give all 16 arc minima in 22 ops; the same for the maxima.
 __device__ __forceinline__ int fast_ring_score(const uint32_t R[9]) {
     const uint32_t cc = R[8] * 0x00010001u;
-    s2_t P[16];
+    s2_t P[8], pmn[8], pmx[8], smn[8], smx[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) P[k] = __builtin_bit_cast(s2_t, pk_sub(cc, R[k]));
+    pmn[0] = pmx[0] = P[0];
+    smn[7] = smx[7] = P[7];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) P[k + 8] = P[k].yx;                       // (d[k+8], d[k]): the ring is circular
-    s2_t mn[12], mx[12];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { mn[k] = __builtin_elementwise_min(P[k], P[k + 1]); mx[k] = __builtin_elementwise_max(P[k], P[k + 1]); }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { mn[8 + k] = mn[k].yx; mx[8 + k] = mx[k].yx; }
-    s2_t mn4[12], mx4[12];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { mn4[k] = __builtin_elementwise_min(mn[k], mn[k + 2]); mx4[k] = __builtin_elementwise_max(mx[k], mx[k + 2]); }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { mn4[8 + k] = mn4[k].yx; mx4[8 + k] = mx4[k].yx; }
+    for (int k = 1; k < 8; ++k) {
+        pmn[k] = __builtin_elementwise_min(pmn[k - 1], P[k]); pmx[k] = __builtin_elementwise_max(pmx[k - 1], P[k]);
+        smn[7 - k] = __builtin_elementwise_min(smn[8 - k], P[7 - k]); smx[7 - k] = __builtin_elementwise_max(smx[8 - k], P[7 - k]);
+    }
     s2_t bright = {-32768, -32768}, dark = {32767, 32767};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const s2_t m9 = __builtin_elementwise_min(__builtin_elementwise_min(mn4[k], mn4[k + 4]), P[k + 8]);   // arcs starting at k and k+8
-        const s2_t x9 = __builtin_elementwise_max(__builtin_elementwise_max(mx4[k], mx4[k + 4]), P[k + 8]);
-        bright = __builtin_elementwise_max(bright, m9);
-        dark = __builtin_elementwise_min(dark, x9);
+        bright = __builtin_elementwise_max(bright, __builtin_elementwise_min(smn[k], pmn[k].yx));   // arcs starting at k (.x) and k+8 (.y)
+        dark = __builtin_elementwise_min(dark, __builtin_elementwise_max(smx[k], pmx[k].yx));
     }
     return max(max((int)bright.x, (int)bright.y), -min((int)dark.x, (int)dark.y));
 }
