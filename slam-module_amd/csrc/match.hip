@@ -96,30 +96,24 @@ __global__ __launch_bounds__(256) void k_hamming_best2(HamArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The unmasked all-pairs search as an integer matrix product on the matrix cores.  With descriptor bits mapped to
-// +-1 bytes (queries: 0 -> +1, 1 -> -1; targets the opposite sign) the i8 dot product of a query and a target is
-// 2*hamming - 256, exactly, so a 32x32 tile of distances is eight v_mfma_i32_32x32x32_i8 (K = 256 bits).
+// The unmasked all-pairs search as an integer matrix product on the matrix cores.  Queries become +-1 bytes (bit 0 -> +1,
+// bit 1 -> -1), targets stay 0 / 1 bytes; then  hamming(q, t) = popcount(q) + sum_k t_k * (1 - 2 q_k)  exactly, i.e. the i8 dot
+// product plus a per-query constant that does not change the order of the targets.  A 32x32 tile of distances is eight
+// v_mfma_i32_32x32x32_i8 (K = 256 bits).
+//   * target bytes cost two full-rate VALU ops per dword: (word >> s) & 0x01010101 puts bits s, s+8, s+16, s+24 of a descriptor
+//     word into the four bytes -- which bit sits in which k slot of a fragment is irrelevant as long as queries and targets use
+//     the same rule, so the k order is chosen to make the expansion free of multiplies and byte shuffles;
 //   * a wave owns 64 queries (two 32-wide column tiles) whose operand fragments live in 64 registers for the whole kernel;
-//   * the workgroup (4 waves = 256 queries) expands 128 targets per stage from packed bits into LDS, already in operand
-//     order ([row tile][k step][lane][16 B]), so an A fragment is one conflict-free ds_read_b128;
-//   * accumulator layout: column (= query) on the lane, 16 target rows in the registers, so best / second are tracked per
-//     lane with the same packed (distance<<20 | index) keys and min / max / min as the VALU kernel: 4 VALU ops per pair
-//     instead of 21.  The two lane halves (rows 4h..) of a column are merged once at the end.
-// Which bit sits in which k slot of a fragment is irrelevant as long as queries and targets use the same rule.
+//   * the workgroup (4 waves = 256 queries) expands 128 targets per stage into LDS, already in operand order
+//     ([row tile][k step][lane][16 B]), so an A fragment is one conflict-free ds_read_b128;
+//   * accumulator layout: column (= query) on the lane, 16 target rows in the registers, so best / second are tracked per lane,
+//     both column tiles at once on packed 16-bit keys (2.5 VALU ops per pair instead of 21).  The two lane halves (rows 4h..)
+//     of a column are merged once at the end, where popcount(q) turns the dot product back into the distance.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 constexpr int kHmStage = 128;      // targets per LDS stage (four 32-row tiles, 32 KB of +-1 bytes)
 
-template <bool NEG>
-__device__ __forceinline__ uint32_t expand4(uint32_t nib) {          // 4 bits -> 4 bytes: bit i -> byte i = +1 / -1
-    const uint32_t x = (nib * 0x00204081u) & 0x01010101u;
-    return ((NEG ? x ^ 0x01010101u : x) * 0xFEu) | 0x01010101u;      // NEG: 0 -> -1, 1 -> +1; else 0 -> +1, 1 -> -1
-}
-template <bool NEG>
-__device__ __forceinline__ v4i_t expand16(uint32_t bits) {
-    return v4i_t{(int)expand4<NEG>(bits & 15u), (int)expand4<NEG>((bits >> 4) & 15u), (int)expand4<NEG>((bits >> 8) & 15u), (int)expand4<NEG>((bits >> 12) & 15u)};
-}
 __device__ __forceinline__ void best2_push(uint32_t &best, uint32_t &second, uint32_t key) {
     const uint32_t lo = min(best, key), hi = max(best, key);
     second = min(second, hi);
@@ -142,6 +136,7 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
     const uint4 *Q = reinterpret_cast<const uint4 *>(A.q + (uint64_t)qs * A.q_stride * 8);
     const uint4 *T = reinterpret_cast<const uint4 *>(A.t + (uint64_t)ts * A.t_stride * 8);
     v4i_t bq[2][8];
+    int popq[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int qi = blockIdx.x * 256 + wave * 64 + n * 32 + col;
@@ -149,7 +144,12 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
         if (qi < nq) { lo = Q[2 * qi]; hi = Q[2 * qi + 1]; }
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) bq[n][s] = expand16<false>((w[s] >> (16 * h)) & 0xFFFFu);
+        for (int s = 0; s < 8; ++s)                   // lane half h holds bits 4h+j (+8, +16, +24) of word s in dword j, as +1 / -1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[n][s][j] = (int)((((w[s] >> (4 * h + j)) & 0x01010101u) * 0xFEu) | 0x01010101u);
+        popq[n] = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) popq[n] += __popc(w[s]);
     }
     uint32_t best[2] = {kNone, kNone}, second[2] = {kNone, kNone};
     for (int base = 0; base < nt; base += kHmStage) {
@@ -162,8 +162,11 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-                    *reinterpret_cast<v4i_t *>(&s_a[((tau >> 5) * 8 + 4 * half + k) * 256 + (hh * 32 + (tau & 31)) * 4]) = expand16<true>((w4[k] >> (16 * hh)) & 0xFFFFu);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint32_t w = w4[k] >> (4 * hh);
+                    *reinterpret_cast<v4i_t *>(&s_a[((tau >> 5) * 8 + 4 * half + k) * 256 + (hh * 32 + (tau & 31)) * 4]) =
+                        v4i_t{(int)(w & 0x01010101u), (int)((w >> 1) & 0x01010101u), (int)((w >> 2) & 0x01010101u), (int)((w >> 3) & 0x01010101u)};
+                }
         }
         __syncthreads();
         const int mtiles = min(kHmStage / 32, (nt - base + 31) >> 5);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
             }
             const int row0 = base + m * 32 + 4 * h;                   // this lane's rows: row0 + (reg & 3) + 8 * (reg >> 2)
             if (base + m * 32 + 32 <= nt) {                           // full tile (uniform)
-                // both column tiles at once on packed 16-bit lanes: key16 = (2*distance) * 16 + register index (< 2^14); the
+                // both column tiles at once on packed 16-bit lanes: key16 = (dot + 256) * 16 + register index (< 2^14); the
                 // register index orders a lane's rows, so the packed minimum is the lowest row among equal distances
                 us2_t lb = {0xFFFF, 0xFFFF}, ls = {0xFFFF, 0xFFFF};
 #pragma unroll
@@ -191,10 +194,10 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const uint32_t kb = n ? lb.y : lb.x, ks = n ? ls.y : ls.x;      // d * 32 + r
+                    const uint32_t kb = n ? lb.y : lb.x, ks = n ? ls.y : ls.x;      // (dot + 256) * 16 + r
                     const uint32_t rb = kb & 15u, rs = ks & 15u;
-                    best2_push(best[n], second[n], ((kb >> 5) << 20) + (uint32_t)row0 + (rb & 3u) + 8u * (rb >> 2));
-                    second[n] = min(second[n], ((ks >> 5) << 20) + (uint32_t)row0 + (rs & 3u) + 8u * (rs >> 2));
+                    best2_push(best[n], second[n], ((kb >> 4) << 20) + (uint32_t)row0 + (rb & 3u) + 8u * (rb >> 2));
+                    second[n] = min(second[n], ((ks >> 4) << 20) + (uint32_t)row0 + (rs & 3u) + 8u * (rs >> 2));
                 }
             } else {                                                  // last tile of the set: rows beyond nt do not exist
 #pragma unroll
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + (r & 3) + 8 * (r >> 2);
-                        const uint32_t key = (((uint32_t)acc[n][r] + 256u) << 19) + (uint32_t)row;
+                        const uint32_t key = (((uint32_t)acc[n][r] + 256u) << 20) + (uint32_t)row;
                         best2_push(best[n], second[n], row < nt ? key : kNone);
                     }
             }
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
             const uint64_t o = (uint64_t)p * A.q_stride + qi;
             const bool live = qi < nq;
             A.best_idx[o] = (!live || b == kNone) ? -1 : (int32_t)(b & 0xFFFFFu);
-            A.best_dist[o] = (!live || b == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(b >> 20);
-            A.second_dist[o] = (!live || s2 == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(s2 >> 20);
+            A.best_dist[o] = (!live || b == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)((int)(b >> 20) - 256 + popq[n]);
+            A.second_dist[o] = (!live || s2 == kNone) ? (uint16_t)MS_HAMMING_MAX : (uint16_t)((int)(s2 >> 20) - 256 + popq[n]);
         }
     }
 }
