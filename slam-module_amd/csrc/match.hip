@@ -172,11 +172,14 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
         const int mtiles = min(kHmStage / 32, (nt - base + 31) >> 5);
         for (int m = 0; m < mtiles; ++m) {
             v16i_t acc[2] = {};
+            v4i_t a[8];                                               // all eight fragments of the tile are requested before the first MFMA waits
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const v4i_t *>(&s_a[(m * 8 + s) * 256 + lane * 4]);
+            __builtin_amdgcn_sched_barrier(0);                        // keep the reads ahead of the chain (the scheduler would re-serialise them to save registers)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const v4i_t a = *reinterpret_cast<const v4i_t *>(&s_a[(m * 8 + s) * 256 + lane * 4]);
-                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[1][s], acc[1], 0, 0, 0);
             }
             const int row0 = base + m * 32 + 4 * h;                   // this lane's rows: row0 + (reg & 3) + 8 * (reg >> 2)
             if (base + m * 32 + 32 <= nt) {                           // full tile (uniform)
