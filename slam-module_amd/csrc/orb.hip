@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t *src, uint64_
 // (12 bytes cover the <= 8-byte tap window of its 4 pixels for scale factors up to 2) and funnel-shifts
 // them into a 64-bit window; the per-column (offset, a0, a1) and per-row (row0, row1, b0, b1) tables are
 // packed so a lane needs two 16-byte table loads.  HBM-bound by design: reads level l-1, writes level l.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+typedef short s2_t __attribute__((ext_vector_type(2)));
+
 struct ResizeTab {
     const int16_t *xtab;   // [dw][4] : sx, a0, a1, 0
     const int16_t *ytab;   // [dh][4] : sy0, sy1 (clamped rows), b0, b1
@@ -107,10 +110,6 @@ struct Window3 { uint32_t d0, d1, d2; };
 __device__ __forceinline__ Window3 window_load(const uint8_t *row, int base, int last_dword) {
     return {*reinterpret_cast<const uint32_t *>(row + min(base, last_dword)), *reinterpret_cast<const uint32_t *>(row + min(base + 4, last_dword)),
             *reinterpret_cast<const uint32_t *>(row + min(base + 8, last_dword))};
-}
-__device__ __forceinline__ uint64_t window_shift(const Window3 &W, int sh) {
-    const uint64_t lo = ((uint64_t)W.d1 << 32) | W.d0;
-    return sh ? (lo >> sh) | ((uint64_t)W.d2 << (64 - sh)) : lo;
 }
 
 template <bool WIDE>   // WIDE: tap window of 4 pixels may exceed 8 bytes (scale factor > 2) -> per-tap byte loads
@@ -132,7 +131,15 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) yt[r] = reinterpret_cast<const short4 *>(T.ytab)[dy0 + r];
     if (!WIDE) {
-        const int sx0 = xt[0].x, last = (sw - 1) & ~3, base = sx0 & ~3, sh = 8 * (sx0 & 3);
+        const int sx0 = xt[0].x, last = (sw - 1) & ~3, base = sx0 & ~3;
+        // per column: the two taps as one v_dot2 operand (a0, a1), and a v_perm selector that lifts source bytes k, k+1 of the
+        // row's 8-byte window into 16-bit lanes (k = sx - sx0 <= 6)
+        uint32_t A[4], sel[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A[i] = (uint32_t)(uint16_t)xt[i].y | ((uint32_t)(uint16_t)xt[i].z << 16);
+            sel[i] = 0x0C010C00u + (uint32_t)(xt[i].x - sx0) * 0x00010001u;
+        }
         Window3 W0[kResizeRows], W1[kResizeRows];
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
@@ -141,10 +148,18 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
         }
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
-            const uint64_t w0 = window_shift(W0[r], sh), w1 = window_shift(W1[r], sh);
-            uint32_t packed = 0;
+            // window = source bytes sx0 .. sx0+7 of each tap row (byte funnel of the three aligned dwords)
+            const uint32_t lo0 = __builtin_amdgcn_alignbyte(W0[r].d1, W0[r].d0, (uint32_t)sx0), hi0 = __builtin_amdgcn_alignbyte(W0[r].d2, W0[r].d1, (uint32_t)sx0);
+            const uint32_t lo1 = __builtin_amdgcn_alignbyte(W1[r].d1, W1[r].d0, (uint32_t)sx0), hi1 = __builtin_amdgcn_alignbyte(W1[r].d2, W1[r].d1, (uint32_t)sx0);
+            const uint32_t b0 = (uint32_t)yt[r].z, b1 = (uint32_t)yt[r].w;
+            uint32_t v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) packed |= (uint32_t)resize_px(w0, w1, xt[i].x - sx0, xt[i].y, xt[i].z, yt[r].z, yt[r].w) << (8 * i);
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi0, lo0, sel[i])), __builtin_bit_cast(us2_t, A[i]), 0u, false);
+                const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi1, lo1, sel[i])), __builtin_bit_cast(us2_t, A[i]), 0u, false);
+                v[i] = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2) >> 2;      // <= 255 by construction (taps sum to 2048 +- 1)
+            }
+            const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
             if (dy0 + r < D.h) *reinterpret_cast<uint32_t *>(dst + (uint64_t)(dy0 + r) * D.pitch + dx0) = packed;
         }
     } else {
@@ -173,8 +188,6 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
 //                   v_dot2_u32_u16 with the rounding constant as the initial accumulator
 // Lanes 0 and 63 only provide halo (248 outputs per 256 loaded pixels); REFLECT_101 is applied when the
 // bytes are loaded, which commutes with the vertical pass.
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-typedef short s2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int reflect101(int i, int n) {
     i = i < 0 ? -i : i;
