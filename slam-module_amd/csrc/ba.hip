@@ -404,12 +404,14 @@ __device__ __noinline__ void build_system(const BaProb &P_) {
     __syncthreads();
 }
 
-__device__ __forceinline__ void schur_fetch(const MS_GLOBAL int32_t *chunk_items, const MS_GLOBAL double *Y, const MS_GLOBAL double *Hpl, int ch, int lane,
-                                            d2_t (&v)[9]) {
+// The (observation a, observation b) pairs of a chunk, one per record piece this lane moves (9 pieces per lane) ...
+__device__ __forceinline__ void schur_fetch_items(const MS_GLOBAL int32_t *chunk_items, int ch, int lane, i2_t (&ab)[9]) {
     const MS_GLOBAL i2_t *items = reinterpret_cast<const MS_GLOBAL i2_t *>(chunk_items) + (size_t)ch * CH;
-    i2_t ab[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) ab[k] = items[(lane + 64 * k) / 18];
+}
+// ... and the 16-byte pieces of their Y_a / Hpl_b records
+__device__ __forceinline__ void schur_fetch_records(const MS_GLOBAL double *Y, const MS_GLOBAL double *Hpl, int lane, const i2_t (&ab)[9], d2_t (&v)[9]) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int piece = (lane + 64 * k) % 18;
@@ -506,14 +508,21 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
 #pragma unroll
             for (int q = 0; q < 18; ++q) acc[q] = 0;
             const int t = lane >> 1, half = lane & 1;
-            // software pipeline: the 9 record pieces of chunk ch+1 are in flight while chunk ch is multiplied
+            // software pipeline, two deep: while chunk ch is multiplied the record pieces of chunk ch+1 and the item indices of
+            // chunk ch+2 are in flight, so neither of the two dependent L2 round trips of a chunk is on the critical path
             const int ch_begin = seg_start[seg], ch_end = seg_start[seg + 1];
             d2_t cur[9], nxt[9];
-            schur_fetch(chunk_items, Yp, Hplp, ch_begin, lane, cur);
+            i2_t idx[9];
+            schur_fetch_items(chunk_items, ch_begin, lane, idx);
+            schur_fetch_records(Yp, Hplp, lane, idx, cur);
+            if (ch_begin + 1 < ch_end) schur_fetch_items(chunk_items, ch_begin + 1, lane, idx);
             for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) reinterpret_cast<MS_LDS d2_t *>(stage)[lane + 64 * k] = cur[k];
-                if (ch + 1 < ch_end) schur_fetch(chunk_items, Yp, Hplp, ch + 1, lane, nxt);
+                if (ch + 1 < ch_end) {
+                    schur_fetch_records(Yp, Hplp, lane, idx, nxt);
+                    if (ch + 2 < ch_end) schur_fetch_items(chunk_items, ch + 2, lane, idx);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const MS_LDS double *rec = stage + t * 36;
