@@ -161,3 +161,29 @@ def test_min_distance_suppression(oracle, ctx):
             if md >= 2 and len(x) > 1:
                 d2 = (x[:, None] - x[None, :]) ** 2 + (y[:, None] - y[None, :]) ** 2 + np.eye(len(x), dtype=np.int64) * 10**9
                 assert d2.min() >= md * md, (l, md)
+
+
+def test_tile_edge_geometries(oracle, ctx):
+    """Widths / heights around the 248 x 14 detector tiles, the 248 x 32 blur tiles and the 4-row resize groups, on noise
+    (corners everywhere, including the last valid columns where the ring falls back to byte loads)."""
+    rng = np.random.default_rng(31)
+    for (w, h) in [(248, 56), (249, 57), (252, 49), (496, 70), (497, 71), (500, 50), (744, 53), (745, 85), (1000, 59)]:
+        img = rng.integers(0, 256, (1, h, w), dtype=np.uint8)
+        img[0, :, : w // 2] = (img[0, :, : w // 2] // 64) * 64                      # flat patches with sharp steps on one half
+        _, got, want = _extract_both(oracle, ctx, img, levels=2, scale_factor=1.2, fast_threshold=12, max_kpts=3000)
+        _assert_same_keypoints(got[0], want[0])
+
+
+def test_full_hd_frame_and_batch_larger_than_one_launch_slot(oracle, ctx):
+    """1920 x 1080 (more tiles per level than 720p) and a batch that reuses an extractor across calls of different size."""
+    import mi355slam
+    img = oracle.synth_frame(1920, 1080, 77)
+    _, got, want = _extract_both(oracle, ctx, img[None], max_kpts=3000)
+    _assert_same_keypoints(got[0], want[0])
+    frames = np.stack([oracle.synth_frame(320, 240, 400 + i, 2 * i, i) for i in range(5)])
+    ocfg, _ = _cfg(oracle, levels=4, max_kpts=500)
+    ex = mi355slam.OrbExtractor(ctx, 320, 240, levels=4, max_kpts=500, max_batch=5)
+    for n in (5, 2, 1, 4):                                                          # shrinking and growing the batch on one extractor
+        ex.extract(frames[:n])
+        for f in range(n):
+            _assert_same_keypoints(ex.download(f), oracle.orb_extract(ocfg, frames[f]))
