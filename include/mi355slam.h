@@ -286,6 +286,11 @@ int ms_ba_create(ms_ctx *ctx, const ms_ba_problem *problems, int n, ms_ba **out)
 void ms_ba_destroy(ms_ba *ba);
 /* Run the full LM schedule of every problem from its initial estimates, one workgroup per problem,
  * entirely on the device; asynchronous on the context stream, repeatable. */
+/* Workgroups (CUs) that share ONE problem in the next ms_ba_solve: 0 = automatic (by problem size, and only while
+ * problems x workgroups fits the chip: a batch of >= #CUs problems always runs one workgroup per problem), 1 = the whole
+ * Levenberg-Marquardt loop in one workgroup, up to 64.  Results agree to rounding (sums are combined in a fixed order per
+ * team size; the reference's own order is unspecified).  A single local-BA window is ~4x faster with a team. */
+int ms_ba_set_team(ms_ba *ba, int workgroups_per_problem);
 int ms_ba_solve(ms_ba *ba);
 /* Results of problem i (synchronises): poses [n_pose*7], points [n_point*3], per-observation chi2
  * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL. */

@@ -35,10 +35,12 @@ constexpr int NW = NT / 64;      // waves
 constexpr int NB = 16;           // Cholesky panel width
 constexpr int CH = 32;           // Schur work items (pairs of observations of one point) per chunk
 constexpr int kMaxFreePoses = 176;   // Cholesky panel (6*176+1) x 16 doubles + solution vector must fit the LDS budget
+constexpr int kMaxTeam = 64;         // workgroups that may share one problem
 constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
 
 struct BaProb {
-    int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters, pad_;
+    int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters;
+    int32_t team;                            // workgroups that share this problem (1 = the whole solve in one workgroup)
     double huber;
     // state
     double *pose, *pose_bk, *point, *point_bk;
@@ -60,6 +62,10 @@ struct BaProb {
     // work
     double *Hpp, *S, *bp, *dp, *y, *Hll, *bl, *Hinv, *Hpl, *dl, *chi2_obs, *Y;
     const double *zrow;                      // n6 + 16 zeros
+    // team state (team > 1): arrival counter (monotonic, one 128-B line), per-workgroup partial sums [2][team][2], solve status
+    uint32_t *bar;
+    double *red;
+    int32_t *flag;
     // results
     double *stats;                           // [16]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -, then cycles per phase:
                                              //       8 eval, 9 linearise, 10 Schur, 11 Cholesky+backsub, 12 points+update, 13 total
@@ -273,13 +279,69 @@ __device__ double block_max(double v, double *s_red) {
     return t;
 }
 
+
+// ---------------------------------------------------------------- a team of workgroups on one problem
+// With team > 1 the phases below stride over all threads / waves of the team and every hand-off between phases is a barrier
+// across the team's workgroups.  Visibility follows the one recipe that is valid across XCDs (per-XCD L2s are not coherent):
+// every wave drains its stores (vmcnt 0) -> workgroup barrier -> one lane: agent-scope RELEASE fence (L2 write-back) ->
+// vmcnt 0 -> relaxed agent atomic on the arrival counter; then that lane polls the counter (relaxed, agent scope), issues ONE
+// agent-scope ACQUIRE fence (L1 invalidate), waits for it, and the workgroup barrier releases the other waves.  The counter only
+// grows (barrier k completes at k * team arrivals), so there is no reset to race with.  All workgroups of a team must be resident:
+// the host launches cooperatively and keeps problems * team <= CUs.  A poll that never completes gives up after ~1 s and marks
+// the problem failed instead of hanging the GPU.
+#define BA_IDS                                                                                                   \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                               \
+    const int T_ = P.team, rank_ = T_ > 1 ? (int)(blockIdx.x % (unsigned)T_) : 0;                                \
+    const int gt = rank_ * NT + tid, GT = T_ * NT, gw = rank_ * NW + wave, GW = T_ * NW;                         \
+    (void)lane; (void)wave; (void)gt; (void)GT; (void)gw; (void)GW;
+
+__device__ __noinline__ void team_sync(const BaProb &P) {
+    if (P.team == 1) { __syncthreads(); return; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t T = (uint32_t)P.team;
+        const uint32_t a = __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = (a / T + 1u) * T;
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(P.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            // give up after ~1 s (or as soon as another workgroup has): every later barrier then falls through at once
+            if (++spins > (1 << 20) || __hip_atomic_load(P.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(P.flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// Sum / maximum over the team, the same value (bit for bit) in every workgroup: partials are combined in rank order.
+// `which` alternates per call site sequence so a fast workgroup cannot overwrite partials a slow one still reads.
+__device__ __noinline__ double team_reduce(const BaProb &P, double v, double *s_red, bool is_max, int &seq) {
+    const double b = is_max ? block_max(v, s_red) : block_sum(v, s_red);
+    if (P.team == 1) return b;
+    const int T = P.team, rank = (int)(blockIdx.x % (unsigned)T);
+    double *slot = P.red + (size_t)(seq & 1) * T;
+    ++seq;
+    if (threadIdx.x == 0) slot[rank] = b;
+    team_sync(P);
+    double t = slot[0];
+    for (int r = 1; r < T; ++r) t = is_max ? fmax(t, slot[r]) : t + slot[r];
+    return t;
+}
+
 // robust chi2 of the current state (activeRobustChi2); optionally stores the plain chi2 per observation
-__device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool store) {
+__device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool store, int &seq) {
     const BaProb &P = P_;
     double *s_red = s_red_;
-    const int tid = threadIdx.x;
+    BA_IDS
     double acc = 0;
-    for (int o = tid; o < P.n_obs; o += NT) {
+    for (int o = gt; o < P.n_obs; o += GT) {
         double e[2];
         proj_edge<false>(P.pose + 7 * (size_t)P.obs_pose[o], P.point + 3 * (size_t)P.obs_point[o], P.obs_uv + 2 * (size_t)o, e, nullptr, nullptr);
         const double chi2 = P.obs_info[o] * (e[0] * e[0] + e[1] * e[1]);
@@ -288,24 +350,25 @@ __device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool 
         if (store) P.chi2_obs[o] = chi2;
         acc += r;
     }
-    for (int k = tid; k < P.n_edge; k += NT) {
+    for (int k = gt; k < P.n_edge; k += GT) {
         double e[6];
         pose_edge(P.pose + 7 * (size_t)P.edge_i[k], P.pose + 7 * (size_t)P.edge_j[k], P.edge_meas + 7 * (size_t)k, e, nullptr, nullptr, false);
         const double *W = P.edge_info + 36 * (size_t)k;
         for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) acc += e[i] * W[6 * i + j] * e[j];
     }
-    return block_sum(acc, s_red);
+    return team_reduce(P, acc, s_red, false, seq);
 }
 
 // ---------------------------------------------------------------- linearisation
 __device__ __noinline__ void build_system(const BaProb &P_) {
     const BaProb &P = P_;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n6 = P.n6;
-    for (size_t i = tid; i < (size_t)n6 * n6; i += NT) P.Hpp[i] = 0;
-    for (int i = tid; i < n6; i += NT) P.bp[i] = 0;
-    __syncthreads();
+    BA_IDS
+    const int n6 = P.n6;
+    for (size_t i = gt; i < (size_t)n6 * n6; i += GT) P.Hpp[i] = 0;
+    for (int i = gt; i < n6; i += GT) P.bp[i] = 0;
+    team_sync(P);
     // per point: Hll, bl, Hpl
-    for (int l = tid; l < P.n_point; l += NT) {
+    for (int l = gt; l < P.n_point; l += GT) {
         const bool lfree = !(P.point_fixed && P.point_fixed[l]);
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const double X[3] = {P.point[3 * (size_t)l], P.point[3 * (size_t)l + 1], P.point[3 * (size_t)l + 2]};
@@ -337,7 +400,7 @@ __device__ __noinline__ void build_system(const BaProb &P_) {
         for (int a = 0; a < 3; ++a) P.bl[3 * (size_t)l + a] = b[a];
     }
     // per free pose: Hpp diagonal block + bp (one wave per pose, lanes over its observations)
-    for (int fp = wave; fp < P.np_free; fp += NW) {
+    for (int fp = gw; fp < P.np_free; fp += GW) {
         const int pi = P.free2pose[fp];
         double pose[7];
 #pragma unroll
@@ -375,10 +438,10 @@ __device__ __noinline__ void build_system(const BaProb &P_) {
             }
         }
     }
-    __syncthreads();
+    team_sync(P);
     // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior): one thread per edge, contributions
     // added with fp64 atomics (a handful of edges; neighbouring edges share a pose block)
-    for (int k = tid; k < P.n_edge; k += NT) {
+    for (int k = gt; k < P.n_edge; k += GT) {
         const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
         if (fi < 0 && fj < 0) continue;
         double e[6], Ji[36], Jj[36], We[6];
@@ -404,7 +467,7 @@ __device__ __noinline__ void build_system(const BaProb &P_) {
             }
         }
     }
-    __syncthreads();
+    team_sync(P);
 }
 
 // The (observation a, observation b) pairs of a chunk, one per record piece this lane moves (9 pieces per lane) ...
@@ -428,28 +491,28 @@ __device__ __forceinline__ void schur_fetch_records(const MS_GLOBAL double *Y, c
 // The damped solve, phase by phase.  The phases are compiled out of line (noinline): each gets its own register
 // allocation, so the staging registers of the Schur loop are not spilled because another phase needs many registers
 // (measured: 67.4 -> 65.7 Mcycles per C4 solve; fully inlined without the register prefetch: 112 Mcycles).
-__device__ __noinline__ void schur_prepare(const BaProb &P_, double lambda, int *s_flag_) {
+__device__ __noinline__ void schur_prepare(const BaProb &P_, double lambda) {
     const BaProb &P = P_;
-    int *s_flag = s_flag_;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6;
-    (void)lane; (void)wave; (void)n;
+    BA_IDS
+    const int n = P.n6;
+    (void)n;
     // (Hll + lambda I)^-1, closed form
-    for (int l = tid; l < P.n_point; l += NT) {
+    for (int l = gt; l < P.n_point; l += GT) {
         if (P.point_fixed && P.point_fixed[l]) continue;
         double H[6];
         load6(P.Hll + 6 * (size_t)l, H);
         const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e = H[4], f = H[5] + lambda;
         const double A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
         const double det = a * A + b * B + c * C;
-        if (!(fabs(det) > 0) || !isfinite(det)) *s_flag = 0;
+        if (!(fabs(det) > 0) || !isfinite(det)) P.flag[0] = 0;
         const double id = 1.0 / det;
         const double Hi[6] = {A * id, B * id, C * id, (a * f - c * c) * id, (b * c - a * e) * id, (a * d - b * b) * id};
         store6(P.Hinv + 6 * (size_t)l, Hi);
     }
-    __syncthreads();
+    team_sync(P);
     // Schur complement S = Hpp + lambda I - sum_l Hpl (Hll + lambda I)^-1 Hpl^T (lower block triangle), rhs y = bp - sum Y bl.
     // Deterministic and atomic-free: every (pose pair) block is the ordered sum of per-chunk partial blocks.
-    for (int o = tid; o < P.n_obs; o += NT) {                         // Y_o = Hpl_o * Hinv_l
+    for (int o = gt; o < P.n_obs; o += GT) {                         // Y_o = Hpl_o * Hinv_l
         const int l = P.obs_point[o];
         if (P.pidx[P.obs_pose[o]] < 0 || (P.point_fixed && P.point_fixed[l])) continue;
         double W[18], h[6], Yo[18];
@@ -466,13 +529,13 @@ __device__ __noinline__ void schur_prepare(const BaProb &P_, double lambda, int 
         const double *__restrict__ Hp = P.Hpp;
         double *__restrict__ Sp0 = P.S;
         const int strips = (n + 63) / 64;
-        for (int w = tid >> 6; w < n * strips; w += NW) {
+        for (int w = gw; w < n * strips; w += GW) {
             const int r = w / strips, c = (w - r * strips) * 64 + (tid & 63);
             if (c < n && c / 6 <= r / 6) Sp0[(size_t)r * n + c] = Hp[(size_t)r * n + c] + (c == r ? lambda : 0.0);
         }
     }
-    __syncthreads();
-    for (int fp = wave; fp < P.np_free; fp += NW) {                   // rhs: fixed-order wave reduction per pose
+    team_sync(P);
+    for (int fp = gw; fp < P.np_free; fp += GW) {                   // rhs: fixed-order wave reduction per pose
         double gsum[6] = {0, 0, 0, 0, 0, 0};
         for (int ii = P.fstart[fp] + lane; ii < P.fstart[fp + 1]; ii += 64) {
             const int o = P.fobs[ii], l = P.obs_point[o];
@@ -487,14 +550,15 @@ __device__ __noinline__ void schur_prepare(const BaProb &P_, double lambda, int 
         for (int r = 0; r < 6; ++r) gsum[r] = wave_sum_d(gsum[r]);
         if (lane < 6) P.y[6 * fp + lane] = P.bp[6 * fp + lane] - gsum[lane];
     }
-    __syncthreads();
+    team_sync(P);
 }
 
 __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     double *lds = lds_;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6;
-    (void)lane; (void)wave; (void)n;
+    BA_IDS
+    const int n = P.n6;
+    (void)n;
     // One wave per pose-pair segment.  Per chunk of 32 items the wave stages the 32 Y_a and 32 Hpl_b records
     // (144 B each) into its private LDS slab with coalesced 16-byte pieces (9 lanes per record), then lane
     // (t = lane/2, half = lane%2) multiplies item t's record pair into 18 of the 36 block entries and keeps the
@@ -506,7 +570,7 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
         const MS_GLOBAL double *Yp = (const MS_GLOBAL double *)P.Y, *Hplp = (const MS_GLOBAL double *)P.Hpl;
         MS_GLOBAL double *Sp = (MS_GLOBAL double *)P.S;
         const int n_seg = P.n_seg;
-        for (int seg = wave; seg < n_seg; seg += NW) {
+        for (int seg = gw; seg < n_seg; seg += GW) {
             double acc[18];
 #pragma unroll
             for (int q = 0; q < 18; ++q) acc[q] = 0;
@@ -557,13 +621,12 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
             }
         }
     }
-    __syncthreads();
+    team_sync(P);
 }
 
-__device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_, int *s_flag_) {
+__device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     double *lds = lds_;
-    int *s_flag = s_flag_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6;
     (void)lane; (void)wave; (void)n;
     // blocked left-looking Cholesky of S (lower), rhs y carried as row n
@@ -646,7 +709,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_, int 
                 }
 #pragma unroll
                 for (int c = 0; c < NB; ++c) if (lane < nb && c < nb) pan[lane * NB + c] = r[c];
-                if (!ok && lane == 0) *s_flag = 0;
+                if (!ok && lane == 0) P.flag[0] = 0;
             }
             __syncthreads();
             for (int i = nb + tid; i < m; i += NT) {     // rows below: x L11^T = a
@@ -705,10 +768,9 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_, int 
 
 __device__ __noinline__ void point_backsub(const BaProb &P_) {
     const BaProb &P = P_;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6;
-    (void)lane; (void)wave; (void)n;
+    BA_IDS
     // point back-substitution: dl = Hinv (bl - sum_a Hpl_a^T dp_a)
-    for (int l = tid; l < P.n_point; l += NT) {
+    for (int l = gt; l < P.n_point; l += GT) {
         double *d = P.dl + 3 * (size_t)l;
         if (P.point_fixed && P.point_fixed[l]) { d[0] = d[1] = d[2] = 0; continue; }
         double r[3] = {P.bl[3 * (size_t)l], P.bl[3 * (size_t)l + 1], P.bl[3 * (size_t)l + 2]};
@@ -729,85 +791,88 @@ __device__ __noinline__ void point_backsub(const BaProb &P_) {
         d[1] = h[1] * r[0] + h[3] * r[1] + h[4] * r[2];
         d[2] = h[2] * r[0] + h[4] * r[1] + h[5] * r[2];
     }
-    __syncthreads();
+    team_sync(P);
 }
 
 // Returns false (uniformly) when a pivot is not positive / a point block is singular.
-__device__ bool solve_step(const BaProb &P, double lambda, double *lds, int *s_flag, long long *cyc) {
+__device__ bool solve_step(const BaProb &P, double lambda, double *lds, long long *cyc) {
     long long t0 = clock64();
-    if (threadIdx.x == 0) *s_flag = 1;
-    __syncthreads();
-    schur_prepare(P, lambda, s_flag);
+    const bool lead = P.team == 1 || blockIdx.x % (unsigned)P.team == 0;
+    if (lead && threadIdx.x == 0) P.flag[0] = 1;
+    team_sync(P);
+    schur_prepare(P, lambda);
     { const long long t1 = clock64(); cyc[6] += t1 - t0; }
     schur_segments(P, lds);
     { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
-    cholesky_solve(P, lds, s_flag);
+    if (lead) cholesky_solve(P, lds);                  // the dense 6 np x 6 np factorisation stays in one workgroup (panel in LDS)
+    team_sync(P);
     { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
-    const bool ok = *s_flag != 0;
-    __syncthreads();
+    const bool ok = P.flag[0] != 0;
     if (!ok) return false;
     point_backsub(P);
     cyc[4] += clock64() - t0;
     return true;
 }
 
-__global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
+// grid = problems x team workgroups; workgroup b works on problem b / team
+__global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s_red[NW];
-    __shared__ int s_flag;
-    __shared__ double s_ctl[4];
-    const BaProb &P = probs[blockIdx.x];      // fields stay in constant memory: uniform scalar loads, no private copy
-    const int tid = threadIdx.x, n6 = P.n6;
+    const BaProb &P = probs[blockIdx.x / (unsigned)team];      // fields stay in constant memory: uniform scalar loads, no private copy
+    BA_IDS
+    const int n6 = P.n6;
+    int seq = 0;                                               // team_reduce call counter (same in every workgroup)
     // restart from the initial estimates
-    for (int i = tid; i < 7 * P.n_pose; i += NT) P.pose[i] = P.pose0[i];
-    for (int i = tid; i < 3 * P.n_point; i += NT) P.point[i] = P.point0[i];
-    __syncthreads();
+    for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose0[i];
+    for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] = P.point0[i];
+    team_sync(P);
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, stop = 0;
     long long cyc[7] = {0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
-    const double chi2_init = eval_chi2(P, s_red, false);
+    const double chi2_init = eval_chi2(P, s_red, false, seq);
     for (it = 0; it < P.max_iters; ++it) {
         long long tt = clock64();
-        double current = eval_chi2(P, s_red, false), temp = current;
+        double current = eval_chi2(P, s_red, false, seq), temp = current;
         { const long long t1 = clock64(); cyc[0] += t1 - tt; tt = t1; }
         build_system(P);
         cyc[1] += clock64() - tt;
         if (it == 0) {                                   // computeLambdaInit
             double md = 0;
-            for (int i = tid; i < n6; i += NT) md = fmax(md, fabs(P.Hpp[(size_t)i * n6 + i]));
-            for (int l = tid; l < P.n_point; l += NT)
+            for (int i = gt; i < n6; i += GT) md = fmax(md, fabs(P.Hpp[(size_t)i * n6 + i]));
+            for (int l = gt; l < P.n_point; l += GT)
                 if (!(P.point_fixed && P.point_fixed[l])) { const double *h = P.Hll + 6 * (size_t)l; md = fmax(md, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])))); }
-            lambda = 1e-5 * block_max(md, s_red); ni = 2;
+            lambda = 1e-5 * team_reduce(P, md, s_red, true, seq); ni = 2;
         }
         double rho = 0;
         int qmax = 0;
         do {
-            for (int i = tid; i < 7 * P.n_pose; i += NT) P.pose_bk[i] = P.pose[i];          // push()
-            for (int i = tid; i < 3 * P.n_point; i += NT) P.point_bk[i] = P.point[i];
-            __syncthreads();
-            const bool ok2 = solve_step(P, lambda, lds, &s_flag, cyc);
+            // push(): element i is saved and (on rejection) restored by the same thread, and every phase that changes the state
+            // sits behind later barriers, so the copy itself needs none
+            for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose_bk[i] = P.pose[i];
+            for (int i = gt; i < 3 * P.n_point; i += GT) P.point_bk[i] = P.point[i];
+            const bool ok2 = solve_step(P, lambda, lds, cyc);
             tt = clock64();
             if (ok2) {
-                for (int fp = tid; fp < P.np_free; fp += NT) {
+                for (int fp = gt; fp < P.np_free; fp += GT) {
                     const int pi = P.free2pose[fp];
                     double ex[7], r[7];
                     se3_exp(P.dp + 6 * fp, ex);
                     se3_mul(ex, P.pose + 7 * (size_t)pi, r);
                     for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = r[a];
                 }
-                for (int i = tid; i < 3 * P.n_point; i += NT) P.point[i] += P.dl[i];
-                __syncthreads();
+                for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] += P.dl[i];
+                team_sync(P);
             }
             cyc[4] += clock64() - tt; tt = clock64();
-            temp = ok2 ? eval_chi2(P, s_red, false) : DBL_MAX;
+            temp = ok2 ? eval_chi2(P, s_red, false, seq) : DBL_MAX;
             cyc[0] += clock64() - tt;
             double sc = 0;
             if (ok2) {
-                for (int i = tid; i < n6; i += NT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
-                for (int i = tid; i < 3 * P.n_point; i += NT) sc += P.dl[i] * (lambda * P.dl[i] + P.bl[i]);
+                for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
+                for (int i = gt; i < 3 * P.n_point; i += GT) sc += P.dl[i] * (lambda * P.dl[i] + P.bl[i]);
             }
-            const double scale = block_sum(sc, s_red) + 1e-3;
+            const double scale = team_reduce(P, sc, s_red, false, seq) + 1e-3;
             rho = (current - temp) / scale;
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
@@ -816,23 +881,23 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs) {
                 ni = 2; current = temp;
             } else {
                 lambda *= ni; ni *= 2;
-                for (int i = tid; i < 7 * P.n_pose; i += NT) P.pose[i] = P.pose_bk[i];      // pop()
-                for (int i = tid; i < 3 * P.n_point; i += NT) P.point[i] = P.point_bk[i];
-                __syncthreads();
+                for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose_bk[i];      // pop()
+                for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] = P.point_bk[i];
+                team_sync(P);
                 if (!isfinite(lambda)) break;
             }
             ++qmax; ++trials;
         } while (rho < 0 && qmax < 10);
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) { stop = 1; ++it; break; }
     }
-    const double chi2_final = eval_chi2(P, s_red, true);
-    if (tid == 0) {
-        P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = chi2_final;
-        P.stats[6] = isfinite(chi2_final) ? 1 : 0; P.stats[7] = 0;
+    const double chi2_final = eval_chi2(P, s_red, true, seq);
+    if (gt == 0) {
+        const bool hung = P.team > 1 && P.flag[1] != 0;        // a team barrier gave up: the result is not to be trusted
+        P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
+        P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = 0;
         for (int k = 0; k < 5; ++k) P.stats[8 + k] = (double)cyc[k];
         P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5]; P.stats[15] = (double)cyc[6];
     }
-    (void)s_ctl;
 }
 
 }  // namespace
@@ -848,6 +913,8 @@ struct ms_ba {
     BaProb *d_probs = nullptr;
     char *d_arena = nullptr;
     size_t arena_bytes = 0;
+    int team = 0;                      // workgroups per problem of the next launch (ms_ba_set_team; 0 = automatic)
+    int cus = 0;
 };
 
 extern "C" {
@@ -862,7 +929,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -947,6 +1014,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.Hll = bump(6 * Q.n_point * D); O.bl = bump(3 * Q.n_point * D); O.Hinv = bump(6 * Q.n_point * D); O.Hpl = bump(18 * ((size_t)Q.n_obs + 1) * D);
         O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(16 * D);
         O.Y = bump(18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
+        O.bar = bump(256); O.red = bump(2 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
     }
     ms_ba *B = new ms_ba();
     B->ctx = c; B->n = n; B->arena_bytes = total;
@@ -987,6 +1055,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.chi2_obs = PTR(double, chi2); H.stats = PTR(double, stats);
         H.n_chunks = R.n_chunks; H.n_seg = R.n_seg; H.chunk_items = PTR(int32_t, chunk_items); H.seg_start = PTR(int32_t, seg_start); H.seg_pair = PTR(int32_t, seg_pair);
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
+        H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1;
 #undef PTR
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1007,11 +1076,35 @@ void ms_ba_destroy(ms_ba *B) {
     delete B;
 }
 
+int ms_ba_set_team(ms_ba *B, int workgroups_per_problem) {
+    if (!B || workgroups_per_problem < 0 || workgroups_per_problem > kMaxTeam) return MS_ERR_INVALID;
+    B->team = workgroups_per_problem;
+    return MS_OK;
+}
+
 int ms_ba_solve(ms_ba *B) {
     if (!B) return MS_ERR_INVALID;
     ms_ctx *c = B->ctx;
     MS_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs);
+    if (!B->cus) { hipDeviceProp_t pr; MS_HIP(c, hipGetDeviceProperties(&pr, c->device)); B->cus = pr.multiProcessorCount; }
+    // A workgroup takes more than half a CU's LDS, so one per CU: a team is only possible while problems x team fits the chip
+    // (all its workgroups must be resident for the barriers), hence the cooperative launch below.  Automatic choice: as many
+    // workgroups per problem as fit, at most 32 (beyond that the single-workgroup Cholesky dominates).
+    int most_obs = 0;
+    for (const auto &h : B->host) most_obs = std::max(most_obs, h.n_obs);
+    int team = B->team == 0 ? std::min(32, std::max(1, most_obs / 1024)) : B->team;      // small problems are latency-bound on the barriers
+    team = std::max(1, std::min(team, B->cus / std::max(B->n, 1)));
+    if (team != B->host[0].team) {
+        for (auto &h : B->host) h.team = team;
+        MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
+    }
+    if (team == 1) {
+        hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
+    } else {
+        const BaProb *probs = B->d_probs;
+        void *args[] = {(void *)&probs, (void *)&team};
+        MS_HIP(c, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_ba_lm), dim3(B->n * team), dim3(NT), args, (unsigned)kLdsBytes, c->stream));
+    }
     MS_KERNEL_CHECK(c, "k_ba_lm");
     return MS_OK;
 }

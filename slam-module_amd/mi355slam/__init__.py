@@ -469,6 +469,9 @@ class BundleAdjuster:
         ctx.check(lib().ms_ba_create(ctx._h, arr, self.n, C.byref(self._h)), "ms_ba_create")
         ctx._children.append(weakref.ref(self))
 
+    def set_team(self, workgroups_per_problem):
+        self.ctx.check(lib().ms_ba_set_team(self._h, int(workgroups_per_problem)), "ms_ba_set_team")
+
     def solve(self):
         self.ctx.check(lib().ms_ba_solve(self._h), "ms_ba_solve")
 
