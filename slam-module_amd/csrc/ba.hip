@@ -360,7 +360,7 @@ __device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool 
 }
 
 // ---------------------------------------------------------------- linearisation
-__device__ __noinline__ void build_system(const BaProb &P_) {
+__device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     BA_IDS
     const int n6 = P.n6;
@@ -439,32 +439,48 @@ __device__ __noinline__ void build_system(const BaProb &P_) {
         }
     }
     team_sync(P);
-    // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior): one thread per edge, contributions
-    // added with fp64 atomics (a handful of edges; neighbouring edges share a pose block)
-    for (int k = gt; k < P.n_edge; k += GT) {
-        const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
-        if (fi < 0 && fj < 0) continue;
-        double e[6], Ji[36], Jj[36], We[6];
-        pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
-        const double *W = P.edge_info + 36 * (size_t)k;
-        for (int a = 0; a < 6; ++a) { double v = 0; for (int b = 0; b < 6; ++b) v += W[6 * a + b] * e[b]; We[a] = -v; }
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            const int fs = sidx ? fj : fi;
-            if (fs < 0) continue;
-            const double *Js = sidx ? Jj : Ji;
-            for (int a = 0; a < 6; ++a) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + a] * We[r2]; atomicAdd(&P.bp[6 * fs + a], v); }
-            for (int tidx = 0; tidx < 2; ++tidx) {
-                const int ft = tidx ? fj : fi;
-                if (ft < 0) continue;
-                const double *Jt = tidx ? Jj : Ji;
-                double M[36];                                   // W * Jt
-                for (int r2 = 0; r2 < 6; ++r2) for (int b = 0; b < 6; ++b) { double v = 0; for (int c2 = 0; c2 < 6; ++c2) v += W[6 * r2 + c2] * Jt[6 * c2 + b]; M[6 * r2 + b] = v; }
-                for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
-                    double v = 0;
-                    for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + a] * M[6 * r2 + b];
-                    atomicAdd(&P.Hpp[(size_t)(6 * fs + a) * n6 + 6 * ft + b], v);
+    // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior): one WAVE per edge.  Every lane evaluates the edge
+    // (error, both 6x6 Jacobians), the wave parks them and the information matrix in its LDS slab, and lane (a, b) < 36 forms
+    // entry (a, b) of each of the up to four 6x6 blocks Js^T (W Jt) with the same operation order as a scalar loop would;
+    // contributions are added with fp64 atomics (neighbouring edges share a pose block).  One thread per edge ran ~2000
+    // dependent multiply-adds out of scratch memory: 168 k cycles per linearisation, whatever the team size.
+    {
+        MS_LDS double *slab = (MS_LDS double *)lds_ + (size_t)wave * (CH * 36);      // [Ji 36][Jj 36][W 36][We 6]
+        for (int k = gw; k < P.n_edge; k += GW) {
+            const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
+            if (fi < 0 && fj < 0) continue;                                       // wave-uniform
+            double e[6], Ji[36], Jj[36];
+            pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+            const double *W = P.edge_info + 36 * (size_t)k;
+            if (lane < 36) { slab[lane] = Ji[lane]; slab[36 + lane] = Jj[lane]; slab[72 + lane] = W[lane]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 6) { double v = 0; for (int b2 = 0; b2 < 6; ++b2) v += slab[72 + 6 * lane + b2] * e[b2]; slab[108 + lane] = -v; }      // We = -W e
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int a2 = lane / 6, b3 = lane - 6 * a2;
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const int fs = sidx ? fj : fi;
+                if (fs < 0) continue;
+                const MS_LDS double *Js = slab + 36 * sidx;
+                if (lane < 6) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + lane] * slab[108 + r2]; atomicAdd(&P.bp[6 * fs + lane], v); }
+                for (int tidx = 0; tidx < 2; ++tidx) {
+                    const int ft = tidx ? fj : fi;
+                    if (ft < 0) continue;
+                    const MS_LDS double *Jt = slab + 36 * tidx;
+                    if (lane < 36) {
+                        double v = 0;
+                        for (int r2 = 0; r2 < 6; ++r2) {
+                            double m = 0;                                         // (W Jt)[r2][b3]
+                            for (int c2 = 0; c2 < 6; ++c2) m += slab[72 + 6 * r2 + c2] * Jt[6 * c2 + b3];
+                            v += Js[6 * r2 + a2] * m;
+                        }
+                        atomicAdd(&P.Hpp[(size_t)(6 * fs + a2) * n6 + 6 * ft + b3], v);
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     team_sync(P);
@@ -835,7 +851,7 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
         long long tt = clock64();
         double current = eval_chi2(P, s_red, false, seq), temp = current;
         { const long long t1 = clock64(); cyc[0] += t1 - tt; tt = t1; }
-        build_system(P);
+        build_system(P, lds);
         cyc[1] += clock64() - tt;
         if (it == 0) {                                   // computeLambdaInit
             double md = 0;
