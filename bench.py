@@ -207,14 +207,20 @@ def bench_ba(ctx, args, world, rank, dist, torch):
     solves_total, dt = shard.aggregate(dist, torch, args.ba_batch * args.ba_steps, dt, device="cuda")
     st = ba.download(0)["stats"]
     # single-window latency (one workgroup on one CU)
+    # latency of ONE window (what a sequential SLAM pipeline sees): a team of workgroups shares the problem (automatic size);
+    # one_cu = the same solve confined to a single workgroup, as every window of the 256-window launch above runs
     one = mi355slam.BundleAdjuster(ctx, probs[:1], max_iters=10)
     one.solve(); ctx.sync()
     ctx.event_mark(4); one.solve(); ctx.event_mark(5)
     single_ms = ctx.event_elapsed_ms(4, 5)
+    one.set_team(1); one.solve(); ctx.sync()
+    ctx.event_mark(4); one.solve(); ctx.event_mark(5)
+    single_one_cu_ms = ctx.event_elapsed_ms(4, 5)
     alg_bytes_per_solve = 6.61e6 * st["iters"]               # 6.61 MB per LM iteration at C4
     res = {"metric": "local-BA solves/sec (50 KF x 2000 pts x 20k obs, 10 LM iters)", "value": round(solves_total / dt, 1),
            "unit": "solves/s", "windows_per_launch": args.ba_batch, "ms_per_launch": round(kernel_ms, 3), "lm_iterations": st["iters"],
            "lm_trials": st["trials"], "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
+           "single_window_one_cu_ms": round(single_one_cu_ms, 3),
            "alg_GBs": round(alg_bytes_per_solve * args.ba_batch / (kernel_ms * 1e-3) / 1e9, 1), "dtype": "f64"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

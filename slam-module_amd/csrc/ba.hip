@@ -1108,7 +1108,7 @@ int ms_ba_solve(ms_ba *B) {
     // workgroups per problem as fit, at most 32 (beyond that the single-workgroup Cholesky dominates).
     int most_obs = 0;
     for (const auto &h : B->host) most_obs = std::max(most_obs, h.n_obs);
-    int team = B->team == 0 ? std::min(32, std::max(1, most_obs / 1024)) : B->team;      // small problems are latency-bound on the barriers
+    int team = B->team == 0 ? std::min(32, std::max(1, most_obs / 512)) : B->team;      // small problems are latency-bound on the barriers
     team = std::max(1, std::min(team, B->cus / std::max(B->n, 1)));
     if (team != B->host[0].team) {
         for (auto &h : B->host) h.team = team;

@@ -104,3 +104,28 @@ def test_global_ba_sized_window(oracle, ctx):
     p = ba_synth.make_problem(150, 1500, 12, seed=77, fix_first=True)
     ba = mi355slam.BundleAdjuster(ctx, [p], max_iters=12); ba.solve()
     _check(p, ba.download(0), oracle.ba_solve(p, 12, False))
+
+
+def test_team_of_workgroups_matches_single_workgroup_and_oracle(oracle, ctx):
+    """ms_ba_set_team: one problem spread over 1 .. 32 workgroups (grid barriers, agent-scope release / acquire) gives the
+    oracle's result at every team size -- C4, a pose-only problem, a window with outliers and a batch of 3 with teams of 7."""
+    import mi355slam
+    c4 = ba_synth.make_problem(50, 2000, 10, seed=42)
+    want = oracle.ba_solve(c4, 10, False)
+    for team in (1, 2, 5, 16, 32):
+        ba = mi355slam.BundleAdjuster(ctx, [c4], max_iters=10); ba.set_team(team); ba.solve()
+        _check(c4, ba.download(0), want)
+        ba.solve()                                                   # a second launch on the same (monotonic) barrier counter
+        _check(c4, ba.download(0), want)
+        ba.close()
+    po = dict(c4); po["pose_fixed"] = np.ones(50, np.uint8); po["pose_fixed"][49] = 0; po["point_fixed"] = np.ones(2000, np.uint8)
+    ba = mi355slam.BundleAdjuster(ctx, [po], max_iters=10); ba.set_team(8); ba.solve()
+    _check(po, ba.download(0), oracle.ba_solve(po, 10, False), strict_trajectory=False)
+    ba.close()
+    probs = [ba_synth.make_problem(20, 400, 6, seed=200 + i, outlier_frac=0.05) for i in range(3)]
+    ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=8); ba.set_team(7); ba.solve()
+    for i in range(3):
+        _check(probs[i], ba.download(i), oracle.ba_solve(probs[i], 8, False))
+    with pytest.raises(mi355slam.MsError):
+        ba.set_team(65)
+    ba.close()

@@ -11,11 +11,12 @@ cases["stage 1 (one free pose, points free)"] = p1
 p2 = dict(p1); p2["point_fixed"] = np.ones(2000, np.uint8)
 cases["pose BA (one free pose, points fixed)"] = p2
 for name, p in cases.items():
-    for nb in (1, 256):
+    for nb, team in ((1, 1), (1, 0), (256, 0)):
         ba = mi355slam.BundleAdjuster(ctx, [p] * nb, max_iters=10)
+        ba.set_team(team)
         ba.solve(); ctx.sync()
         ctx.event_mark(0); ba.solve(); ctx.event_mark(1); ms = ctx.event_elapsed_ms(0, 1)
         st = ba.download(0)["stats"]
         pc = st["phase_cycles"]; tot = pc["total"]
-        print("%-40s x%-3d %8.3f ms  iters %d trials %d  %s" % (name, nb, ms, st["iters"], st["trials"], {k: round(v / tot, 2) for k, v in pc.items() if k != "total"}), flush=True)
+        print("%-40s x%-3d team %d %8.3f ms  iters %d trials %d  %s" % (name, nb, team, ms, st["iters"], st["trials"], {k: round(v / tot, 2) for k, v in pc.items() if k != "total"}), flush=True)
         ba.close()
