@@ -62,6 +62,7 @@ struct BaProb {
     // work
     double *Hpp, *S, *bp, *dp, *y, *Hll, *bl, *Hinv, *Hpl, *dl, *chi2_obs, *Y;
     const double *zrow;                      // n6 + 16 zeros
+    double *dinv;                            // [n6] reciprocals of the Cholesky diagonal
     // team state (team > 1): arrival counter (monotonic, one 128-B line), per-workgroup partial sums [2][team][2], solve status
     uint32_t *bar;
     double *red;
@@ -725,6 +726,13 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
                 }
 #pragma unroll
                 for (int c = 0; c < NB; ++c) if (lane < nb && c < nb) pan[lane * NB + c] = r[c];
+                // 1 / L[j][j], once per column: the substitutions below and the back substitution multiply instead of dividing
+                double di = 1.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (lane == c) di = r[c];
+                di = 1.0 / di;
+                if (lane < NB) tvec[lane] = di;
+                if (lane < nb) P.dinv[c0 + lane] = di;
                 if (!ok && lane == 0) P.flag[0] = 0;
             }
             __syncthreads();
@@ -735,7 +743,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
                     if (j < nb) {
                         double s = pan[i * NB + j];
                         for (int k = 0; k < j; ++k) s -= x[k] * pan[j * NB + k];
-                        x[j] = s / pan[j * NB + j];
+                        x[j] = s * tvec[j];
                     }
                 }
 #pragma unroll
@@ -750,30 +758,38 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
             }
             __syncthreads();
         }
-        // back substitution L^T x = y, panels in reverse.  x lives in LDS; the 16x16 triangular solve of a panel is a
-        // wave-level recurrence (lane k owns x_k, one shuffle per step) -- not a serial loop over global memory.
-        double *xs = tvec + NB;                                    // [n]
+        // back substitution L^T x = z (z = the forward-substituted rhs, now in P.y), panels in reverse, in LDS.  Per panel: wave 0
+        // solves the 16x16 triangle as a lane recurrence (lane k owns x_k; one shuffle and one multiply by the stored reciprocal
+        // per step), then every thread k < c0 subtracts the panel's 16 rows from z_k -- rows of L are contiguous in memory, so
+        // these are coalesced, independent loads with no reduction (the column-dot formulation needed a wave sum per column).
+        double *xs = tvec + NB;                                    // [n]: z on entry, x on exit
+        for (int i = tid; i < n; i += NT) xs[i] = P.y[i];
+        __syncthreads();
         const int last = ((n - 1) / NB) * NB;
         for (int c0 = last; c0 >= 0; c0 -= NB) {
-            const int nb = min(NB, n - c0), m = n - c0;            // rows c0..n-1
-            for (int idx = tid; idx < m * NB; idx += NT) { const int i = idx / NB, j = idx - i * NB; pan[idx] = j < nb ? P.S[(size_t)(c0 + i) * n + c0 + j] : 0.0; }
-            __syncthreads();
-            for (int c = wave; c < nb; c += NW) {
-                double sacc = 0;
-                for (int i = nb + lane; i < m; i += 64) sacc += pan[i * NB + c] * xs[c0 + i];
-                sacc = wave_sum_d(sacc);
-                if (lane == 0) tvec[c] = sacc;
-            }
-            __syncthreads();
+            const int nb = min(NB, n - c0);
             if (wave == 0) {
-                double r = (lane < nb) ? P.y[c0 + lane] - tvec[lane] : 0.0;
-                double xk = 0;
-                for (int j = nb - 1; j >= 0; --j) {
-                    const double xj = __shfl(r, j, 64) / pan[j * NB + j];
-                    if (lane == j) xk = xj;
-                    if (lane < j) r -= pan[j * NB + lane] * xj;          // L[c0+j][c0+lane]
+                double col[NB];                                    // lane k: column c0+k of the diagonal block, L[c0+j][c0+k] for j > k
+#pragma unroll
+                for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? P.S[(size_t)(c0 + j) * n + c0 + lane] : 0.0;
+                const double di = lane < nb ? P.dinv[c0 + lane] : 0.0;
+                double r = lane < nb ? xs[c0 + lane] : 0.0, xk = 0;
+#pragma unroll
+                for (int j = NB - 1; j >= 0; --j) {
+                    if (j < nb) {                                  // uniform
+                        const double xj = readlane_d(r, j) * readlane_d(di, j);
+                        if (lane == j) xk = xj;
+                        r -= col[j] * xj;                          // col[j] is zero for lanes >= j
+                    }
                 }
                 if (lane < nb) xs[c0 + lane] = xk;
+            }
+            __syncthreads();
+            for (int k = tid; k < c0; k += NT) {
+                double zk = xs[k];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) if (j < nb) zk -= P.S[(size_t)(c0 + j) * n + k] * xs[c0 + j];
+                xs[k] = zk;
             }
             __syncthreads();
         }
@@ -945,7 +961,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -1030,6 +1046,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.Hll = bump(6 * Q.n_point * D); O.bl = bump(3 * Q.n_point * D); O.Hinv = bump(6 * Q.n_point * D); O.Hpl = bump(18 * ((size_t)Q.n_obs + 1) * D);
         O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(16 * D);
         O.Y = bump(18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
+        O.dinv = bump((n6 + 16) * D);
         O.bar = bump(256); O.red = bump(2 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
     }
     ms_ba *B = new ms_ba();
@@ -1071,6 +1088,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.chi2_obs = PTR(double, chi2); H.stats = PTR(double, stats);
         H.n_chunks = R.n_chunks; H.n_seg = R.n_seg; H.chunk_items = PTR(int32_t, chunk_items); H.seg_start = PTR(int32_t, seg_start); H.seg_pair = PTR(int32_t, seg_pair);
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
+        H.dinv = PTR(double, dinv);
         H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1;
 #undef PTR
     }
