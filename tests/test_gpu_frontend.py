@@ -187,3 +187,22 @@ def test_full_hd_frame_and_batch_larger_than_one_launch_slot(oracle, ctx):
         ex.extract(frames[:n])
         for f in range(n):
             _assert_same_keypoints(ex.download(f), oracle.orb_extract(ocfg, frames[f]))
+
+
+def test_randomised_configurations(oracle, ctx):
+    """Differential fuzz: 40 random (size, levels, scale factor, threshold, quota, image kind) configurations, bit-exact each."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 40:
+        w, h = int(rng.integers(60, 700)), int(rng.integers(60, 420))
+        levels = int(rng.integers(1, 7)); sf = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
+        if min(w, h) / sf ** (levels - 1) < 41: continue                      # every level must hold a 40 x 40 patch area
+        thr = int(rng.integers(5, 60)); kp = int(rng.integers(50, 3000))
+        kind = int(rng.integers(0, 3))
+        if kind == 0: img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1: img = oracle.synth_frame(w, h, int(rng.integers(0, 1000)))
+        else:
+            img = (rng.integers(0, 4, (h // 8 + 1, w // 8 + 1), dtype=np.uint8) * 80).repeat(8, 0).repeat(8, 1)[:h, :w].copy()   # blocky
+        _, got, want = _extract_both(oracle, ctx, np.ascontiguousarray(img)[None], levels=levels, scale_factor=sf, fast_threshold=thr, max_kpts=kp)
+        _assert_same_keypoints(got[0], want[0])
+        done += 1
