@@ -288,7 +288,7 @@ __device__ double block_max(double v, double *s_red) {
 // vmcnt 0 -> relaxed agent atomic on the arrival counter; then that lane polls the counter (relaxed, agent scope), issues ONE
 // agent-scope ACQUIRE fence (L1 invalidate), waits for it, and the workgroup barrier releases the other waves.  The counter only
 // grows (barrier k completes at k * team arrivals), so there is no reset to race with.  All workgroups of a team must be resident:
-// the host launches cooperatively and keeps problems * team <= CUs.  A poll that never completes gives up after ~1 s and marks
+// the host keeps problems * team <= CUs with one workgroup per CU (LDS), so they all become resident.  A poll that never completes gives up after ~1 s and marks
 // the problem failed instead of hanging the GPU.
 #define BA_IDS                                                                                                   \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                               \
@@ -1132,13 +1132,10 @@ int ms_ba_solve(ms_ba *B) {
         for (auto &h : B->host) h.team = team;
         MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
     }
-    if (team == 1) {
-        hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
-    } else {
-        const BaProb *probs = B->d_probs;
-        void *args[] = {(void *)&probs, (void *)&team};
-        MS_HIP(c, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_ba_lm), dim3(B->n * team), dim3(NT), args, (unsigned)kLdsBytes, c->stream));
-    }
+    // A plain launch: every workgroup needs more than half a CU's LDS and problems x team <= CUs, so all of a team's workgroups
+    // become resident as soon as CUs are free (other kernels drain on their own; nothing in this library runs beside it on the
+    // stream).  The cooperative-launch API would assert the same thing, but rocprofv3 crashes at process exit after one.
+    hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
     MS_KERNEL_CHECK(c, "k_ba_lm");
     return MS_OK;
 }
