@@ -63,6 +63,7 @@ struct BaProb {
     double *Hpp, *S, *bp, *dp, *y, *Hll, *bl, *Hinv, *Hpl, *dl, *chi2_obs, *Y;
     const double *zrow;                      // n6 + 16 zeros
     double *dinv;                            // [n6] reciprocals of the Cholesky diagonal
+    const int32_t *env16;                    // [n6/16 + 2] envelope of S per 16-row block: first structurally non-zero column (0 for the rhs row's block)
     // team state (team > 1): arrival counter (monotonic, one 128-B line), per-workgroup partial sums [2][team][2], solve status
     uint32_t *bar;
     double *red;
@@ -660,16 +661,24 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
             // Each wave works on TWO row tiles at once (independent accumulators) and two k-chunks per trip, so 16 double2
             // loads are in flight per group of 16 MFMAs instead of 4 per 4.
             const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S, *yg = (const MS_GLOBAL double *)P.y, *zg = (const MS_GLOBAL double *)P.zrow;
+            // Envelope: rows of a 16-row block have no entries left of env[block] (and Cholesky creates none), so a row tile whose
+            // envelope starts right of this panel is skipped outright and the k loop of the others starts at the later of the two
+            // envelopes.  Skipped rows never enter the panel buffer; the substitution and the write-back skip them the same way.
+            const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
+            const int pblk = c0 / NB, penv = env[pblk];
             const int q = lane >> 4, jb = lane & 15;
             const MS_GLOBAL d2_t *bp2 = reinterpret_cast<const MS_GLOBAL d2_t *>(((jb < nb) ? Sg + (size_t)(c0 + jb) * n : zg) + 4 * q);
             for (int rt = wave; rt * 16 < m; rt += 2 * NW) {
                 const int rt2 = rt + NW;
+                const int e1 = env[pblk + rt], e2 = rt2 * 16 < m ? env[pblk + rt2] : 0x7fffffff;
+                const bool act1 = e1 <= c0 + NB - 1, act2 = e2 <= c0 + NB - 1;
+                if (!act1 && !act2) continue;                       // wave-uniform
                 const int ia = rt * 16 + (lane & 15), ib = rt2 * 16 + (lane & 15);
                 const MS_GLOBAL double *arow = (c0 + ia < n) ? Sg + (size_t)(c0 + ia) * n : (c0 + ia == n ? yg : zg);
                 const MS_GLOBAL double *brow2 = (c0 + ib < n) ? Sg + (size_t)(c0 + ib) * n : (c0 + ib == n ? yg : zg);
                 const MS_GLOBAL d2_t *ap = reinterpret_cast<const MS_GLOBAL d2_t *>(arow + 4 * q), *ap2 = reinterpret_cast<const MS_GLOBAL d2_t *>(brow2 + 4 * q);
                 d4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-                int kk = 0;
+                int kk = max(penv, min(act1 ? e1 : 0x7fffffff, act2 ? e2 : 0x7fffffff)) & ~15;
                 for (; kk + 32 <= c0; kk += 32) {
                     const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], a2 = ap[kk / 2 + 8], a3 = ap[kk / 2 + 9];
                     const d2_t e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], e2 = ap2[kk / 2 + 8], e3 = ap2[kk / 2 + 9];
@@ -737,6 +746,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
             }
             __syncthreads();
             for (int i = nb + tid; i < m; i += NT) {     // rows below: x L11^T = a
+                if (env[(c0 + i) / NB] > c0 + NB - 1) continue;     // outside the envelope: structurally zero, not in the panel
                 double x[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -752,7 +762,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
             __syncthreads();
             for (int idx = tid; idx < cnt; idx += NT) {
                 const int i = idx / NB, j = idx - i * NB;
-                if (j < nb && (i >= j || i >= nb)) {
+                if (j < nb && (i >= j || i >= nb) && env[(c0 + i) / NB] <= c0 + NB - 1) {
                     if (c0 + i < n) P.S[(size_t)(c0 + i) * n + c0 + j] = pan[idx]; else P.y[c0 + j] = pan[idx];
                 }
             }
@@ -785,7 +795,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
                 if (lane < nb) xs[c0 + lane] = xk;
             }
             __syncthreads();
-            for (int k = tid; k < c0; k += NT) {
+            for (int k = (P.env16[c0 / NB] & ~15) + tid; k < c0; k += NT) {     // columns left of the panel rows' envelope hold zeros
                 double zk = xs[k];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) if (j < nb) zk -= P.S[(size_t)(c0 + j) * n + k] * xs[c0 + j];
@@ -956,12 +966,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair; int np_free = 0, n_chunks = 0, n_seg = 0; };
+    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16; int np_free = 0, n_chunks = 0, n_seg = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -1029,6 +1039,23 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 ++R.n_seg;
             }
         }
+        {   // envelope of the reduced camera matrix: the first free pose each free pose is coupled with (a shared point or a
+            // pose-pose edge).  Cholesky creates no fill left of it, so the factorisation skips everything outside.
+            const int np = R.np_free, n6i = 6 * np;
+            std::vector<int> first(np);
+            for (int f = 0; f < np; ++f) first[f] = f;
+            for (int32_t pr : R.seg_pair) { const int fa = pr >> 16, fb = pr & 0xFFFF; first[fa] = std::min(first[fa], fb); }
+            for (int k = 0; k < Q.n_pose_edge; ++k) {
+                const int fi = R.pidx[Q.edge_i[k]], fj = R.pidx[Q.edge_j[k]];
+                if (fi >= 0 && fj >= 0) { first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj)); }
+            }
+            R.env16.assign(n6i / 16 + 2, 0);
+            for (int b = 0; b < (int)R.env16.size(); ++b) {
+                int e = n6i;
+                for (int r = 16 * b; r < 16 * b + 16; ++r) e = r < n6i ? std::min(e, 6 * first[r / 6]) : 0;     // the rhs row (r = n6) is dense
+                R.env16[b] = std::min(e, n6i);
+            }
+        }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
         // inputs first, contiguous: they go up in ONE host->device copy per problem
@@ -1040,6 +1067,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.free2pose = bump(4 * R.np_free); O.edge_i = bump(4 * Q.n_pose_edge); O.edge_j = bump(4 * Q.n_pose_edge);
         O.edge_meas = bump(7 * Q.n_pose_edge * D); O.edge_info = bump(36 * Q.n_pose_edge * D);
         O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
+        O.env16 = bump(4 * R.env16.size());
         in_hi[p] = total;
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
@@ -1069,6 +1097,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.pt_start, R.pt_start.data(), 4 * (Q.n_point + 1)); up(O.pt_obs, R.pt_obs.data(), 4 * Q.n_obs);
         up(O.fstart, R.fstart.data(), 4 * (R.np_free + 1)); up(O.fobs, R.fobs.data(), 4 * R.fobs.size()); up(O.free2pose, R.free2pose.data(), 4 * R.np_free);
         up(O.chunk_items, R.chunk_items.data(), 4 * R.chunk_items.size()); up(O.seg_start, R.seg_start.data(), 4 * R.seg_start.size()); up(O.seg_pair, R.seg_pair.data(), 4 * R.seg_pair.size());
+        up(O.env16, R.env16.data(), 4 * R.env16.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
         if (hipMemcpyAsync(B->d_arena + in_lo[p], stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
@@ -1087,6 +1116,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.Hll = PTR(double, Hll); H.bl = PTR(double, bl); H.Hinv = PTR(double, Hinv); H.Hpl = PTR(double, Hpl); H.dl = PTR(double, dl);
         H.chi2_obs = PTR(double, chi2); H.stats = PTR(double, stats);
         H.n_chunks = R.n_chunks; H.n_seg = R.n_seg; H.chunk_items = PTR(int32_t, chunk_items); H.seg_start = PTR(int32_t, seg_start); H.seg_pair = PTR(int32_t, seg_pair);
+        H.env16 = PTR(int32_t, env16);
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
         H.dinv = PTR(double, dinv);
         H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1;
