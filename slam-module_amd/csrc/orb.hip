@@ -772,19 +772,27 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
                                                   const float *__restrict__ trk_py, const int32_t *__restrict__ trk_id, const int32_t *__restrict__ trk_count,
                                                   float *__restrict__ out_x, float *__restrict__ out_y, float *__restrict__ out_angle,
                                                   int32_t *__restrict__ out_octave, uint32_t *__restrict__ out_desc, int32_t *__restrict__ out_track,
-                                                  int32_t *__restrict__ out_count) {
+                                                  int32_t *__restrict__ out_count, int levels) {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // one keypoint per wave: everything derived from it is scalar
-    const int levels = g->levels;
+    // A keypoint is a chain of dependent memory round trips (its slot -> coordinates -> patch -> angle -> BRIEF samples) and the
+    // kernel is bound by that latency, so everything that does not depend on the keypoint is requested up front: the lane's
+    // patch-offset table and the counts of ALL levels in one batch (not one load per loop trip).  (Holding the four BRIEF
+    // point pairs from here on as well costs 16 registers = one wave per SIMD, and loses more than the round trip it saves.)
+    const uint4 ta = moment_tab[2 * lane], tb = moment_tab[2 * lane + 1];
+    int cnt[MS_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < MS_MAX_LEVELS; ++l) cnt[l] = l < levels ? det_count[f * levels + l] : 0;
     // segment table of this frame: [tracks][level 0][level 1]...
     const int nt = trk_count[f];
     int level = -1, idx = slot, total = nt;
     bool is_track = false;
     if (slot < nt) is_track = true;
     else idx = slot - nt;
-    for (int l = 0; l < levels; ++l) {
-        const int c = det_count[f * levels + l];
-        if (!is_track && level < 0) { if (idx < c) level = l; else idx -= c; }
+#pragma unroll
+    for (int l = 0; l < MS_MAX_LEVELS; ++l) {
+        const int c = cnt[l];
+        if (!is_track && level < 0 && l < levels) { if (idx < c) level = l; else idx -= c; }
         total += c;
     }
     if (slot == 0 && lane == 0) out_count[f] = total;
@@ -808,7 +816,6 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     // use the wave-uniform patch centre as scalar base, so an offset costs one multiply-add.
     int m10 = 0, m01 = 0;
     {
-        const uint4 ta = moment_tab[2 * lane], tb = moment_tab[2 * lane + 1];
         const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         int I[16], uu[16], vv[16];
 #pragma unroll
@@ -1154,7 +1161,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     MS_STAGE_MARK();
     hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
-                       o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count);
+                       o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count, G.levels);
     MS_KERNEL_CHECK(c, "k_describe");
     MS_STAGE_MARK();
 #undef MS_STAGE_MARK
