@@ -33,8 +33,8 @@ struct LevelGeom {
     int32_t min_dist;                 // per-level minimum keypoint distance (0/1 = none), feature_detector.cpp:79-82
     int32_t det_base;                 // first slot of this level in det arrays (prefix of quotas)
     int32_t cand_cap;                 // capacity of this level's candidate list (entries)
-    int32_t btiles_x, btile_base;     // k_blur tile table (248x16 tiles)
-    int32_t ftiles_x, ftile_base;     // k_fast tile table (248x30 tiles)
+    int32_t btiles_x, btile_base;     // k_blur tile table (248 x 32 tiles: 4 waves x 8 rows)
+    int32_t ftiles_x, ftile_base;     // k_fast tile table (248 x 14 tiles)
     uint32_t btiles_inv, ftiles_inv;  // ceil(2^32 / tiles_x): row of a tile = mulhi(t, inv), exact for t < 2^16
     uint64_t img_off, blur_off;       // byte offsets inside a frame slab
     uint64_t cand_off;                // entry offset inside a frame's candidate buffer
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, 
 // (4 pixels) of a row; a wave owns a 256-pixel row segment and walks 8 output rows.
 //   vertical pass   on the raw bytes, two pixels per instruction: even/odd bytes of the dword are two
 //                   16-bit lanes (sums stay < 2^16 because the 8.8 taps add up to 256) -> v_pk_mad_u16
-//   horizontal pass on the 16-bit column sums of the lane and its two neighbours (ds_bpermute shuffles),
+//   horizontal pass on the 16-bit column sums of the lane and its two neighbours (DPP wave shifts),
 //                   v_dot2_u32_u16 with the rounding constant as the initial accumulator
 // Lanes 0 and 63 only provide halo (248 outputs per 256 loaded pixels); REFLECT_101 is applied when the
 // bytes are loaded, which commutes with the vertical pass.
