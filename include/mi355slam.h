@@ -205,6 +205,23 @@ int ms_hamming_candidates(ms_ctx *ctx, const uint32_t *q_desc, int nq, const uin
 int ms_descriptor_medoid(ms_ctx *ctx, const uint32_t *desc_pool, const int32_t *obs_start, const int32_t *obs_idx, int n_points,
                          int max_obs, int32_t *best_local, int32_t *best_pool);
 
+/* FeatureSearch (feature_search.{hpp,cpp}): the keyframe's keypoints sorted by y.  Host helper; std::stable_sort, so points
+ * with equal y keep index order (the reference's std::sort leaves that order unspecified).  sorted_idx[p] = keypoint index. */
+int ms_feature_search_sort(const float *x, const float *y, int n, float *sorted_x, float *sorted_y, int32_t *sorted_idx);
+
+/* getFeaturesAround + the candidate scan of searchByProjection / replaceDuplication / findMatchesTranformedMps in one launch
+ * (feature_search.cpp:33-48 + keyframe_matcher.cpp:349-378, :479-494, :600-623): query i = (projected position, search radius,
+ * map-point descriptor, optional octave window [min, max] as in :611).  Candidates are the keypoints with
+ * y in [qy - r, qy + r] and dx*dx + dy*dy < r*r (float32), in sorted order; t_skip / t_octave are indexed by KEYPOINT index, as are
+ * the returned best / second indices.  Outputs as ms_hamming_candidates; n_candidates[i] = size of the reference's output vector
+ * (before skip / octave filtering), may be NULL.  All pointers are device memory. */
+int ms_projection_candidates(ms_ctx *ctx, const float *sorted_x, const float *sorted_y, const int32_t *sorted_idx, int n_kp,
+                             const uint32_t *t_desc, const int32_t *t_octave, const uint8_t *t_skip,
+                             const float *q_x, const float *q_y, const float *q_radius, const int32_t *q_min_octave, const int32_t *q_max_octave,
+                             const uint32_t *q_desc, int nq,
+                             int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave,
+                             int32_t *second_idx, int32_t *n_candidates);
+
 /* Rotation-consistency histogram (openvslam/match_angle_checker.h:60-134), host arithmetic: 30 bins of
  * cvRound(delta/30), everything outside the 3 fullest bins is invalid (ties between bins go to the lower bin).
  * Writes the ids of invalid entries (bin order, then insertion order) and returns their count. */

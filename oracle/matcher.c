@@ -229,3 +229,18 @@ int mso_descriptor_medoid(const uint32_t *desc, int n) {
     free(m); free(row);
     return best_idx;
 }
+
+/* N2: FeatureSearch::getFeaturesAround (feature_search.cpp:33-48) on arrays ALREADY sorted by y (stable: ties keep index order;
+ * the reference's std::sort leaves them unspecified): lower_bound on y - r, walk while y <= y + r, keep dx*dx + dy*dy < r*r.
+ * Writes sorted positions; returns how many. */
+int mso_features_around(const float *sx, const float *sy, int n, float x, float y, float r, int32_t *out_pos) {
+    const float ylo = y - r, yhi = y + r, r2 = r * r;
+    int lo = 0, hi = n, cnt = 0;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sy[mid] < ylo) lo = mid + 1; else hi = mid; }
+    for (int p = lo; p < n && sy[p] <= yhi; ++p) {
+        const float dx = x - sx[p], dy = y - sy[p];
+        const float a = dx * dx, b = dy * dy;              /* separate roundings: no fused multiply-add */
+        if (a + b < r2) out_pos[cnt++] = p;
+    }
+    return cnt;
+}

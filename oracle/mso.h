@@ -147,6 +147,9 @@ int mso_best2_candidates(const uint32_t *qdesc, const uint32_t *tdesc, const int
                          const uint8_t *skip, const int32_t *t_octave,
                          unsigned *best, unsigned *second, int *best_oct, int *second_oct);
 
+/* ---- N2: FeatureSearch::getFeaturesAround (feature_search.cpp:33-48) on arrays sorted by y; writes sorted positions ---- */
+int mso_features_around(const float *sx, const float *sy, int n, float x, float y, float r, int32_t *out_pos);
+
 /* ---- N4: MapPoint::updateDescriptor (map_point.cpp:75-116): index of the median-Hamming medoid, -1 when n == 0 ---- */
 int mso_descriptor_medoid(const uint32_t *desc /* [n][8] */, int n);
 

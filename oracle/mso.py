@@ -244,6 +244,15 @@ def best2_candidates(qdesc, tdesc, cand, skip=None, t_octave=None):
     return bi, best.value, second.value, bo.value, so.value
 
 
+def features_around(sx, sy, x, y, r):
+    """positions (in the y-sorted arrays) of the points within radius r, in the reference's output order"""
+    sx = np.ascontiguousarray(sx, np.float32); sy = np.ascontiguousarray(sy, np.float32)
+    out = np.zeros(len(sx), np.int32)
+    lib().mso_features_around.restype = C.c_int
+    n = lib().mso_features_around(_p(sx, f32p), _p(sy, f32p), len(sx), C.c_float(x), C.c_float(y), C.c_float(r), _p(out, i32p))
+    return out[:n].copy()
+
+
 def descriptor_medoid(desc):
     d = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
     lib().mso_descriptor_medoid.restype = C.c_int

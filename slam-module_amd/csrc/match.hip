@@ -13,6 +13,7 @@
 // staged through LDS in tiles of 256 and read back as wave-uniform broadcasts (2 x ds_read_b128 per target), distance is
 // 8 x (v_xor, v_bcnt_u32_b32-accumulate), best/second are tracked branch-free on packed (distance<<20 | index) keys.
 #include "ms_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -330,6 +331,69 @@ __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Radius query + scoring in one pass (FeatureSearch::getFeaturesAround, feature_search.cpp:33-48, feeding the scans of
+// searchByProjection / replaceDuplication / findMatchesTranformedMps): one wavefront per query.  The keyframe's keypoints are
+// sorted by y; the wave binary-searches the first y >= qy - r (std::lower_bound), then its lanes walk the range up to
+// y <= qy + r, keep the points with dx*dx + dy*dy < r*r (float32, no contraction), and score the survivors exactly like
+// k_hamming_candidates: candidates are ordered by their position in the sorted array, best = first minimum, second = next.
+__global__ __launch_bounds__(256) void k_projection_candidates(const float *__restrict__ sx, const float *__restrict__ sy, const int32_t *__restrict__ sidx, int n,
+                                                               const uint32_t *__restrict__ td, const int32_t *__restrict__ toct, const uint8_t *__restrict__ skip,
+                                                               const float *__restrict__ qx, const float *__restrict__ qy, const float *__restrict__ qr_,
+                                                               const int32_t *__restrict__ qlmin, const int32_t *__restrict__ qlmax,
+                                                               const uint32_t *__restrict__ qd, int nq,
+                                                               int32_t *__restrict__ bi, uint16_t *__restrict__ bd, uint16_t *__restrict__ sd,
+                                                               int32_t *__restrict__ bo, int32_t *__restrict__ so, int32_t *__restrict__ si, int32_t *__restrict__ ncand) {
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const uint4 qa = reinterpret_cast<const uint4 *>(qd)[2 * i], qb = reinterpret_cast<const uint4 *>(qd)[2 * i + 1];
+    const uint32_t qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const float x = qx[i], y = qy[i], r = qr_[i];
+    const float ylo = __fsub_rn(y, r), yhi = __fadd_rn(y, r), r2 = __fmul_rn(r, r);
+    const int lmin = qlmin ? qlmin[i] : -0x7fffffff, lmax = qlmax ? qlmax[i] : 0x7fffffff;
+    int lo = 0, hi = n;
+    while (lo < hi) {                                   // first position whose y is not < qy - r
+        const int mid = (lo + hi) >> 1;
+        if (sy[mid] < ylo) lo = mid + 1; else hi = mid;
+    }
+    uint32_t best = kNone, second = kNone;
+    int count = 0;
+    for (int pos = lo + lane;; pos += 64) {
+        const bool in_y = pos < n && sy[pos] <= yhi;
+        if (__ballot(in_y) == 0) break;                 // sorted: nothing further can be inside
+        if (!in_y) continue;
+        const float dx = __fsub_rn(x, sx[pos]), dy = __fsub_rn(y, sy[pos]);
+        if (!(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < r2)) continue;
+        const int j = sidx[pos];
+        ++count;                                        // size of the reference's output vector
+        if (skip && skip[j]) continue;
+        if (toct && (toct[j] < lmin || toct[j] > lmax)) continue;
+        const uint4 ta = reinterpret_cast<const uint4 *>(td)[2 * j], tb = reinterpret_cast<const uint4 *>(td)[2 * j + 1];
+        const uint32_t key = (hamming8(qr, ta, tb) << 20) | (uint32_t)pos;
+        const uint32_t l2 = min(best, key), h2 = max(best, key);
+        second = min(second, h2);
+        best = l2;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t ob = __shfl_xor(best, off, 64), os = __shfl_xor(second, off, 64);
+        const uint32_t l2 = min(best, ob), h2 = max(best, ob);
+        second = min(min(second, os), h2);
+        best = l2;
+        count += __shfl_xor(count, off, 64);
+    }
+    if (lane == 0) {
+        const int jb = best == kNone ? -1 : sidx[best & 0xFFFFFu], js = second == kNone ? -1 : sidx[second & 0xFFFFFu];
+        bi[i] = jb;
+        bd[i] = best == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(best >> 20);
+        sd[i] = second == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(second >> 20);
+        if (bo) bo[i] = (jb >= 0 && toct) ? toct[jb] : -1;
+        if (so) so[i] = (js >= 0 && toct) ? toct[js] : -1;
+        if (si) si[i] = js;
+        if (ncand) ncand[i] = count;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Greedy BoW matchers: one wavefront per keyframe pair.  The walk over shared vocabulary nodes and
 // over kf1's keypoints is sequential (targets are consumed as they are matched, so query i depends on
 // the queries before it: keyframe_matcher.cpp:98-100,:128 / :224-226,:249); the 64 lanes scan the
@@ -519,6 +583,33 @@ int ms_hamming_candidates(ms_ctx *c, const uint32_t *q_desc, int nq, const uint3
     hipLaunchKernelGGL(k_hamming_candidates, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, q_desc, nq, t_desc, cand_start, cand_idx, t_skip, t_octave,
                        best_idx, best_dist, second_dist, best_octave, second_octave, second_idx);
     MS_KERNEL_CHECK(c, "k_hamming_candidates");
+    return MS_OK;
+}
+
+int ms_feature_search_sort(const float *x, const float *y, int n, float *sorted_x, float *sorted_y, int32_t *sorted_idx) {
+    if (n < 0 || (n && (!x || !y || !sorted_x || !sorted_y || !sorted_idx))) return MS_ERR_INVALID;
+    std::vector<int32_t> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return y[a] < y[b]; });     // feature_search.cpp:26-29, ties by index
+    for (int i = 0; i < n; ++i) { sorted_x[i] = x[order[i]]; sorted_y[i] = y[order[i]]; sorted_idx[i] = order[i]; }
+    return MS_OK;
+}
+
+int ms_projection_candidates(ms_ctx *c, const float *sorted_x, const float *sorted_y, const int32_t *sorted_idx, int n_kp,
+                             const uint32_t *t_desc, const int32_t *t_octave, const uint8_t *t_skip,
+                             const float *q_x, const float *q_y, const float *q_radius, const int32_t *q_min_octave, const int32_t *q_max_octave,
+                             const uint32_t *q_desc, int nq,
+                             int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave,
+                             int32_t *second_idx, int32_t *n_candidates) {
+    if (!c || n_kp < 0 || nq < 0 || !q_x || !q_y || !q_radius || !q_desc || !best_idx || !best_dist || !second_dist) return MS_ERR_INVALID;
+    if (n_kp && (!sorted_x || !sorted_y || !sorted_idx || !t_desc)) return MS_ERR_INVALID;
+    if (n_kp >= (1 << 20)) return ms_fail(c, MS_ERR_CAPACITY, "ms_projection_candidates: %d keypoints (max %d)", n_kp, (1 << 20) - 1);
+    if (nq == 0) return MS_OK;
+    if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_projection_candidates: descriptors must be 16-byte aligned");
+    MS_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_projection_candidates, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, sorted_x, sorted_y, sorted_idx, n_kp, t_desc, t_octave, t_skip,
+                       q_x, q_y, q_radius, q_min_octave, q_max_octave, q_desc, nq, best_idx, best_dist, second_dist, best_octave, second_octave, second_idx, n_candidates);
+    MS_KERNEL_CHECK(c, "k_projection_candidates");
     return MS_OK;
 }
 

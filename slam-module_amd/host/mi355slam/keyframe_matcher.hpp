@@ -40,7 +40,15 @@ public:
         f_.n = (std::int32_t)n;
         f_.desc = up(desc); f_.angle = up(ang); f_.octave = up(oct); f_.bearing = up(bear); f_.usable = up(kf.usable);
         f_.bow.n_nodes = (std::int32_t)node_id.size(); f_.bow.node_id = up(node_id); f_.bow.node_start = up(node_start); f_.bow.kp_idx = up(kp_idx);
+        // FeatureSearch::create (feature_search.cpp:22-30): the keypoints sorted by y, for the radius queries of M3-M5
+        std::vector<float> x(n), y(n), sx(n), sy(n); std::vector<std::int32_t> si(n);
+        for (std::size_t i = 0; i < n; ++i) { x[i] = kps[i].pt.x; y[i] = kps[i].pt.y; }
+        ctx_.check(ms_feature_search_sort(x.data(), y.data(), (int)n, sx.data(), sy.data(), si.data()), "ms_feature_search_sort");
+        sx_ = up(sx); sy_ = up(sy); si_ = up(si);
     }
+    const float *sortedX() const { return sx_; }
+    const float *sortedY() const { return sy_; }
+    const std::int32_t *sortedIndex() const { return si_; }
     ~DeviceKeyframe() { for (void *p : owned_) ms_dev_free(ctx_.get(), p); }
     DeviceKeyframe(const DeviceKeyframe &) = delete;
     const ms_match_frame &frame() const { return f_; }
@@ -54,6 +62,8 @@ private:
     }
     Context &ctx_;
     ms_match_frame f_{};
+    const float *sx_ = nullptr, *sy_ = nullptr;
+    const std::int32_t *si_ = nullptr;
     std::vector<void *> owned_;
 };
 
@@ -114,6 +124,14 @@ struct ProjectionQuery {
     std::vector<std::int32_t> candidates;       // indices from kf.getFeaturesAround(...) (keyframe_matcher.cpp:340-344, :473, :596)
 };
 
+// The same scan with the radius query done on the device: the reprojected position and the search radius instead of a candidate list
+// (kf.getFeaturesAround(reprojection, radius, indices), keyframe_matcher.cpp:340-344 / :470-473 / :596).
+struct RadiusQuery {
+    KeyPoint::Descriptor descriptor;
+    float x = 0, y = 0, radius = 0;
+    std::int32_t minOctave = -0x7fffffff, maxOctave = 0x7fffffff;      // findMatchesTranformedMps keeps [pred - 1, pred] (:611)
+};
+
 struct CandidateScores { std::vector<std::int32_t> best, second, bestOctave, secondOctave; std::vector<std::uint16_t> bestDist, secondDist; };
 
 namespace detail {
@@ -152,12 +170,51 @@ inline CandidateScores score_candidates(Context &ctx, const DeviceKeyframe &kf, 
 }
 }  // namespace detail
 
+namespace detail {
+inline CandidateScores score_candidates(Context &ctx, const DeviceKeyframe &kf, const std::vector<RadiusQuery> &qs,
+                                        const std::vector<std::uint8_t> *skip, std::size_t first = 0, std::size_t count = ~std::size_t(0)) {
+    count = std::min(count, qs.size() - first);
+    CandidateScores out;
+    out.best.assign(count, -1); out.second.assign(count, -1); out.bestOctave.assign(count, -1); out.secondOctave.assign(count, -1);
+    out.bestDist.assign(count, MS_HAMMING_MAX); out.secondDist.assign(count, MS_HAMMING_MAX);
+    if (count == 0) return out;
+    std::vector<std::uint32_t> desc(8 * count);
+    std::vector<float> x(count), y(count), r(count);
+    std::vector<std::int32_t> lo(count), hi(count);
+    for (std::size_t i = 0; i < count; ++i) {
+        const RadiusQuery &q = qs[first + i];
+        for (int k = 0; k < 8; ++k) desc[8 * i + k] = q.descriptor[k];
+        x[i] = q.x; y[i] = q.y; r[i] = q.radius; lo[i] = q.minOctave; hi[i] = q.maxOctave;
+    }
+    std::vector<void *> bufs;
+    auto up = [&](const void *src, std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d);
+                                                         if (bytes && src) { ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); }
+                                                         return d; };
+    void *dq = up(desc.data(), desc.size() * 4), *dx = up(x.data(), 4 * count), *dy = up(y.data(), 4 * count), *dr = up(r.data(), 4 * count);
+    void *dlo = up(lo.data(), 4 * count), *dhi = up(hi.data(), 4 * count), *dk = skip ? up(skip->data(), skip->size()) : nullptr;
+    void *b = up(nullptr, 4 * count), *bd = up(nullptr, 2 * count), *sd = up(nullptr, 2 * count), *bo = up(nullptr, 4 * count), *so = up(nullptr, 4 * count), *si = up(nullptr, 4 * count);
+    const ms_match_frame &f = kf.frame();
+    ctx.check(ms_projection_candidates(ctx.get(), kf.sortedX(), kf.sortedY(), kf.sortedIndex(), f.n, f.desc, f.octave, static_cast<const std::uint8_t *>(dk),
+                                       static_cast<const float *>(dx), static_cast<const float *>(dy), static_cast<const float *>(dr),
+                                       static_cast<const std::int32_t *>(dlo), static_cast<const std::int32_t *>(dhi), static_cast<const std::uint32_t *>(dq), (int)count,
+                                       static_cast<std::int32_t *>(b), static_cast<std::uint16_t *>(bd), static_cast<std::uint16_t *>(sd), static_cast<std::int32_t *>(bo),
+                                       static_cast<std::int32_t *>(so), static_cast<std::int32_t *>(si), nullptr), "ms_projection_candidates");
+    ctx.check(ms_dev_download(ctx.get(), out.best.data(), b, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.second.data(), si, 4 * count), "download");
+    ctx.check(ms_dev_download(ctx.get(), out.bestDist.data(), bd, 2 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondDist.data(), sd, 2 * count), "download");
+    ctx.check(ms_dev_download(ctx.get(), out.bestOctave.data(), bo, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondOctave.data(), so, 4 * count), "download");
+    for (void *p : bufs) ms_dev_free(ctx.get(), p);
+    return out;
+}
+}  // namespace detail
+
 // Scoring + accept rule of searchByProjection (keyframe_matcher.cpp:349-389).  `bound[k]` != 0 marks keypoints that already
 // carry an observed map point (:358-360); it is updated as matches are accepted, in query order, exactly like the
 // reference's loop: all queries are scored in one launch against the initial mask, and a query whose best or second
 // candidate was taken by an earlier query of this call is re-scored (on the GPU) against the current mask.
 // Returns, per query, the matched keypoint index or -1; the caller performs addObservation (:388-389).
-inline std::vector<int> searchByProjectionCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &queries,
+// `Query` is ProjectionQuery (candidate lists from the host's getFeaturesAround) or RadiusQuery (radius query on the device).
+template <class Query>
+inline std::vector<int> searchByProjectionCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<Query> &queries,
                                                std::vector<std::uint8_t> &bound) {
     std::vector<int> match(queries.size(), -1);
     CandidateScores s = detail::score_candidates(ctx, kf, queries, &bound);
@@ -179,7 +236,8 @@ inline std::vector<int> searchByProjectionCore(Context &ctx, const DeviceKeyfram
 
 // Scoring of replaceDuplication (keyframe_matcher.cpp:479-499: best only, accept <= 50) and findMatchesTranformedMps
 // (:600-627: accept <= 100; the caller pre-filters candidates by octave, :611).  No greedy state in the scoring itself.
-inline std::vector<int> bestCandidateCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &queries, unsigned maxDist) {
+template <class Query>
+inline std::vector<int> bestCandidateCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<Query> &queries, unsigned maxDist) {
     CandidateScores s = detail::score_candidates(ctx, kf, queries, nullptr);
     std::vector<int> match(queries.size(), -1);
     for (std::size_t i = 0; i < queries.size(); ++i) if (s.best[i] >= 0 && s.bestDist[i] <= maxDist) match[i] = s.best[i];

@@ -334,6 +334,36 @@ def ratio_test(ctx, best_idx, best_dist, second_dist, lowe_ratio, max_dist=50):
     return m.download(np.int32, (n,))
 
 
+def feature_search_sort(x, y):
+    """FeatureSearch::create: (sorted_x, sorted_y, sorted_idx), stable by y."""
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    sx, sy, si = np.zeros_like(x), np.zeros_like(y), np.zeros(len(x), np.int32)
+    rc = lib().ms_feature_search_sort(_vp(x), _vp(y), len(x), _vp(sx), _vp(sy), _vp(si))
+    if rc != 0:
+        raise MsError("ms_feature_search_sort failed (%d)" % rc)
+    return sx, sy, si
+
+
+def projection_candidates(ctx, kp_x, kp_y, t_desc, q_x, q_y, q_r, q_desc, t_octave=None, t_skip=None, q_min_octave=None, q_max_octave=None):
+    """Radius query + best/second scan per query.  Returns (best_idx, best_dist, second_dist, best_oct, second_oct, second_idx, n_candidates)."""
+    sx, sy, si = feature_search_sort(kp_x, kp_y)
+    t = np.ascontiguousarray(t_desc, np.uint32).reshape(-1, 8); q = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8)
+    nq, n = len(q), len(sx)
+    up = lambda a, dt: ctx.upload(np.ascontiguousarray(a, dt) if len(a) else np.zeros(4, dt))
+    dsx, dsy, dsi, dt_, dq = up(sx, np.float32), up(sy, np.float32), up(si, np.int32), ctx.upload(t if n else np.zeros((1, 8), np.uint32)), ctx.upload(q if nq else np.zeros((1, 8), np.uint32))
+    doc = None if t_octave is None else up(t_octave, np.int32)
+    dsk = None if t_skip is None else up(t_skip, np.uint8)
+    dqx, dqy, dqr = up(q_x, np.float32), up(q_y, np.float32), up(q_r, np.float32)
+    dlo = None if q_min_octave is None else up(q_min_octave, np.int32)
+    dhi = None if q_max_octave is None else up(q_max_octave, np.int32)
+    outs = [ctx.alloc(4 * nq + 16), ctx.alloc(2 * nq + 16), ctx.alloc(2 * nq + 16), ctx.alloc(4 * nq + 16), ctx.alloc(4 * nq + 16), ctx.alloc(4 * nq + 16), ctx.alloc(4 * nq + 16)]
+    ctx.check(lib().ms_projection_candidates(ctx._h, _vp(dsx), _vp(dsy), _vp(dsi), n, _vp(dt_), _vp(doc), _vp(dsk), _vp(dqx), _vp(dqy), _vp(dqr), _vp(dlo), _vp(dhi),
+                                             _vp(dq), nq, *[_vp(o) for o in outs]), "ms_projection_candidates")
+    ctx.sync()
+    dts = (np.int32, np.uint16, np.uint16, np.int32, np.int32, np.int32, np.int32)
+    return tuple(o.download(d, (nq,)) for o, d in zip(outs, dts))
+
+
 def descriptor_medoid(ctx, desc_pool, obs_lists):
     """MapPoint::updateDescriptor for many map points: obs_lists[p] = indices into desc_pool.  Returns (best_local, best_pool)."""
     pool = np.ascontiguousarray(desc_pool, np.uint32).reshape(-1, 8)

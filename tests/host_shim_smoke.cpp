@@ -74,6 +74,43 @@ int main(int argc, char **argv) {
             if ((bi >= 0 && bd <= 50 ? bi : -1) != dup[i]) { std::printf("bestCandidateCore mismatch at %zu\n", i); return 6; }
         }
     }
+    // the same matcher with the radius query on the device: reprojections + radii in, getFeaturesAround restated on the CPU as the check
+    {
+        unsigned rng = 777u;
+        auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+        auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { int d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
+        std::vector<std::size_t> order(kps.size());
+        for (std::size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](std::size_t a, std::size_t b) { return kps[a].pt.y < kps[b].pt.y; });   // feature_search.cpp:26-29
+        std::vector<RadiusQuery> rq;
+        for (int i = 0; i < 300; ++i) {
+            const KeyPoint &k = kps[rnd() % kps.size()];
+            RadiusQuery q; q.descriptor = k.descriptor; q.descriptor[rnd() % 8] ^= 1u << (rnd() % 32);
+            q.x = k.pt.x + (float)(rnd() % 9) - 4.f; q.y = k.pt.y + (float)(rnd() % 9) - 4.f; q.radius = 3.f + (float)(rnd() % 40);
+            rq.push_back(q);
+        }
+        std::vector<std::uint8_t> bound(kps.size(), 0), bound_ref;
+        for (std::size_t k = 0; k < bound.size(); k += 5) bound[k] = 1;
+        bound_ref = bound;
+        std::vector<int> want(rq.size(), -1);
+        for (std::size_t i = 0; i < rq.size(); ++i) {
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (std::size_t o : order) {                                  // feature_search.cpp:33-48 (lower_bound + walk == filter in sorted order)
+                const float dx = rq[i].x - kps[o].pt.x, dy = rq[i].y - kps[o].pt.y;
+                if (kps[o].pt.y < rq[i].y - rq[i].radius || !(kps[o].pt.y <= rq[i].y + rq[i].radius) || !(dx * dx + dy * dy < rq[i].radius * rq[i].radius)) continue;
+                if (bound_ref[o]) continue;
+                const int dist = popc(rq[i].descriptor, kps[o].descriptor), level = kps[o].octave;
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = (int)o; }
+                else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+            }
+            if (bestIdx == -1) continue;
+            if (bestDist <= 100) { if (bestLevel == bestLevel2 && bestDist > 0.8 * bestDist2) continue; want[i] = bestIdx; bound_ref[bestIdx] = 1; }
+        }
+        std::vector<int> got = searchByProjectionCore(ctx, d1, rq, bound);
+        int nm = 0; for (int m : want) nm += m >= 0;
+        std::printf("searchByProjection (device radius query): %d matches of %zu queries\n", nm, rq.size());
+        if (got != want || bound != bound_ref || nm < 20) { std::printf("radius searchByProjectionCore mismatch\n"); return 8; }
+    }
     {   auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { unsigned d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
         // updateDescriptor for a batch of map points vs the plain median-of-row rule (map_point.cpp:75-116)
         std::vector<std::vector<KeyPoint::Descriptor>> obs(40);

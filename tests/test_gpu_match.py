@@ -212,3 +212,33 @@ def test_descriptor_medoid_equals_update_descriptor(oracle, ctx):
         assert bp[p] == (obs[want] if want >= 0 else -1), p
     with pytest.raises(mi355slam.MsError):
         mi355slam.descriptor_medoid(ctx, pool, [np.arange(257, dtype=np.int32)])
+
+
+def test_projection_candidates_radius_query_and_scan(oracle, ctx):
+    """getFeaturesAround + the candidate scan of searchByProjection (feature_search.cpp:33-48, keyframe_matcher.cpp:349-378)."""
+    import mi355slam
+    rng = np.random.default_rng(123)
+    n, nq = 1900, 700
+    kx = np.round(rng.uniform(0, 1280, n), 0).astype(np.float32) * np.float32(1.2)         # coordinates are level pixels x scale: many equal y
+    ky = np.round(rng.uniform(0, 720, n), 0).astype(np.float32) * np.float32(1.2)
+    toct = rng.integers(0, 8, n).astype(np.int32)
+    q, t = make_pair(7, nq, n, 500)
+    skip = (rng.random(n) < 0.25).astype(np.uint8)
+    qx = rng.uniform(-20, 1300, nq).astype(np.float32); qy = rng.uniform(-20, 740, nq).astype(np.float32)
+    qr = rng.uniform(0.5, 60, nq).astype(np.float32); qr[:5] = [0.0, 1e-3, 2000.0, 15.0, 15.0]
+    qx[3], qy[3] = kx[10], ky[10]                                                           # dead centre on a keypoint
+    t[11] = q[3]; kx[11], ky[11] = kx[10], ky[10]                                           # two keypoints at the same place, one an exact match
+    lo = rng.integers(0, 6, nq).astype(np.int32); hi = lo + rng.integers(0, 3, nq).astype(np.int32)
+    sx, sy, si = mi355slam.feature_search_sort(kx, ky)
+    assert np.all(np.diff(sy) >= 0) and np.array_equal(np.sort(si), np.arange(n))
+    for (sk, use_oct) in ((None, False), (skip, False), (skip, True)):
+        got = mi355slam.projection_candidates(ctx, kx, ky, t, qx, qy, qr, q, t_octave=toct, t_skip=sk,
+                                              q_min_octave=lo if use_oct else None, q_max_octave=hi if use_oct else None)
+        for i in range(nq):
+            pos = oracle.features_around(sx, sy, qx[i], qy[i], qr[i])
+            cand = si[pos]
+            assert got[6][i] == len(cand), i
+            if use_oct: cand = cand[(toct[cand] >= lo[i]) & (toct[cand] <= hi[i])]
+            w = oracle.best2_candidates(q[i], t, cand, skip=sk, t_octave=toct)
+            assert (got[0][i], got[1][i], got[2][i], got[3][i], got[4][i]) == w, (i, sk is not None, use_oct)
+    assert got[6][0] == 0 and got[0][0] == -1                                               # radius 0: nothing is strictly inside

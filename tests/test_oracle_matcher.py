@@ -143,3 +143,15 @@ def test_descriptor_medoid_follows_update_descriptor(oracle):
         med = np.sort(mat, axis=1)[:, int(0.5 * (n - 1))]
         assert oracle.descriptor_medoid(d) == int(np.argmin(med)), n
     assert oracle.descriptor_medoid(np.zeros((0, 8), np.uint32)) == -1
+
+
+def test_features_around_is_the_sorted_radius_query(oracle):
+    """feature_search.cpp:33-48 in numpy: points sorted by y (stable), those with y in [qy - r, qy + r] and dx^2 + dy^2 < r^2 (float32)."""
+    rng = np.random.default_rng(8)
+    x = np.round(rng.uniform(0, 640, 500)).astype(np.float32); y = np.round(rng.uniform(0, 480, 500)).astype(np.float32)
+    order = np.argsort(y, kind="stable"); sx, sy = x[order], y[order]
+    for _ in range(200):
+        qx, qy, r = np.float32(rng.uniform(-10, 650)), np.float32(rng.uniform(-10, 490)), np.float32(rng.uniform(0, 80))
+        dx, dy = qx - sx, qy - sy
+        inside = (sy >= qy - r) & (sy <= qy + r) & ((dx * dx + dy * dy).astype(np.float32) < r * r)
+        assert np.array_equal(oracle.features_around(sx, sy, qx, qy, r), np.nonzero(inside)[0])
