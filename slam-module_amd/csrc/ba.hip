@@ -856,6 +856,12 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     return true;
 }
 
+// before a team launch: arrival counters and the gave-up marker back to zero (the counter is monotonic within a launch)
+__global__ void k_ba_team_reset(const BaProb *probs, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { probs[i].bar[0] = 0; probs[i].flag[1] = 0; }
+}
+
 // grid = problems x team workgroups; workgroup b works on problem b / team
 __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1165,6 +1171,7 @@ int ms_ba_solve(ms_ba *B) {
     // A plain launch: every workgroup needs more than half a CU's LDS and problems x team <= CUs, so all of a team's workgroups
     // become resident as soon as CUs are free (other kernels drain on their own; nothing in this library runs beside it on the
     // stream).  The cooperative-launch API would assert the same thing, but rocprofv3 crashes at process exit after one.
+    if (team > 1) hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, c->stream, B->d_probs, B->n);
     hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
     MS_KERNEL_CHECK(c, "k_ba_lm");
     return MS_OK;
