@@ -677,6 +677,15 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
                 const MS_GLOBAL double *arow = (c0 + ia < n) ? Sg + (size_t)(c0 + ia) * n : (c0 + ia == n ? yg : zg);
                 const MS_GLOBAL double *brow2 = (c0 + ib < n) ? Sg + (size_t)(c0 + ib) * n : (c0 + ib == n ? yg : zg);
                 const MS_GLOBAL d2_t *ap = reinterpret_cast<const MS_GLOBAL d2_t *>(arow + 4 * q), *ap2 = reinterpret_cast<const MS_GLOBAL d2_t *>(brow2 + 4 * q);
+                // the panel's own entries (what the products are subtracted from) are requested first: their round trip runs under the k loop
+                double sv[2][4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg, j = lane & 15;
+                        sv[which][reg] = (ii < m && j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
+                    }
                 d4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
                 int kk = max(penv, min(act1 ? e1 : 0x7fffffff, act2 ? e2 : 0x7fffffff)) & ~15;
                 for (; kk + 32 <= c0; kk += 32) {
@@ -706,8 +715,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
                     for (int which = 0; which < 2; ++which) {
                         const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg;
                         if (ii < m) {
-                            const double v = (j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
-                            pan[ii * NB + j] = v - (which ? acc2[reg] : acc[reg]);
+                            pan[ii * NB + j] = sv[which][reg] - (which ? acc2[reg] : acc[reg]);
                         }
                     }
                 }
