@@ -126,6 +126,16 @@ def main():
     from mi355slam import shard
     frames_total, dt = shard.aggregate(dist if world > 1 else None, torch, BATCH * args.steps, dt, device="cuda")
 
+    # outside the timed region: the same 256 searches on the popcount kernel (v_xor / v_bcnt), for comparison with the matrix-core one
+    mi355slam.lib().ms_hamming_set_path(1)
+    for rep in range(3):
+        if rep == 1:
+            ctx.event_mark(2)
+        mi355slam.hamming_best2_sets(ctx, view.desc, cap, view.count, view.desc, cap, view.count, pair_q.data_ptr(), pair_t.data_ptr(),
+                                     BATCH, best_idx.data_ptr(), best_dist.data_ptr(), second_dist.data_ptr())
+    ctx.event_mark(3)
+    popcount_ms = ctx.event_elapsed_ms(2, 3) / 2
+    mi355slam.lib().ms_hamming_set_path(0)
     n_kp = np.frombuffer(ctx_download(ctx, view.count, 4 * BATCH), dtype=np.int32)
     n_match = int((match.view(BATCH, cap) >= 0).sum().item())
     value = frames_total / dt
@@ -143,6 +153,7 @@ def main():
     dom = max(avg_ms, key=avg_ms.get)
     kernels = {k: {"ms_per_launch": round(avg_ms[k], 4), "alg_GBs": round(alg[k] * BATCH / (avg_ms[k] * 1e-3) / 1e9, 1) if avg_ms[k] > 0 else None}
                for k in avg_ms}
+    kernels["hamming"]["popcount_kernel_ms"] = round(popcount_ms, 4)
     achieved = alg[dom] * BATCH / (avg_ms[dom] * 1e-3) / 1e9
     # From the committed PMC passes (profiles/r01_pmc_traffic.json, tools/pmc_summary.py): HBM bytes per launch and the
     # wave-level VALU instruction count.  The front-end kernels are bound by VALU ISSUE, not by HBM: almost all their

@@ -157,6 +157,11 @@ int ms_orb_download_detections(ms_orb *orb, int frame, int level, int32_t *x, in
  * Descriptor matching -- the scoring core of keyframe_matcher.cpp (compute_descriptor_distance_32,
  * openvslam/match_base.h:18-39) as device primitives.
  * ------------------------------------------------------------------------------------------- */
+/* Process-wide choice of the kernel behind the UNMASKED searches: 0 = automatic (the i8 matrix-core kernel), 1 = the popcount
+ * kernel (v_xor / v_bcnt, wave reductions) that the masked searches always use.  Both give identical results; the switch exists to
+ * cross-check one against the other and to time them side by side (bench.py reports both). */
+int ms_hamming_set_path(int path);
+
 /* Brute-force best / second-best of every query against every target, for `n_pairs` independent
  * (query set, target set) pairs laid out back to back: pair p uses q + p*nq*8 and t + p*nt*8.
  * Update rule of keyframe_matcher.cpp:106-112 (strict '<': lowest index wins ties).

@@ -242,3 +242,22 @@ def test_projection_candidates_radius_query_and_scan(oracle, ctx):
             w = oracle.best2_candidates(q[i], t, cand, skip=sk, t_octave=toct)
             assert (got[0][i], got[1][i], got[2][i], got[3][i], got[4][i]) == w, (i, sk is not None, use_oct)
     assert got[6][0] == 0 and got[0][0] == -1                                               # radius 0: nothing is strictly inside
+
+
+def test_matrix_core_search_equals_popcount_search(ctx):
+    """The two kernels behind the unmasked search (i8 matrix cores vs v_xor / v_bcnt popcount) agree bit for bit."""
+    import mi355slam
+    L = mi355slam.lib()
+    rng = np.random.default_rng(99)
+    try:
+        for nq, nt in [(2000, 2000), (1837, 1911), (77, 3000)]:
+            q = rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32)
+            t = rng.integers(0, 2**32, (nt, 8), dtype=np.uint64).astype(np.uint32)
+            t[: nq // 2] = q[: nq // 2] ^ np.uint32(1 << 7)              # near copies: small distances and ties
+            assert L.ms_hamming_set_path(0) == 0
+            a = mi355slam.hamming_best2(ctx, q, t)
+            assert L.ms_hamming_set_path(1) == 0
+            b = mi355slam.hamming_best2(ctx, q, t)
+            for x, y in zip(a, b): assert np.array_equal(x, y)
+    finally:
+        L.ms_hamming_set_path(0)
