@@ -154,6 +154,10 @@ def main():
     kernels = {k: {"ms_per_launch": round(avg_ms[k], 4), "alg_GBs": round(alg[k] * BATCH / (avg_ms[k] * 1e-3) / 1e9, 1) if avg_ms[k] > 0 else None}
                for k in avg_ms}
     kernels["hamming"]["popcount_kernel_ms"] = round(popcount_ms, 4)
+    # the unmasked search is an i8 matrix product (1 multiply-add per descriptor bit and pair): its own roofline is the dense i8 MFMA peak
+    pair_ops = 2.0 * 256 * float((n_kp.astype(np.float64) * np.roll(n_kp, 1).astype(np.float64)).sum())
+    kernels["hamming"]["mfma"] = {"bound": "mfma", "achieved": round(pair_ops / (avg_ms["hamming"] * 1e-3) / 1e12, 1), "peak": 5000.0, "unit": "Top/s (i8)",
+                                  "frac": round(pair_ops / (avg_ms["hamming"] * 1e-3) / 1e12 / 5000.0, 4)}
     achieved = alg[dom] * BATCH / (avg_ms[dom] * 1e-3) / 1e9
     # From the committed PMC passes (profiles/r01_pmc_traffic.json, tools/pmc_summary.py): HBM bytes per launch and the
     # wave-level VALU instruction count.  The front-end kernels are bound by VALU ISSUE, not by HBM: almost all their
