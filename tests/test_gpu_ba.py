@@ -153,3 +153,31 @@ def test_team_barriers_hold_beside_a_saturating_front_end_batch(oracle):
         assert abs(out["stats"]["chi2_final"] - ref["stats"]["chi2_final"]) <= 1e-9 * abs(ref["stats"]["chi2_final"]), it
         assert np.abs(out["pose"] - ref["pose"]).max() < 1e-9 and np.abs(out["point"] - ref["point"]).max() < 1e-9, it
     ba.close(); ca.close(); cb.close()
+
+
+def test_envelope_with_loop_closure_and_scattered_covisibility(oracle, ctx):
+    """The Cholesky skips what lies outside the envelope of the reduced camera matrix; a loop-closure edge between far keyframes,
+    points seen by scattered keyframes and fixed poses in the middle must all widen / shift it correctly (batch and team)."""
+    import mi355slam
+    p = ba_synth.make_problem(40, 700, 6, seed=11)
+    rng = np.random.default_rng(3)
+    gt_pose, gt_point = p["gt_pose"], p["gt_point"]
+    # 25 extra observations: old points re-observed by keyframes far from their run (covisibility off the band)
+    op, ol, uv, info = list(p["obs_pose"]), list(p["obs_point"]), list(p["obs_uv"]), list(p["obs_info"])
+    for _ in range(25):
+        l, i = int(rng.integers(0, 700)), int(rng.integers(0, 40))
+        q = ba_synth._R_from_quat(gt_pose[i, :4]) @ gt_point[l] + gt_pose[i, 4:]
+        if q[2] < 0.5: continue
+        op.append(i); ol.append(l); uv.append(q[:2] / q[2] + rng.normal(0, 1 / 500, 2)); info.append(500.0 ** 2)
+    p["obs_pose"], p["obs_point"] = np.array(op, np.int32), np.array(ol, np.int32)
+    p["obs_uv"], p["obs_info"] = np.array(uv), np.array(info)
+    # a loop-closure edge between keyframes 3 and 37 (makeLoopClosureEdge, bundle_adjuster.cpp:87-111)
+    M = ba_synth._compose(gt_pose[37], ba_synth._inverse(gt_pose[3]))
+    p["edge_i"] = np.append(p["edge_i"], 3).astype(np.int32); p["edge_j"] = np.append(p["edge_j"], 37).astype(np.int32)
+    p["edge_meas"] = np.vstack([p["edge_meas"], M[None]]); p["edge_info"] = np.vstack([p["edge_info"], (np.eye(6) * 400.0).reshape(1, 36)])
+    p["pose_fixed"] = p["pose_fixed"].copy(); p["pose_fixed"][[0, 17, 18]] = 1
+    want = oracle.ba_solve(p, 8, False)
+    for team in (1, 6):
+        ba = mi355slam.BundleAdjuster(ctx, [p, p], max_iters=8); ba.set_team(team); ba.solve()
+        _check(p, ba.download(0), want); _check(p, ba.download(1), want)
+        ba.close()
