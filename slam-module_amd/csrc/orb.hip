@@ -766,6 +766,13 @@ __device__ __forceinline__ int wave_sum(int v) {      // DPP inclusive scan, tot
     return __builtin_amdgcn_readlane(wave_scan_add(v), 63);
 }
 
+// Keypoints a wave works on at once.  Measured: 1 at 8 waves per SIMD = 0.60 ms, 2 side by side (5 waves) = 0.64 ms, and the older
+// build at 6 or 7 waves per SIMD also 0.60 ms: k_describe is bound by the throughput of scattered line fetches (1.75 GB of HBM
+// traffic for 0.87 GB of patch bytes), not by occupancy or by the length of a keypoint's dependent chain.
+constexpr int kDescPerWave = 1;
+
+struct DescKp { int x, y, oct, tid_out; float ox, oy; bool valid; };
+
 __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
                                                   const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
                                                   const int16_t *__restrict__ trk_x, const int16_t *__restrict__ trk_y, const float *__restrict__ trk_px,
@@ -774,80 +781,96 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
                                                   int32_t *__restrict__ out_octave, uint32_t *__restrict__ out_desc, int32_t *__restrict__ out_track,
                                                   int32_t *__restrict__ out_count, int levels) {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // one keypoint per wave: everything derived from it is scalar
+    const int slot0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kDescPerWave;   // wave-uniform: everything derived from it is scalar
     // A keypoint is a chain of dependent memory round trips (its slot -> coordinates -> patch -> angle -> BRIEF samples) and the
-    // kernel is bound by that latency, so everything that does not depend on the keypoint is requested up front: the lane's
-    // patch-offset table and the counts of ALL levels in one batch (not one load per loop trip).  (Holding the four BRIEF
-    // point pairs from here on as well costs 16 registers = one wave per SIMD, and loses more than the round trip it saves.)
+    // everything that does not depend on the keypoint is requested up front -- the lane's patch-offset table and the counts of
+    // ALL levels in one batch (not one load per loop trip).
     const uint4 ta = moment_tab[2 * lane], tb = moment_tab[2 * lane + 1];
+    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
     int cnt[MS_MAX_LEVELS];
 #pragma unroll
     for (int l = 0; l < MS_MAX_LEVELS; ++l) cnt[l] = l < levels ? det_count[f * levels + l] : 0;
     // segment table of this frame: [tracks][level 0][level 1]...
     const int nt = trk_count[f];
-    int level = -1, idx = slot, total = nt;
-    bool is_track = false;
-    if (slot < nt) is_track = true;
-    else idx = slot - nt;
+    int total = nt;
 #pragma unroll
-    for (int l = 0; l < MS_MAX_LEVELS; ++l) {
-        const int c = cnt[l];
-        if (!is_track && level < 0 && l < levels) { if (idx < c) level = l; else idx -= c; }
-        total += c;
+    for (int l = 0; l < MS_MAX_LEVELS; ++l) total += cnt[l];
+    if (slot0 == 0 && lane == 0) out_count[f] = total;
+    if (slot0 >= total) return;
+    DescKp K[kDescPerWave];
+#pragma unroll
+    for (int k = 0; k < kDescPerWave; ++k) {
+        const int slot = slot0 + k;
+        K[k].valid = slot < total;
+        const int sl = K[k].valid ? slot : slot0;            // an absent second keypoint mirrors the first (its results are not stored)
+        if (sl < nt) {
+            const uint64_t s2 = (uint64_t)f * g->max_tracks + sl;
+            K[k].x = trk_x[s2]; K[k].y = trk_y[s2]; K[k].ox = trk_px[s2]; K[k].oy = trk_py[s2]; K[k].oct = g->lk_level; K[k].tid_out = trk_id[s2];
+        } else {
+            int level = -1, idx = sl - nt;
+#pragma unroll
+            for (int l = 0; l < MS_MAX_LEVELS; ++l)
+                if (level < 0 && l < levels) { if (idx < cnt[l]) level = l; else idx -= cnt[l]; }
+            const uint64_t s2 = (uint64_t)f * g->max_kpts + g->L[level].det_base + idx;
+            K[k].x = det_x[s2]; K[k].y = det_y[s2]; K[k].oct = level; K[k].tid_out = -1;
+            K[k].ox = __fmul_rn((float)K[k].x, g->L[level].scale);     // orb_extractor.cpp:156
+            K[k].oy = __fmul_rn((float)K[k].y, g->L[level].scale);
+        }
     }
-    if (slot == 0 && lane == 0) out_count[f] = total;
-    if (slot >= total) return;
-    int x, y, oct, tid_out;
-    float ox, oy;
-    if (is_track) {
-        const uint64_t s = (uint64_t)f * g->max_tracks + slot;
-        x = trk_x[s]; y = trk_y[s]; ox = trk_px[s]; oy = trk_py[s]; oct = g->lk_level; tid_out = trk_id[s];
-    } else {
-        const uint64_t s = (uint64_t)f * g->max_kpts + g->L[level].det_base + idx;
-        x = det_x[s]; y = det_y[s]; oct = level; tid_out = -1;
-        ox = __fmul_rn((float)x, g->L[level].scale);     // orb_extractor.cpp:156
-        oy = __fmul_rn((float)y, g->L[level].scale);
-    }
-    int pitch;
-    const uint8_t *img = level_ptr(src, g, f, oct, pitch);
-    const uint8_t *ctr = img + (int64_t)y * pitch + x;
-    // O1: moments.  The 961 offsets of the 31x31 box are strided over the 64 lanes (offset lane + 64 k); the (u, v) of each is a
+    // O1: moments.  The 961 offsets of the 31x31 box are strided over the 64 lanes (offset lane + 64 j); the (u, v) of each is a
     // host-built table entry (two int8, zero outside the radius-15 disc), 32 bytes per lane = two 16-byte loads; the pixel gathers
     // use the wave-uniform patch centre as scalar base, so an offset costs one multiply-add.
-    int m10 = 0, m01 = 0;
-    {
-        const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-        int I[16], uu[16], vv[16];
+    int I[kDescPerWave][16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {                 // 16 gathers in flight
-            uu[k] = __builtin_amdgcn_sbfe((int)tw[k >> 1], 16 * (k & 1), 8);
-            vv[k] = __builtin_amdgcn_sbfe((int)tw[k >> 1], 16 * (k & 1) + 8, 8);
-            I[k] = ctr[vv[k] * pitch + uu[k]];
-        }
+    for (int k = 0; k < kDescPerWave; ++k) {
+        int pitch;
+        const uint8_t *img = level_ptr(src, g, f, K[k].oct, pitch);
+        // base = top-left corner of the 31x31 box and NON-NEGATIVE offsets (the table stores u + 15, v + 15): with a wave-uniform
+        // base the compiler addresses these gathers as scalar base + unsigned 32-bit lane offset, which a negative offset breaks
+        const uint8_t *corner = img + (int64_t)(K[k].y - kHalfPatch) * pitch + (K[k].x - kHalfPatch);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { m10 += uu[k] * I[k]; m01 += vv[k] * I[k]; }
+        for (int j = 0; j < 16; ++j)                   // 16 gathers in flight per keypoint
+            I[k][j] = corner[__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1) + 8, 8) * (uint32_t)pitch + __builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1), 8)];
     }
-    m10 = wave_sum(m10); m01 = wave_sum(m01);
-    const float angle_deg = dev_fast_atan2((float)m01, (float)m10);
-    // O2: steered BRIEF on the blurred level
-    const float angle = (float)__ddiv_rn(__dmul_rn((double)angle_deg, M_PI), 180.0);
-    const float ca = dev_cos(angle), sa = dev_sin(angle);
-    const int bp = g->L[oct].pitch;
-    const uint8_t *bctr = blur_ptr(src, g, f, oct) + (int64_t)y * bp + x;
-    unsigned long long bits[4];
+    float angle_deg[kDescPerWave], ca[kDescPerWave], sa[kDescPerWave];
+#pragma unroll
+    for (int k = 0; k < kDescPerWave; ++k) {
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            m10 += ((int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1), 8) - kHalfPatch) * I[k][j];
+            m01 += ((int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1) + 8, 8) - kHalfPatch) * I[k][j];
+        }
+        m10 = wave_sum(m10); m01 = wave_sum(m01);
+        angle_deg[k] = dev_fast_atan2((float)m01, (float)m10);
+        const float angle = (float)__ddiv_rn(__dmul_rn((double)angle_deg[k], M_PI), 180.0);
+        ca[k] = dev_cos(angle); sa[k] = dev_sin(angle);
+    }
+    // O2: steered BRIEF on the blurred level; the lane's point pairs are shared by the wave's keypoints
+    unsigned long long bits[kDescPerWave][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float4 pt = pattern_f[q * 64 + lane];             // the test's two points, already float
         const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-        const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa), __fmul_rn(y2, ca)));
-        const int c2 = __float2int_rn(__fsub_rn(__fmul_rn(x2, ca), __fmul_rn(y2, sa)));
-        bits[q] = __ballot(bctr[r1 * bp + c1] < bctr[r2 * bp + c2]);
+#pragma unroll
+        for (int k = 0; k < kDescPerWave; ++k) {
+            const int bp = g->L[K[k].oct].pitch;
+            const uint8_t *bcorner = blur_ptr(src, g, f, K[k].oct) + (int64_t)(K[k].y - kPatchRadius) * bp + (K[k].x - kPatchRadius);   // steered points stay within +-19
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa[k]), __fmul_rn(y1, ca[k])));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca[k]), __fmul_rn(y1, sa[k])));
+            const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa[k]), __fmul_rn(y2, ca[k])));
+            const int c2 = __float2int_rn(__fsub_rn(__fmul_rn(x2, ca[k]), __fmul_rn(y2, sa[k])));
+            bits[k][q] = __ballot(bcorner[(uint32_t)(r1 + kPatchRadius) * (uint32_t)bp + (uint32_t)(c1 + kPatchRadius)] <
+                                  bcorner[(uint32_t)(r2 + kPatchRadius) * (uint32_t)bp + (uint32_t)(c2 + kPatchRadius)]);
+        }
     }
-    const uint64_t o = (uint64_t)f * g->capacity + slot;
-    if (lane < 8) out_desc[o * 8 + lane] = (uint32_t)(bits[lane >> 1] >> ((lane & 1) * 32));
-    if (lane == 0) { out_x[o] = ox; out_y[o] = oy; out_angle[o] = angle_deg; out_octave[o] = oct; out_track[o] = tid_out; }
+#pragma unroll
+    for (int k = 0; k < kDescPerWave; ++k) {
+        if (!K[k].valid) continue;                              // wave-uniform
+        const uint64_t o = (uint64_t)f * g->capacity + slot0 + k;
+        if (lane < 8) out_desc[o * 8 + lane] = (uint32_t)(bits[k][lane >> 1] >> ((lane & 1) * 32));
+        if (lane == 0) { out_x[o] = K[k].ox; out_y[o] = K[k].oy; out_angle[o] = angle_deg[k]; out_octave[o] = K[k].oct; out_track[o] = K[k].tid_out; }
+    }
 }
 
 }  // namespace
@@ -1001,13 +1024,14 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         static const int8_t pattern[1024] = {
 #include "orb_pattern.inc"
         };
-        std::vector<uint16_t> mt(64 * 16, 0);
+        std::vector<uint16_t> mt(64 * 16, (uint16_t)(kHalfPatch | (kHalfPatch << 8)));      // entries are (u + 15, v + 15)
         for (int lane = 0; lane < 64; ++lane)
             for (int k = 0; k < 16; ++k) {
                 const int i = lane + 64 * k;
                 if (i >= 31 * 31) continue;
                 const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
-                if (std::abs(u) <= G.umax[std::min(std::abs(v), 15)]) mt[lane * 16 + k] = (uint16_t)((u & 0xFF) | ((v & 0xFF) << 8));
+                mt[lane * 16 + k] = (uint16_t)(kHalfPatch | (kHalfPatch << 8));                 // outside the disc: the centre pixel with weight (0, 0)
+                if (std::abs(u) <= G.umax[std::min(std::abs(v), 15)]) mt[lane * 16 + k] = (uint16_t)((u + kHalfPatch) | ((v + kHalfPatch) << 8));
             }
         std::vector<float> pf(1024);
         for (int i = 0; i < 1024; ++i) pf[i] = (float)pattern[i];
@@ -1159,7 +1183,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
                        o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
     MS_KERNEL_CHECK(c, "k_tracks");
     MS_STAGE_MARK();
-    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
+    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
                        o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count, G.levels);
     MS_KERNEL_CHECK(c, "k_describe");
