@@ -817,36 +817,54 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
             K[k].oy = __fmul_rn((float)K[k].y, g->L[level].scale);
         }
     }
-    // O1: moments.  The 961 offsets of the 31x31 box are strided over the 64 lanes (offset lane + 64 j); the (u, v) of each is a
-    // host-built table entry (two int8, zero outside the radius-15 disc), 32 bytes per lane = two 16-byte loads; the pixel gathers
-    // use the wave-uniform patch centre as scalar base, so an offset costs one multiply-add.
-    int I[kDescPerWave][16];
+    // Both patches of the keypoint are first copied into the wave's LDS slab with coalesced row loads (31 rows x 32 B of the level,
+    // 39 rows x 40 B of its blurred twin: 11 wave-wide dword loads that touch ~120 cache lines), and the 16 moment samples and 8
+    // BRIEF samples of every lane are byte reads from LDS.  Gathered straight from memory the same samples were 24 byte loads that
+    // touch ~400 lines per keypoint, and the texture addresser's line rate, not HBM or latency, set the kernel's pace.
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescPerWave][31 * 32 + 39 * 40];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
         int pitch;
         const uint8_t *img = level_ptr(src, g, f, K[k].oct, pitch);
-        // base = top-left corner of the 31x31 box and NON-NEGATIVE offsets (the table stores u + 15, v + 15): with a wave-uniform
-        // base the compiler addresses these gathers as scalar base + unsigned 32-bit lane offset, which a negative offset breaks
         const uint8_t *corner = img + (int64_t)(K[k].y - kHalfPatch) * pitch + (K[k].x - kHalfPatch);
+        uint32_t *pu = reinterpret_cast<uint32_t *>(&s_patch[wv][k][0]);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)                   // 16 gathers in flight per keypoint
-            I[k][j] = corner[__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1) + 8, 8) * (uint32_t)pitch + __builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1), 8)];
+        for (int t = 0; t < 4; ++t) {                                   // 31 rows x 8 dwords
+            const int i = lane + 64 * t, r = i >> 3, c4 = i & 7;
+            if (i < 31 * 8) pu[i] = reinterpret_cast<const U32u *>(corner + (uint32_t)r * (uint32_t)pitch + 4u * c4)->v;
+        }
+        const int bp = g->L[K[k].oct].pitch;
+        const uint8_t *bcorner = blur_ptr(src, g, f, K[k].oct) + (int64_t)(K[k].y - kPatchRadius) * bp + (K[k].x - kPatchRadius);
+        uint32_t *pb = reinterpret_cast<uint32_t *>(&s_patch[wv][k][31 * 32]);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {                                   // 39 rows x 10 dwords
+            const int i = lane + 64 * t, r = i / 10, c4 = i - 10 * r;
+            if (i < 39 * 10) pb[i] = reinterpret_cast<const U32u *>(bcorner + (uint32_t)r * (uint32_t)bp + 4u * c4)->v;   // the 40th byte (x + 20) is never sampled; it may be the next row's first
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // O1: moments.  The 961 offsets of the 31x31 box are strided over the 64 lanes (offset lane + 64 j); the (u + 15, v + 15) of each
+    // is a host-built table entry (two bytes, the centre with weight zero outside the radius-15 disc), 32 bytes per lane.
     float angle_deg[kDescPerWave], ca[kDescPerWave], sa[kDescPerWave];
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
+        const uint8_t *pu = &s_patch[wv][k][0];
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            m10 += ((int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1), 8) - kHalfPatch) * I[k][j];
-            m01 += ((int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1) + 8, 8) - kHalfPatch) * I[k][j];
+            const int ub = (int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1), 8), vb = (int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1) + 8, 8);
+            const int I = pu[vb * 32 + ub];
+            m10 += (ub - kHalfPatch) * I;
+            m01 += (vb - kHalfPatch) * I;
         }
         m10 = wave_sum(m10); m01 = wave_sum(m01);
         angle_deg[k] = dev_fast_atan2((float)m01, (float)m10);
         const float angle = (float)__ddiv_rn(__dmul_rn((double)angle_deg[k], M_PI), 180.0);
         ca[k] = dev_cos(angle); sa[k] = dev_sin(angle);
     }
-    // O2: steered BRIEF on the blurred level; the lane's point pairs are shared by the wave's keypoints
+    // O2: steered BRIEF on the blurred patch; the lane's point pairs are shared by the wave's keypoints
     unsigned long long bits[kDescPerWave][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -854,14 +872,12 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
         const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
 #pragma unroll
         for (int k = 0; k < kDescPerWave; ++k) {
-            const int bp = g->L[K[k].oct].pitch;
-            const uint8_t *bcorner = blur_ptr(src, g, f, K[k].oct) + (int64_t)(K[k].y - kPatchRadius) * bp + (K[k].x - kPatchRadius);   // steered points stay within +-19
+            const uint8_t *pb = &s_patch[wv][k][31 * 32];
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa[k]), __fmul_rn(y1, ca[k])));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca[k]), __fmul_rn(y1, sa[k])));
             const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa[k]), __fmul_rn(y2, ca[k])));
             const int c2 = __float2int_rn(__fsub_rn(__fmul_rn(x2, ca[k]), __fmul_rn(y2, sa[k])));
-            bits[k][q] = __ballot(bcorner[(uint32_t)(r1 + kPatchRadius) * (uint32_t)bp + (uint32_t)(c1 + kPatchRadius)] <
-                                  bcorner[(uint32_t)(r2 + kPatchRadius) * (uint32_t)bp + (uint32_t)(c2 + kPatchRadius)]);
+            bits[k][q] = __ballot(pb[(r1 + kPatchRadius) * 40 + (c1 + kPatchRadius)] < pb[(r2 + kPatchRadius) * 40 + (c2 + kPatchRadius)]);
         }
     }
 #pragma unroll
@@ -981,7 +997,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     int rc = MS_OK;
     auto A = [&](int r) { if (rc == MS_OK) rc = r; };
     A(dev_calloc(ctx, &o->d_geom, 1));
-    A(dev_calloc(ctx, &o->d_slab, B * G.slab_stride));
+    A(dev_calloc(ctx, &o->d_slab, B * G.slab_stride + 256));   // + slack: k_describe copies 40-byte patch rows whose last (unused) byte may lie one past a plane
     A(dev_calloc(ctx, &o->d_cand, B * G.cand_stride));
     A(dev_calloc(ctx, &o->d_cand_count, B * MS_MAX_LEVELS));
     A(dev_calloc(ctx, &o->d_det_count, B * MS_MAX_LEVELS));
