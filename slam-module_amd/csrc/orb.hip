@@ -324,6 +324,10 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
 }
 
+__device__ __forceinline__ int mbcnt64(unsigned long long m) {      // number of set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // Compass pre-test on packed 16-bit lanes (pixels 0,2 of a lane's dword in "E" registers, pixels 1,3 in "O").
 // One v_perm_b32 both shifts a 4-byte window out of a dword pair and zero-extends two of its bytes to 16-bit lanes.
 // "At least two of N,S,E,W brighter than c+t" is "the SECOND LARGEST of the four exceeds c+t" (and likewise the second smallest
@@ -396,11 +400,11 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
                                               unsigned long long *__restrict__ stamps, TileMap tm, int levels) {
     long long t_prev = STAMP ? clock64() : 0;
     auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
-    __shared__ uint8_t s_sc[kFastPosRows][264];
-    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPositions + 8];   // compass survivors (+ dump slot); reused as the NMS output buffer
-    __shared__ uint16_t s_cl[kFastPositions];                                // corners (position ids)
-    __shared__ int s_np, s_nc, s_m, s_base;
-    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pre);              // 2004 keys >= 124*7 possible NMS survivors
+    __shared__ uint8_t s_sc[kFastPosRows][256];                                      // score tile (columns 2..253 are touched)
+    __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPositions + 8];     // compass survivors (+ dump slot); each wave's corners overwrite its own consumed slots
+    __shared__ __attribute__((aligned(16))) uint8_t s_pix[(kFastPosRows + 6) * 256]; // the tile's pixels (image rows Y0-4 .. Y0+17) for the ring reads; NMS keys afterwards
+    __shared__ int s_np, s_m, s_base;
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pix);              // 1408 keys >= 124*7 possible NMS survivors
     int t = blockIdx.x;
     const int l = tile_level(tm, levels, t);
     t -= tm.base[l];
@@ -422,8 +426,12 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
 #pragma unroll
         for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
     }
-    if (tid == 0) { s_np = 0; s_nc = 0; s_m = 0; }
-    for (int i = tid; i < kFastPosRows * 264 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
+    if (tid == 0) { s_np = 0; s_m = 0; }
+    for (int i = tid; i < kFastPosRows * 256 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
+    // the rows go to LDS as well: wave w owns tile rows 4w .. 4w+3 (image rows Y0-4+4w ..), the last wave also the six below
+#pragma unroll
+    for (int r = 0; r < kFastRowsPerWave + 6; ++r)
+        if (r < kFastRowsPerWave || wave == 3) reinterpret_cast<uint32_t *>(s_pix)[(wave * kFastRowsPerWave + r) * 64 + lane] = rows[r];
     __syncthreads();
     stamp(0);      // setup + LDS clear
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
@@ -467,26 +475,40 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     // ---- phase A2 + B: the survivors are SCORED directly (corner <=> score > threshold), on packed 16-bit lanes:
     //      P[k] = (d[k], d[k+8]) with d = centre - ring pixel; the sliding min / max of 9 over the circular ring is four
     //      v_pk_min_i16 / v_pk_max_i16 levels (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
+    //      The ring comes from the tile's pixels in LDS (17 byte reads with immediate offsets from one base): as 7 wide global loads per
+    //      survivor the texture addresser had ~30 cache lines to look up per instruction.  A wave appends its corners IN PLACE, into the
+    //      slots of the survivor list it has already consumed (slots 64w + 256i + j belong to wave w), so no second list is needed.
     const int np = s_np;
+    int ncw = 0;                                                         // corners of this wave so far (wave-uniform)
     for (int i = tid; i < np; i += 256) {
         const int e = s_pre[i], pr = e >> 8, c = e & 255;
-        const int px = X0 - 4 + c;
-        const uint8_t *p = img + (uint64_t)(Y0 - 1 + pr) * pitch + px;
+        const uint8_t *q = s_pix + pr * 256 + (c - 3);                   // top-left of the 7x7 box: tile row pr + 3 is the centre's
         uint32_t R[9];
-        // seven unaligned dword / dwordx2 loads cover the ring when no lane's widest row (x-2 .. x+5) leaves the image row;
-        // waves holding a survivor in the last columns fall back to 17 byte loads
-        if (__ballot(px + 5 >= w) == 0) fast_ring_load_wide(p, pitch, R); else fast_ring_load(p, pitch, R);
+        {
+            const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+            const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+            R[8] = q[3 * 256 + 3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) R[k] = (uint32_t)q[(3 + rdy[k]) * 256 + 3 + rdx[k]] | ((uint32_t)q[(3 + rdy[k + 8]) * 256 + 3 + rdx[k + 8]] << 16);
+        }
         const int best = fast_ring_score(R);
-        if (best > thr) { s_sc[pr][c] = (uint8_t)best; s_cl[atomicAdd(&s_nc, 1)] = (uint16_t)e; }
+        const bool corner = best > thr;
+        const unsigned long long cm = __ballot(corner);
+        if (corner) {
+            const int slot = ncw + mbcnt64(cm);
+            s_sc[pr][c] = (uint8_t)best;
+            s_pre[64 * wave + 256 * (slot >> 6) + (slot & 63)] = (uint16_t)e;
+        }
+        ncw += (int)__popcll(cm);
     }
+    ncw = __builtin_amdgcn_readfirstlane(ncw);          // lanes that left the loop early missed the last updates; lane 0 stays to the end
     stamp(3);      // A2 own work
     __syncthreads();
     stamp(4);      // A2 barrier wait
     // ---- phase C: 3x3 strict-maximum NMS, dense over the corner list (only outputs: px X0..X0+247 = columns 4..251,
     //      rows Y0..Y0+13 = position rows 1..14; the halo corners only serve as neighbours)
-    const int nc = s_nc;
-    for (int i = tid; i < nc; i += 256) {
-        const int e = s_cl[i], pr = e >> 8, c = e & 255;
+    for (int i = lane; i < ncw; i += 64) {                               // every wave walks its own corner sublist
+        const int e = s_pre[64 * wave + 256 * (i >> 6) + (i & 63)], pr = e >> 8, c = e & 255;
         const int px = X0 - 4 + c, y = Y0 - 1 + pr;
         if (pr < 1 || pr > kFastRows || c < 4 || c > 251 || px >= w || y >= h) continue;
         const int sc = s_sc[pr][c];
