@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t *src, uint64_
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 typedef short s2_t __attribute__((ext_vector_type(2)));
 
+// Everything k_resize needs about its two levels, by value in the kernel arguments: the launch is per level, and reading the
+// geometry table instead put nine dependent scalar round trips in front of every wave's first pixel load.
+struct ResizeArgs {
+    const uint8_t *src; uint64_t src_frame_stride; int32_t src_pitch, sw;      // level l-1
+    uint8_t *dst; uint64_t dst_frame_stride; int32_t dst_pitch, dw, dh;        // level l
+};
+
 struct ResizeTab {
     const int16_t *xtab;   // [dw][4] : sx, a0, a1, 0
     const int16_t *ytab;   // [dh][4] : sy0, sy1 (clamped rows), b0, b1
@@ -113,16 +120,16 @@ __device__ __forceinline__ Window3 window_load(const uint8_t *row, int base, int
 }
 
 template <bool WIDE>   // WIDE: tap window of 4 pixels may exceed 8 bytes (scale factor > 2) -> per-tap byte loads
-__global__ __launch_bounds__(256) void k_resize(FrameSrc src, const PyrGeom *g, int l, ResizeTab T) {
-    const LevelGeom &D = g->L[l];
-    const int sw = g->L[l - 1].w;
+__global__ __launch_bounds__(256) void k_resize(ResizeArgs R, ResizeTab T) {
+    const struct { int w, h, pitch; } D = {R.dw, R.dh, R.dst_pitch};
+    const int sw = R.sw;
     const int f = blockIdx.z;
     const int dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kResizeRows;   // wave-uniform (SGPR): row addresses stay scalar
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     if (dy0 >= D.h || dx0 >= D.w) return;
-    int spitch;
-    const uint8_t *S = level_ptr(src, g, f, l - 1, spitch);
-    uint8_t *dst = src.slab + (uint64_t)f * g->slab_stride + D.img_off;
+    const int spitch = R.src_pitch;
+    const uint8_t *S = R.src + (uint64_t)f * R.src_frame_stride;
+    uint8_t *dst = R.dst + (uint64_t)f * R.dst_frame_stride;
     // both tables are padded to whole groups (last entry repeated), so a lane's four columns are two 16-byte loads
     const uint4 xa = reinterpret_cast<const uint4 *>(T.xtab)[dx0 >> 1], xb = reinterpret_cast<const uint4 *>(T.xtab)[(dx0 >> 1) + 1];
     const short4 xt[4] = {__builtin_bit_cast(short4, make_uint2(xa.x, xa.y)), __builtin_bit_cast(short4, make_uint2(xa.z, xa.w)),
@@ -1194,8 +1201,13 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     for (int l = 1; l < G.levels; ++l) {
         dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4 * kResizeRows), n_frames);
         const ResizeTab T{o->d_xtab[l], o->d_ytab[l]};
-        if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, src, o->d_geom, l, T);
-        else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, src, o->d_geom, l, T);
+        ResizeArgs RA{};
+        if (l == 1) { RA.src = src.lvl0; RA.src_frame_stride = src.lvl0_frame_stride; RA.src_pitch = src.lvl0_pitch; }
+        else { RA.src = src.slab + G.L[l - 1].img_off; RA.src_frame_stride = G.slab_stride; RA.src_pitch = G.L[l - 1].pitch; }
+        RA.sw = G.L[l - 1].w;
+        RA.dst = src.slab + G.L[l].img_off; RA.dst_frame_stride = G.slab_stride; RA.dst_pitch = G.L[l].pitch; RA.dw = G.L[l].w; RA.dh = G.L[l].h;
+        if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, RA, T);
+        else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, RA, T);
         MS_KERNEL_CHECK(c, "k_resize");
     }
     MS_STAGE_MARK();
