@@ -59,6 +59,11 @@ __device__ __forceinline__ int tile_level(const TileMap &tm, int levels, int t) 
     return l;
 }
 
+// What the tiled kernels (k_blur, k_fast) need about a level, also BY VALUE in the kernel arguments: one batch of scalar loads from the
+// kernel-argument segment once the block knows its level, instead of a chain of dependent loads from the geometry table behind branches.
+struct TileLevel { int32_t w, h, pitch, btiles_x, ftiles_x, cand_cap; uint32_t btiles_inv, ftiles_inv; uint64_t img_off, blur_off, cand_off; };
+struct TileLevels { TileLevel L[MS_MAX_LEVELS]; uint64_t slab_stride, cand_stride; int32_t levels, fast_threshold; };
+
 struct FrameSrc {          // where pyramid level 0 lives for this call
     const uint8_t *lvl0;
     uint64_t lvl0_frame_stride;
@@ -242,19 +247,19 @@ __device__ __forceinline__ int wave_scan_add(int v) {
 constexpr int kBlurSeg = 248;   // outputs per wave row segment
 constexpr int kBlurRows = 8;    // output rows per wave (kBlurRows + 6 input rows are loaded: 1.75x read amplification through L1)
 
-__global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, TileMap tm, int levels) {
+__global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileMap tm) {
     int t = blockIdx.x;
-    const int l = tile_level(tm, levels, t);
+    const int l = tile_level(tm, TL.levels, t);
     t -= tm.base[l];
-    const LevelGeom &G = g->L[l];
+    const TileLevel G = TL.L[l];                       // one batch of loads; everything below is arithmetic on it
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform (SGPR): the 14 row addresses are scalar work
     const int trow = G.btiles_x == 1 ? t : (int)__umulhi((uint32_t)t, G.btiles_inv);     // t / btiles_x without the division sequence (2^32 / 1 does not fit)
     const int x = (t - trow * G.btiles_x) * kBlurSeg - 4 + lane * 4;
     const int y0 = trow * (4 * kBlurRows) + wave * kBlurRows;
     const int f = blockIdx.y, w = G.w, h = G.h;
     if (y0 >= h) return;
-    int pitch;
-    const uint8_t *img = level_ptr(src, g, f, l, pitch);
+    const int pitch = l == 0 ? src.lvl0_pitch : G.pitch;
+    const uint8_t *img = l == 0 ? src.lvl0 + (uint64_t)f * src.lvl0_frame_stride : src.slab + (uint64_t)f * TL.slab_stride + G.img_off;
     uint32_t e[kBlurRows + 6], o[kBlurRows + 6];
     // the column test is the same for every row of a lane: ONE wave-uniform branch picks the plain-dword path for whole waves
     // (per-load branches cost scalar instructions, and the scalar unit is shared by the CU's four SIMDs)
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, const PyrGeom *g, Ti
             o[r] = (d >> 8) & 0x00FF00FFu;
         }
     }
-    uint8_t *dst = blur_ptr(src, g, f, l);
+    uint8_t *dst = src.slab + (uint64_t)f * TL.slab_stride + G.blur_off;
 #pragma unroll
     for (int j = 0; j < kBlurRows; ++j) {
         const uint32_t Ce = vsum7(e + j), Co = vsum7(o + j);            // columns (x, x+2) and (x+1, x+3)
@@ -404,7 +409,7 @@ __device__ __forceinline__ int fast_ring_score(const uint32_t R[9]) {
 
 template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
 __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
-                                              unsigned long long *__restrict__ stamps, TileMap tm, int levels) {
+                                              unsigned long long *__restrict__ stamps, TileMap tm, TileLevels TL) {
     long long t_prev = STAMP ? clock64() : 0;
     auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
     __shared__ uint8_t s_sc[kFastPosRows][256];                                      // score tile (columns 2..253 are touched)
@@ -413,14 +418,14 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     __shared__ int s_np, s_m, s_base;
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pix);              // 1408 keys >= 124*7 possible NMS survivors
     int t = blockIdx.x;
-    const int l = tile_level(tm, levels, t);
+    const int l = tile_level(tm, TL.levels, t);
     t -= tm.base[l];
-    const LevelGeom &G = g->L[l];
+    const TileLevel G = TL.L[l];                       // one batch of loads; everything below is arithmetic on it
     const int trow = G.ftiles_x == 1 ? t : (int)__umulhi((uint32_t)t, G.ftiles_inv);     // t / ftiles_x without the division sequence (2^32 / 1 does not fit)
     const int X0 = (t - trow * G.ftiles_x) * kFastSeg, Y0 = trow * kFastRows;
-    const int f = blockIdx.y, w = G.w, h = G.h, thr = g->fast_threshold;
-    int pitch;
-    const uint8_t *img = level_ptr(src, g, f, l, pitch);
+    const int f = blockIdx.y, w = G.w, h = G.h, thr = TL.fast_threshold;
+    const int pitch = l == 0 ? src.lvl0_pitch : G.pitch;
+    const uint8_t *img = l == 0 ? src.lvl0 + (uint64_t)f * src.lvl0_frame_stride : src.slab + (uint64_t)f * TL.slab_stride + G.img_off;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, in an SGPR: row addresses stay scalar
     // The wave's 10 image rows are requested FIRST, so their latency runs under the LDS clear and the barrier.
     const int x = X0 - 4 + 4 * lane;
@@ -528,12 +533,12 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     stamp(6);      // NMS barrier wait
     const int m = s_m;
     if (m == 0) return;
-    if (tid == 0) s_base = atomicAdd(&cand_count[f * g->levels + l], m);
+    if (tid == 0) s_base = atomicAdd(&cand_count[f * TL.levels + l], m);
     __syncthreads();
     stamp(7);      // global atomic + barrier
     for (int i = tid; i < m; i += 256) {
         const int pos = s_base + i;
-        if (pos < G.cand_cap) cand[(uint64_t)f * g->cand_stride + G.cand_off + pos] = s_out[i];
+        if (pos < G.cand_cap) cand[(uint64_t)f * TL.cand_stride + G.cand_off + pos] = s_out[i];
     }
 }
 
@@ -929,6 +934,7 @@ struct ms_orb {
     PyrGeom geom{};
     PyrGeom *d_geom = nullptr;
     TileMap blur_tiles{}, fast_tiles{};
+    TileLevels tile_levels{};          // per-level geometry of the tiled kernels, passed by value
     uint8_t *d_slab = nullptr;
     uint32_t *d_cand = nullptr;
     int32_t *d_cand_count = nullptr, *d_det_count = nullptr, *d_trk_count = nullptr;
@@ -1016,11 +1022,16 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         L.btiles_inv = (uint32_t)(((1ull << 32) + L.btiles_x - 1) / L.btiles_x); L.ftiles_inv = (uint32_t)(((1ull << 32) + L.ftiles_x - 1) / L.ftiles_x);
     }
     G.btiles_total = bt; G.ftiles_total = ft;
+    for (int l = 0; l < cfg->levels; ++l) {
+        const LevelGeom &L = G.L[l];
+        o->tile_levels.L[l] = TileLevel{L.w, L.h, L.pitch, L.btiles_x, L.ftiles_x, L.cand_cap, L.btiles_inv, L.ftiles_inv, L.img_off, L.blur_off, L.cand_off};
+    }
     for (int l = 0; l <= MS_MAX_LEVELS; ++l) {
         o->blur_tiles.base[l] = l < cfg->levels ? G.L[l].btile_base : bt;
         o->fast_tiles.base[l] = l < cfg->levels ? G.L[l].ftile_base : ft;
     }
     G.slab_stride = ms_align_up(off, 256); G.cand_stride = coff;
+    o->tile_levels.slab_stride = G.slab_stride; o->tile_levels.cand_stride = G.cand_stride; o->tile_levels.levels = G.levels; o->tile_levels.fast_threshold = G.fast_threshold;
     o->lvl0_off = G.L[0].img_off; o->lvl0_pitch = G.L[0].pitch;
     const size_t B = cfg->max_batch, cap = G.capacity;
     int rc = MS_OK;
@@ -1213,11 +1224,11 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     MS_STAGE_MARK();
     // (k_blur was tried on a second stream beside k_fast: no gain -- the detection kernel already fills the chip -- and
     // overlapped launches have no well-defined per-kernel duration, so everything stays on the context stream.)
-    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->blur_tiles, G.levels);
+    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->tile_levels, o->blur_tiles);
     MS_KERNEL_CHECK(c, "k_blur");
     MS_STAGE_MARK();
-    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->fast_tiles, G.levels);
-    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->fast_tiles, G.levels);
+    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->fast_tiles, o->tile_levels);
+    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->fast_tiles, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
     if (o->cfg.min_distance > 0.f)
