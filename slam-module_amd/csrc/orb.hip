@@ -116,7 +116,7 @@ __device__ __forceinline__ int resize_px(uint64_t w0, uint64_t w1, int k, int a0
     return min(max(v, 0), 255);
 }
 
-constexpr int kResizeRows = 4;   // destination rows per lane: the table fetch is paid once and 24 source dwords are in flight per lane
+constexpr int kResizeRows = 5;   // destination rows per lane: the table fetch is paid once and 30 source dwords are in flight per lane (3..6 measured in one session: 0.571, 0.565, 0.555, 0.556 ms)
 
 struct Window3 { uint32_t d0, d1, d2; };
 __device__ __forceinline__ Window3 window_load(const uint8_t *row, int base, int last_dword) {
@@ -245,7 +245,7 @@ __device__ __forceinline__ int wave_scan_add(int v) {
 }
 
 constexpr int kBlurSeg = 248;   // outputs per wave row segment
-constexpr int kBlurRows = 8;    // output rows per wave (kBlurRows + 6 input rows are loaded: 1.75x read amplification through L1)
+constexpr int kBlurRows = 18;   // output rows per wave (+ 6 halo rows loaded).  Measured in one session: 8 -> 0.61 ms, 14 -> 0.53, 16 -> 0.67 (64-row tiles: row starts collide), 18 -> 0.51, 28 -> 0.51
 
 __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileMap tm) {
     int t = blockIdx.x;
