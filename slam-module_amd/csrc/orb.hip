@@ -344,13 +344,13 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) {      // number of
 // One v_perm_b32 both shifts a 4-byte window out of a dword pair and zero-extends two of its bytes to 16-bit lanes.
 // "At least two of N,S,E,W brighter than c+t" is "the SECOND LARGEST of the four exceeds c+t" (and likewise the second smallest
 // for darker): two sorted pairs give both order statistics in 8 packed min/max, then one packed subtract each exposes the sign.
-// Returns bit 15 of each 16-bit lane set where the pixel survives.
+// Returns bit 15 of each 16-bit lane set where the pixel survives (the lower bits are not meaningful).
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b))); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b))); }
 __device__ __forceinline__ uint32_t compass_pass(uint32_t n, uint32_t s_, uint32_t e, uint32_t w, uint32_t hi, uint32_t lo) {
     const uint32_t a = pk_max(n, s_), b = pk_min(n, s_), c = pk_max(e, w), d = pk_min(e, w);
     const uint32_t p = pk_min(a, c), q = pk_max(b, d);                    // the two middle values of the four
-    return (pk_sub(hi, pk_max(p, q)) | pk_sub(pk_min(p, q), lo)) & 0x80008000u;
+    return pk_sub(hi, pk_max(p, q)) | pk_sub(pk_min(p, q), lo);
 }
 
 // Ring of one FAST candidate: R[8] = centre, R[k] = ring pixels k and k+8 in the two 16-bit lanes.
@@ -407,6 +407,21 @@ __device__ __forceinline__ int fast_ring_score(const uint32_t R[9]) {
     return max(max((int)bright.x, (int)bright.y), -min((int)dark.x, (int)dark.y));
 }
 
+// One step of a lane's list append: the mask's top bit is shifted out into the carry (v_add_co m, m, m), lanes whose bit was set
+// write `entry` as a 16-bit value at LDS byte address `at` and advance it.  Exec is narrowed to the writers for the two
+// instructions in between and restored, so unset pixels cost no select and no store.
+__device__ __forceinline__ void list_append_top_bit(uint32_t &m, uint32_t &at, uint32_t entry) {
+    unsigned long long saved;
+    asm volatile("v_add_co_u32 %[m], vcc, %[m], %[m]\n\t"
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                 "ds_write_b16 %[at], %[e]\n\t"
+                 "v_add_u32 %[at], 2, %[at]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [m] "+v"(m), [at] "+v"(at), [sv] "=&s"(saved)
+                 : [e] "v"(entry)
+                 : "vcc", "memory");
+}
+
 template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
 __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
                                               unsigned long long *__restrict__ stamps, TileMap tm, TileLevels TL) {
@@ -449,15 +464,18 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
     {
         const uint32_t T2 = (uint32_t)thr * 0x00010001u;
-        uint32_t vmask = 0;                              // which of the lane's 4 pixels are valid positions (same for every row)
+        uint32_t vmask = 0;                              // which of the lane's 4 pixels are valid positions (same for every row): bit 8i + 7
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = 4 * lane + i, px = x + i;
-            vmask |= (uint32_t)(c >= 3 && c <= 252 && px >= 3 && px < w - 3) << i;
+            vmask |= (uint32_t)(c >= 3 && c <= 252 && px >= 3 && px < w - 3) << (8 * i + 7);
         }
+        uint32_t fr[kFastRowsPerWave];                   // survivors of row r: the top bit of byte i <-> pixel i
+        uint32_t cnt4 = 0;                               // their number, row r in byte r (a row has at most 250 positions, so sums over lanes stay in the byte)
 #pragma unroll
         for (int r = 0; r < kFastRowsPerWave; ++r) {
-            const int pr = wave * kFastRowsPerWave + r, y = Y0 - 1 + pr;
+            const int y = Y0 - 1 + wave * kFastRowsPerWave + r;
+            fr[r] = 0;
             if (y < 3 || y >= h - 3) continue;                           // wave-uniform
             const uint32_t C = rows[r + 3], Cn = rows[r + 6], Cs = rows[r];
             // neighbours' dwords by DPP wave shifts (one VALU op each); lanes 0 / 63 get a don't-care: their edge pixels are masked by vmask
@@ -470,16 +488,30 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
                                              hie, loe);
             const uint32_t po = compass_pass(__builtin_amdgcn_perm(0u, Cn, 0x0C030C01u), __builtin_amdgcn_perm(0u, Cs, 0x0C030C01u),     // bytes 1,3
                                              __builtin_amdgcn_perm(Rw, C, 0x0C060C04u), __builtin_amdgcn_perm(C, Lw, 0x0C040C02u), hio, loo);
-            const uint32_t flags = (((pe >> 15) & 1u) | ((po >> 14) & 2u) | ((pe >> 29) & 4u) | ((po >> 28) & 8u)) & vmask;   // pixel i -> bit i
-            if (flags) {
-                const int pos = atomicAdd(&s_np, __popc(flags));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {           // predicated by index: unset pixels write the dump slot (no exec-mask branches)
-                    const int at = (flags >> i) & 1u ? pos + __popc(flags & ((1u << i) - 1u)) : kFastPositions;
-                    s_pre[at] = (uint16_t)((pr << 8) | (4 * lane + i));
-                }
-            }
+            fr[r] = __builtin_amdgcn_perm(po, pe, 0x07030501u) & vmask;  // the sign bytes of the four pixels side by side (pixel i in byte i)
+            cnt4 += (uint32_t)__popc(fr[r]) << (8 * r);
         }
+        // ONE list append per wave, in the order row by row, lane by lane (neighbouring list slots = neighbouring pixels of a row, which
+        // keeps the ring reads of phase A2 off each other's LDS banks): a single DPP scan of the packed per-row counts gives every lane
+        // its offset inside each row, the row totals come out of lane 63, one lane adds their sum to the tile's counter.
+        const uint32_t incl = (uint32_t)wave_scan_add((int)cnt4);
+        const uint32_t tot4 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - cnt4;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_np, (int)((tot4 & 255u) + ((tot4 >> 8) & 255u) + ((tot4 >> 16) & 255u) + (tot4 >> 24)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t ebase = (uint32_t)((wave * kFastRowsPerWave) << 8) | (uint32_t)(4 * lane);
+        const uint32_t pre_addr = (uint32_t)(uintptr_t)s_pre;
+#pragma unroll
+        for (int r = 0; r < kFastRowsPerWave; ++r) {
+            uint32_t at = pre_addr + 2u * ((uint32_t)base + ((excl >> (8 * r)) & 255u));      // byte address of the lane's first slot of this row
+            base += (int)((tot4 >> (8 * r)) & 255u);
+            uint32_t f = fr[r];
+            list_append_top_bit(f, at, ebase + (r << 8) + 3); f <<= 7;
+            list_append_top_bit(f, at, ebase + (r << 8) + 2); f <<= 7;
+            list_append_top_bit(f, at, ebase + (r << 8) + 1); f <<= 7;
+            list_append_top_bit(f, at, ebase + (r << 8) + 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     stamp(1);      // A1 own work
     __syncthreads();
