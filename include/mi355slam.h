@@ -210,6 +210,26 @@ int ms_hamming_candidates(ms_ctx *ctx, const uint32_t *q_desc, int nq, const uin
 int ms_descriptor_medoid(ms_ctx *ctx, const uint32_t *desc_pool, const int32_t *obs_start, const int32_t *obs_idx, int n_points,
                          int max_obs, int32_t *best_local, int32_t *best_pool);
 
+/* ---- N3: vocabulary-tree descent behind BowIndex::transform (bow_index.cpp:59-93) -------------------------------------
+ * The reference hands every keypoint descriptor to DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features,
+ * bowVector, featureVector, levelsup = 4) (bow_index.cpp:86-92; DBoW2 is an external library, not in the reference tree).
+ * ms_bow_vocab_create takes the loaded vocabulary the way DBoW2 stores it -- HOST arrays: parent[i] = parent node id
+ * (node 0 = root, parent[0] ignored, every parent id smaller than its children's ids, as DBoW2's loaders and k-means builder
+ * produce), node_desc[i] = the node's 256-bit descriptor, node_weight[i] = its weight, node_word[i] = its word id for a leaf
+ * (-1 for inner nodes), depth_levels = the vocabulary's L -- and keeps a device copy laid out for the descent.
+ * ms_bow_transform walks n descriptors (DEVICE memory, 8 words each, 16-byte aligned) down the tree: at every level the child
+ * with the smallest Hamming distance, the first child (lowest node id) on ties; word[i] / weight[i] are the reached leaf's,
+ * node[i] is the node passed at level depth_levels - levels_up (0 = root when that level is <= 0; the leaf's own id when the
+ * leaf lies above that level, where DBoW2 leaves the value unset).  word = -1, weight = 0 for a vocabulary without words.
+ * weight / node may be NULL.  The BowVector / FeatureVector maps are assembled from these arrays by the host mirror
+ * (mi355slam::BowIndex::transform) in feature order, so the sums match the reference's. */
+typedef struct ms_bow_vocab ms_bow_vocab;
+int ms_bow_vocab_create(ms_ctx *ctx, int n_nodes, const int32_t *parent, const uint32_t *node_desc, const double *node_weight,
+                        const int32_t *node_word, int depth_levels, ms_bow_vocab **out);
+void ms_bow_vocab_destroy(ms_bow_vocab *vocab);
+int ms_bow_transform(ms_ctx *ctx, const ms_bow_vocab *vocab, const uint32_t *desc, int n, int levels_up,
+                     int32_t *word, double *weight, int32_t *node);
+
 /* FeatureSearch (feature_search.{hpp,cpp}): the keyframe's keypoints sorted by y.  Host helper; std::stable_sort, so points
  * with equal y keep index order (the reference's std::sort leaves that order unspecified).  sorted_idx[p] = keypoint index. */
 int ms_feature_search_sort(const float *x, const float *y, int n, float *sorted_x, float *sorted_y, int32_t *sorted_idx);

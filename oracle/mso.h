@@ -13,7 +13,7 @@
  *                                         pyramid geometry, keypoint quotas, BA problem construction
  *   PARITY UNPINNED vs the reference    : cv::resize / cv::GaussianBlur pixels, the corner detector
  *                                         (external tracker::FeatureDetector), cv::fastAtan2, the g2o
- *                                         LM iterates -- arithmetic lives in un-vendored, un-pinned
+ *                                         LM iterates, the DBoW2 tree descent (bow.c) -- arithmetic lives in un-vendored, un-pinned
  *                                         third-party code; restated here from their published
  *                                         algorithms and that restatement is the spec.
  */
@@ -152,6 +152,13 @@ int mso_features_around(const float *sx, const float *sy, int n, float x, float 
 
 /* ---- N4: MapPoint::updateDescriptor (map_point.cpp:75-116): index of the median-Hamming medoid, -1 when n == 0 ---- */
 int mso_descriptor_medoid(const uint32_t *desc /* [n][8] */, int n);
+
+/* ---- N3: DBoW2 vocabulary-tree descent behind BowIndex::transform (bow_index.cpp:59-93); see bow.c (PARITY UNPINNED) ---- */
+void mso_bow_transform(int n_nodes, const int32_t *parent, const uint32_t *node_desc, const double *node_weight,
+                       const int32_t *node_word, int depth_levels, const uint32_t *desc, int n, int levels_up,
+                       int32_t *word, double *weight, int32_t *node);
+int mso_bow_assemble(const int32_t *word, const double *weight, const int32_t *node, int n,
+                     int32_t *out_words, double *out_values, int32_t *fv_nodes, int32_t *fv_start, int32_t *fv_feat, int *n_fv);
 
 /* ---- B1-B6: bundle adjustment (bundle_adjuster.cpp:43-111, :141-394; g2o semantics restated in ba.c) ---- */
 typedef struct {

@@ -259,6 +259,30 @@ def descriptor_medoid(desc):
     return lib().mso_descriptor_medoid(_p(d, u32p), len(d))
 
 
+def bow_transform(vocab, desc, levels_up=4):
+    """vocab = dict(parent, desc, weight, word, depth_levels); returns word, weight, node per descriptor"""
+    par = np.ascontiguousarray(vocab["parent"], np.int32); nd = np.ascontiguousarray(vocab["desc"], np.uint32).reshape(-1, 8)
+    wt = np.ascontiguousarray(vocab["weight"], np.float64); wd = np.ascontiguousarray(vocab["word"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+    n = len(d)
+    word = np.zeros(n, np.int32); weight = np.zeros(n, np.float64); node = np.zeros(n, np.int32)
+    lib().mso_bow_transform.restype = None
+    lib().mso_bow_transform(len(par), _p(par, i32p), _p(nd, u32p), _p(wt, f64p), _p(wd, i32p), int(vocab["depth_levels"]),
+                            _p(d, u32p), n, int(levels_up), _p(word, i32p), _p(weight, f64p), _p(node, i32p))
+    return word, weight, node
+
+
+def bow_assemble(word, weight, node):
+    """BowVector (words, values) and FeatureVector (nodes, start, feat) the way DBoW2's std::maps iterate"""
+    word = np.ascontiguousarray(word, np.int32); weight = np.ascontiguousarray(weight, np.float64); node = np.ascontiguousarray(node, np.int32)
+    n = len(word)
+    ow = np.zeros(n + 1, np.int32); ov = np.zeros(n + 1, np.float64); fn = np.zeros(n + 1, np.int32); fs = np.zeros(n + 2, np.int32); ff = np.zeros(n + 1, np.int32)
+    nf = C.c_int(0)
+    lib().mso_bow_assemble.restype = C.c_int
+    nv = lib().mso_bow_assemble(_p(word, i32p), _p(weight, f64p), _p(node, i32p), n, _p(ow, i32p), _p(ov, f64p), _p(fn, i32p), _p(fs, i32p), _p(ff, i32p), C.byref(nf))
+    return ow[:nv].copy(), ov[:nv].copy(), fn[:nf.value].copy(), fs[:nf.value + 1].copy(), ff[:fs[nf.value]].copy()
+
+
 def make_bow(bucket_of_kp):
     """CSR over ascending node ids; keypoints of a node in ascending keypoint index (DBoW2 insertion order)."""
     bucket_of_kp = np.asarray(bucket_of_kp, np.int32)

@@ -379,6 +379,40 @@ def descriptor_medoid(ctx, desc_pool, obs_lists):
     return bl.download(np.int32, (n,)), bp.download(np.int32, (n,))
 
 
+class BowVocabulary:
+    """Device copy of a DBoW2 vocabulary tree (ms_bow_vocab): parent ids, node descriptors, weights, word ids, depth L."""
+
+    def __init__(self, ctx, parent, node_desc, node_weight, node_word, depth_levels):
+        self.ctx = ctx
+        par = np.ascontiguousarray(parent, np.int32); nd = np.ascontiguousarray(node_desc, np.uint32).reshape(-1, 8)
+        wt = np.ascontiguousarray(node_weight, np.float64); wd = np.ascontiguousarray(node_word, np.int32)
+        if not (len(par) == len(nd) == len(wt) == len(wd)): raise ValueError("vocabulary arrays differ in length")
+        h = C.c_void_p()
+        ctx.check(lib().ms_bow_vocab_create(ctx._h, len(par), par.ctypes.data_as(C.c_void_p), nd.ctypes.data_as(C.c_void_p),
+                                            wt.ctypes.data_as(C.c_void_p), wd.ctypes.data_as(C.c_void_p), int(depth_levels), C.byref(h)), "ms_bow_vocab_create")
+        self._h = h
+        ctx._children.append(weakref.ref(self))
+
+    def transform(self, desc, levels_up=4):
+        """desc: host array [n, 8] u32 or a device buffer (then pass n via a tuple (buf, n)).  Returns word, weight, node (host arrays)."""
+        if isinstance(desc, tuple): buf, n = desc
+        else:
+            d = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8); n = len(d)
+            buf = self.ctx.upload(d if n else np.zeros((1, 8), np.uint32))
+        w, wt, nd = self.ctx.alloc(4 * n + 16), self.ctx.alloc(8 * n + 16), self.ctx.alloc(4 * n + 16)
+        self.ctx.check(lib().ms_bow_transform(self.ctx._h, self._h, _vp(buf), n, int(levels_up), _vp(w), _vp(wt), _vp(nd)), "ms_bow_transform")
+        self.ctx.sync()
+        return w.download(np.int32, (n,)), wt.download(np.float64, (n,)), nd.download(np.int32, (n,))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ms_bow_vocab_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
 def hamming_candidates(ctx, q_desc, t_desc, cand_lists, t_skip=None, t_octave=None):
     """cand_lists: list (per query) of keypoint index arrays.  Returns (best_idx, best_dist, second_dist, best_oct, second_oct)."""
     q = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8); t = np.ascontiguousarray(t_desc, np.uint32).reshape(-1, 8)

@@ -6,6 +6,7 @@
 #include "mi355slam/orb_extractor.hpp"
 #include "mi355slam/keyframe_matcher.hpp"
 #include "mi355slam/bundle_adjuster.hpp"
+#include "mi355slam/bow_index.hpp"
 
 using namespace mi355slam;
 
@@ -128,6 +129,49 @@ int main(int argc, char **argv) {
             }
             if (got[p] != want) { std::printf("updateDescriptors mismatch at %zu: %d vs %d\n", p, got[p], want); return 7; }
         }
+    }
+    // BowIndex::transform through the device descent vs DBoW2's transform restated on std::maps (bow_index.cpp:59-93)
+    {
+        unsigned rng = 4242u;
+        auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+        auto popc = [](const std::uint32_t *a, const std::uint32_t *b) { int d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
+        VocabularyTree T; T.branchingFactor = 6; T.depthLevels = 3;
+        T.parent = {0}; T.wordId = {-1}; T.weight = {0.0}; T.descriptor.assign(8, 0u);
+        std::vector<int> frontier{0};
+        int words = 0;
+        for (int lv = 1; lv <= 3; ++lv) {
+            std::vector<int> next;
+            for (int p : frontier) for (int c = 0; c < 6; ++c) {
+                const KeyPoint &k = kps[rnd() % kps.size()];
+                T.parent.push_back(p); T.wordId.push_back(lv == 3 ? words++ : -1); T.weight.push_back(lv == 3 ? (rnd() % 20 == 0 ? 0.0 : 0.25 + (rnd() % 1000) / 128.0) : 0.0);
+                for (int w = 0; w < 8; ++w) T.descriptor.push_back(k.descriptor[w]);
+                next.push_back((int)T.parent.size() - 1);
+            }
+            frontier = next;
+        }
+        BowIndex index(ctx, T);
+        BowVector bv; FeatureVector fv;
+        index.transform(kps, bv, fv);
+        std::vector<std::vector<int>> children(T.size());
+        for (std::size_t i = 1; i < T.size(); ++i) children[T.parent[i]].push_back((int)i);
+        BowVector wantV; FeatureVector wantF;
+        const int nidLevel = T.depthLevels - 4;
+        for (std::size_t i = 0; i < kps.size(); ++i) {
+            int fin = 0, level = 0, nid = nidLevel <= 0 ? 0 : -1;
+            do {
+                ++level;
+                const auto &nodes = children[fin];
+                fin = nodes[0];
+                int best = popc(kps[i].descriptor.data(), &T.descriptor[8 * fin]);
+                for (std::size_t c = 1; c < nodes.size(); ++c) { const int d = popc(kps[i].descriptor.data(), &T.descriptor[8 * nodes[c]]); if (d < best) { best = d; fin = nodes[c]; } }
+                if (level == nidLevel) nid = fin;
+            } while (!children[fin].empty());
+            if (T.weight[fin] > 0) { wantV[(unsigned)T.wordId[fin]] += T.weight[fin]; wantF[(unsigned)nid].push_back((unsigned)i); }
+        }
+        double norm = 0; for (auto &kv : wantV) norm += std::fabs(kv.second);
+        for (auto &kv : wantV) kv.second /= norm;
+        std::printf("BowIndex::transform: %zu words, %zu nodes for %zu keypoints\n", bv.size(), fv.size(), kps.size());
+        if (bv != wantV || fv != wantF || bv.size() < 20) { std::printf("BowIndex::transform mismatch\n"); return 9; }
     }
     // a tiny two-stage local BA: 3 cameras on a line looking at 30 points
     BaWindow w; w.currentKeyframe = 2;

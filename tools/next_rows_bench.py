@@ -32,3 +32,31 @@ def med(): ctx.check(L.ms_descriptor_medoid(ctx._h, vp(dp), vp(ds), vp(di), npts
 med(); ctx.sync()
 ctx.timer_start(); med(); ms = ctx.timer_stop_ms()
 print("descriptor medoid: %d map points x %d observations: %.3f ms = %.1f M map points/s" % (npts, k, ms, npts / ms / 1e3))
+# --- vocabulary-tree descent (N3): k = 10, L = 6 (1 111 111 nodes, 10^6 words -- the shape of the ORB vocabularies), 256 frames x 2000 descriptors
+import time, mso, bow_synth
+k, Lv = 10, 6
+par, desc_l = [np.zeros(1, np.int32)], [np.zeros((1, 8), np.uint32)]
+first = 0
+for lv in range(1, Lv + 1):
+    npar = len(desc_l[-1]); ids = first + np.arange(npar, dtype=np.int32)
+    par.append(np.repeat(ids, k))
+    base = rng.integers(0, 2**32, (npar * k, 8), dtype=np.uint64).astype(np.uint32) if lv == 1 else np.repeat(desc_l[-1], k, axis=0)
+    flips = rng.integers(0, 2**32, base.shape, dtype=np.uint64).astype(np.uint32) & rng.integers(0, 2**32, base.shape, dtype=np.uint64).astype(np.uint32) & rng.integers(0, 2**32, base.shape, dtype=np.uint64).astype(np.uint32)
+    desc_l.append(base ^ (flips if lv > 1 else 0))       # ~12 % of the bits differ from the parent
+    first += npar
+par = np.concatenate(par); nd = np.concatenate(desc_l); nn = len(par)
+word = np.full(nn, -1, np.int32); word[nn - k**Lv:] = np.arange(k**Lv, dtype=np.int32)
+wt = np.zeros(nn); wt[nn - k**Lv:] = rng.random(k**Lv) + 0.1
+V = mi355slam.BowVocabulary(ctx, par, nd, wt, word, Lv)
+nq = 2000 * 256
+q = nd[rng.integers(1, nn, nq)] ^ (rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32) & rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32) & rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32) & rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32))
+dq = up(q); ow, owt, ond = ctx.alloc(4 * nq + 16), ctx.alloc(8 * nq + 16), ctx.alloc(4 * nq + 16)
+def bow(): ctx.check(L.ms_bow_transform(ctx._h, V._h, vp(dq), nq, 4, vp(ow), vp(owt), vp(ond)), "bow")
+bow(); ctx.sync()
+ctx.timer_start(); bow(); ms = ctx.timer_stop_ms()
+vocab = dict(parent=par, desc=nd, weight=wt, word=word, depth_levels=Lv)
+ns = 20000
+t0 = time.perf_counter(); cw, cwt, cnd = mso.bow_transform(vocab, q[:ns], 4); cpu = time.perf_counter() - t0
+assert np.array_equal(ow.download(np.int32, (nq,))[:ns], cw) and np.array_equal(ond.download(np.int32, (nq,))[:ns], cnd)
+print("vocabulary descent: %d descriptors down a k=10 L=6 tree (%d nodes): %.3f ms = %.1f M descriptors/s (%.0f frames of 2000/s); CPU oracle 1 thread %.2f M descriptors/s"
+      % (nq, nn, ms, nq / ms / 1e3, 256 / ms * 1e3, ns / cpu / 1e6))
