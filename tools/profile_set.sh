@@ -1,0 +1,20 @@
+#!/bin/bash
+# One profile set of the current build: usage (on the GPU box)  bash tools/profile_set.sh <tag>
+# Writes gpurun_out/prof_<tag>/: the default bench line, the bench line + kernel stats under rocprofv3, and one --pmc pass per
+# counter group (counters on their own with --kernel-trace only).  Copy what is to be judged into profiles/ afterwards.
+set -e
+tag=$1
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$tag
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+python3 "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err"
+echo "bench done"
+rocprofv3 --kernel-trace --stats -d "$O/stats" -o p --output-format csv -- python3 "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/rocprof.err"
+echo "stats done"
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  name=$(echo "$grp" | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $grp -d "$O/pmc/$name" -o p --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-ba --no-cpu-baseline > /dev/null 2>> "$O/rocprof.err"
+  echo "pmc $name done"
+done
+python3 "$R/tools/pmc_summary.py" "$O/pmc" "$O/pmc_traffic.json"
