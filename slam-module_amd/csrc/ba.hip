@@ -34,7 +34,8 @@ constexpr int NT = 512;          // threads per problem
 constexpr int NW = NT / 64;      // waves
 constexpr int NB = 16;           // Cholesky panel width
 constexpr int CH = 32;           // Schur work items (pairs of observations of one point) per chunk
-constexpr int kMaxFreePoses = 176;   // Cholesky panel (6*176+1) x 16 doubles + solution vector must fit the LDS budget
+constexpr int kMaxFreePoses = 176;   // Cholesky panel (6*176+1) x 16 doubles + solution vector must fit the LDS budget; beyond it the panel lives in global memory
+constexpr int kMaxFreePosesTeam = 2048;   // ... and the factorisation is spread over the team (cholesky_factor_team); the solution vector (6*2048 doubles) still fits the LDS
 constexpr int kMaxTeam = 64;         // workgroups that may share one problem
 constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
 
@@ -63,6 +64,7 @@ struct BaProb {
     double *Hpp, *S, *bp, *dp, *y, *Hll, *bl, *Hinv, *Hpl, *dl, *chi2_obs, *Y;
     const double *zrow;                      // n6 + 16 zeros
     double *dinv;                            // [n6] reciprocals of the Cholesky diagonal
+    double *panG;                            // [(n6+1) x 16] Cholesky panel in global memory, only for systems beyond kMaxFreePoses (else null)
     const int32_t *env16;                    // [n6/16 + 2] envelope of S per 16-row block: first structurally non-zero column (0 for the rhs row's block)
     // team state (team > 1): arrival counter (monotonic, one 128-B line), per-workgroup partial sums [2][team][2], solve status
     uint32_t *bar;
@@ -642,177 +644,246 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
     team_sync(P);
 }
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Left-looking update of the 16-column panel at c0 with the finished columns [0, c0), row tiles tile0, tile0 + tstride, ...
+// (two per trip): result rows go to pan[(row - c0) * NB + col], in LDS for the single-workgroup factorisation, in global
+// memory when the tiles of a panel are spread over a team.
+__device__ __forceinline__ void chol_panel_update(const BaProb &P, int c0, int nb, int m, double *pan, int tile0, int tstride, int lane) {
+    const int n = P.n6;
+    // left-looking update of the 16-column panel with the finished columns [0, c0): a dense
+    // (m x c0)(c0 x 16) product -> v_mfma_f64_16x16x4_f64, one 16-row tile per wave, operands straight
+    // from L2 (each lane streams 4 consecutive doubles of its A row and of its B row per 16-k chunk;
+    // the k order inside a chunk is permuted identically for A and B, which leaves the sum unchanged)
+    // Each wave works on TWO row tiles at once (independent accumulators) and two k-chunks per trip, so 16 double2
+    // loads are in flight per group of 16 MFMAs instead of 4 per 4.
+    const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S, *yg = (const MS_GLOBAL double *)P.y, *zg = (const MS_GLOBAL double *)P.zrow;
+    // Envelope: rows of a 16-row block have no entries left of env[block] (and Cholesky creates none), so a row tile whose
+    // envelope starts right of this panel is skipped outright and the k loop of the others starts at the later of the two
+    // envelopes.  Skipped rows never enter the panel buffer; the substitution and the write-back skip them the same way.
+    const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
+    const int pblk = c0 / NB, penv = env[pblk];
+    const int q = lane >> 4, jb = lane & 15;
+    const MS_GLOBAL d2_t *bp2 = reinterpret_cast<const MS_GLOBAL d2_t *>(((jb < nb) ? Sg + (size_t)(c0 + jb) * n : zg) + 4 * q);
+    for (int rt = tile0; rt * 16 < m; rt += 2 * tstride) {
+        const int rt2 = rt + tstride;
+        const int e1 = env[pblk + rt], e2 = rt2 * 16 < m ? env[pblk + rt2] : 0x7fffffff;
+        const bool act1 = e1 <= c0 + NB - 1, act2 = e2 <= c0 + NB - 1;
+        if (!act1 && !act2) continue;                       // wave-uniform
+        const int ia = rt * 16 + (lane & 15), ib = rt2 * 16 + (lane & 15);
+        const MS_GLOBAL double *arow = (c0 + ia < n) ? Sg + (size_t)(c0 + ia) * n : (c0 + ia == n ? yg : zg);
+        const MS_GLOBAL double *brow2 = (c0 + ib < n) ? Sg + (size_t)(c0 + ib) * n : (c0 + ib == n ? yg : zg);
+        const MS_GLOBAL d2_t *ap = reinterpret_cast<const MS_GLOBAL d2_t *>(arow + 4 * q), *ap2 = reinterpret_cast<const MS_GLOBAL d2_t *>(brow2 + 4 * q);
+        // the panel's own entries (what the products are subtracted from) are requested first: their round trip runs under the k loop
+        double sv[2][4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg, j = lane & 15;
+                sv[which][reg] = (ii < m && j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
+            }
+        d4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        int kk = max(penv, min(act1 ? e1 : 0x7fffffff, act2 ? e2 : 0x7fffffff)) & ~15;
+        for (; kk + 32 <= c0; kk += 32) {
+            const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], a2 = ap[kk / 2 + 8], a3 = ap[kk / 2 + 9];
+            const d2_t e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], e2 = ap2[kk / 2 + 8], e3 = ap2[kk / 2 + 9];
+            const d2_t b0 = bp2[kk / 2], b1 = bp2[kk / 2 + 1], b2 = bp2[kk / 2 + 8], b3 = bp2[kk / 2 + 9];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.x, b0.x, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.y, b0.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.x, b1.x, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.y, b1.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2.x, b2.x, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2.y, b2.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3.x, b3.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3.x, b3.x, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3.y, b3.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3.y, b3.y, acc2, 0, 0, 0);
+        }
+        for (; kk < c0; kk += 16) {
+            const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], b0 = bp2[kk / 2], b1 = bp2[kk / 2 + 1];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.x, b0.x, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.y, b0.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.x, b1.x, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.y, b1.y, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {       // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg, col = lane&15
+            const int j = lane & 15;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg;
+                if (ii < m) {
+                    pan[ii * NB + j] = sv[which][reg] - (which ? acc2[reg] : acc[reg]);
+                }
+            }
+        }
+    }
+}
+
+// Factor the nb x nb diagonal block held as pan[row * NB + col] in the registers of one wave; returns false when a pivot is not
+// positive.  On return lane i holds row i of L in r[], di = 1 / L[i][i].
+__device__ __forceinline__ bool chol_factor_diag(const double *pan, int nb, int lane, double (&r)[NB], double &di) {
+    // factor the nb x nb diagonal block in REGISTERS: lane i holds row i (16 doubles), the pivot and the column
+    // entries L[c][j] are wave-uniform v_readlane broadcasts.  Same operations in the same order as the textbook
+    // loop over LDS it replaces (26.7 k -> ~4 k cycles per block); a short last block is padded with identity.
+#pragma unroll
+    for (int c = 0; c < NB; ++c) r[c] = (lane < nb && c < nb) ? pan[lane * NB + c] : (lane == c ? 1.0 : 0.0);
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double d = readlane_d(r[j], j);
+        if (j < nb && (!(d > 0) || !isfinite(d))) ok = false;
+        const double sd = sqrt(d > 0 ? d : 1.0);
+        r[j] = lane == j ? sd : (lane > j ? r[j] / sd : r[j]);
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            const double lcj = readlane_d(r[j], c);
+            if (lane >= c) r[c] -= r[j] * lcj;
+        }
+    }
+    di = 1.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) if (lane == c) di = r[c];
+    di = 1.0 / di;
+    return ok;
+}
+
+// Back substitution L^T x = z with xs[n] in LDS (z = the forward-substituted rhs in P.y on entry; P.dp on exit).
+__device__ __forceinline__ void chol_back_substitute(const BaProb &P, double *xs, int tid, int lane, int wave) {
+    const int n = P.n6;
+    // back substitution L^T x = z (z = the forward-substituted rhs, now in P.y), panels in reverse, in LDS.  Per panel: wave 0
+    // solves the 16x16 triangle as a lane recurrence (lane k owns x_k; one shuffle and one multiply by the stored reciprocal
+    // per step), then every thread k < c0 subtracts the panel's 16 rows from z_k -- rows of L are contiguous in memory, so
+    // these are coalesced, independent loads with no reduction (the column-dot formulation needed a wave sum per column).
+    for (int i = tid; i < n; i += NT) xs[i] = P.y[i];
+    __syncthreads();
+    const int last = ((n - 1) / NB) * NB;
+    for (int c0 = last; c0 >= 0; c0 -= NB) {
+        const int nb = min(NB, n - c0);
+        if (wave == 0) {
+            double col[NB];                                    // lane k: column c0+k of the diagonal block, L[c0+j][c0+k] for j > k
+#pragma unroll
+            for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? P.S[(size_t)(c0 + j) * n + c0 + lane] : 0.0;
+            const double di = lane < nb ? P.dinv[c0 + lane] : 0.0;
+            double r = lane < nb ? xs[c0 + lane] : 0.0, xk = 0;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                if (j < nb) {                                  // uniform
+                    const double xj = readlane_d(r, j) * readlane_d(di, j);
+                    if (lane == j) xk = xj;
+                    r -= col[j] * xj;                          // col[j] is zero for lanes >= j
+                }
+            }
+            if (lane < nb) xs[c0 + lane] = xk;
+        }
+        __syncthreads();
+        for (int k = (P.env16[c0 / NB] & ~15) + tid; k < c0; k += NT) {     // columns left of the panel rows' envelope hold zeros
+            double zk = xs[k];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) if (j < nb) zk -= P.S[(size_t)(c0 + j) * n + k] * xs[c0 + j];
+            xs[k] = zk;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) P.dp[i] = xs[i];
+    __syncthreads();
+}
+
 __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     double *lds = lds_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6;
-    (void)lane; (void)wave; (void)n;
     // blocked left-looking Cholesky of S (lower), rhs y carried as row n
-    {
-        double *pan = lds;                              // [(n+1)][NB]
-        double *tvec = lds + (size_t)(n + 1) * NB;      // [NB]
-        typedef double d4_t __attribute__((ext_vector_type(4)));
-        for (int c0 = 0; c0 < n; c0 += NB) {
-            const int nb = min(NB, n - c0), m = n - c0 + 1, cnt = m * NB;
-            // left-looking update of the 16-column panel with the finished columns [0, c0): a dense
-            // (m x c0)(c0 x 16) product -> v_mfma_f64_16x16x4_f64, one 16-row tile per wave, operands straight
-            // from L2 (each lane streams 4 consecutive doubles of its A row and of its B row per 16-k chunk;
-            // the k order inside a chunk is permuted identically for A and B, which leaves the sum unchanged)
-            // Each wave works on TWO row tiles at once (independent accumulators) and two k-chunks per trip, so 16 double2
-            // loads are in flight per group of 16 MFMAs instead of 4 per 4.
-            const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S, *yg = (const MS_GLOBAL double *)P.y, *zg = (const MS_GLOBAL double *)P.zrow;
-            // Envelope: rows of a 16-row block have no entries left of env[block] (and Cholesky creates none), so a row tile whose
-            // envelope starts right of this panel is skipped outright and the k loop of the others starts at the later of the two
-            // envelopes.  Skipped rows never enter the panel buffer; the substitution and the write-back skip them the same way.
-            const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
-            const int pblk = c0 / NB, penv = env[pblk];
-            const int q = lane >> 4, jb = lane & 15;
-            const MS_GLOBAL d2_t *bp2 = reinterpret_cast<const MS_GLOBAL d2_t *>(((jb < nb) ? Sg + (size_t)(c0 + jb) * n : zg) + 4 * q);
-            for (int rt = wave; rt * 16 < m; rt += 2 * NW) {
-                const int rt2 = rt + NW;
-                const int e1 = env[pblk + rt], e2 = rt2 * 16 < m ? env[pblk + rt2] : 0x7fffffff;
-                const bool act1 = e1 <= c0 + NB - 1, act2 = e2 <= c0 + NB - 1;
-                if (!act1 && !act2) continue;                       // wave-uniform
-                const int ia = rt * 16 + (lane & 15), ib = rt2 * 16 + (lane & 15);
-                const MS_GLOBAL double *arow = (c0 + ia < n) ? Sg + (size_t)(c0 + ia) * n : (c0 + ia == n ? yg : zg);
-                const MS_GLOBAL double *brow2 = (c0 + ib < n) ? Sg + (size_t)(c0 + ib) * n : (c0 + ib == n ? yg : zg);
-                const MS_GLOBAL d2_t *ap = reinterpret_cast<const MS_GLOBAL d2_t *>(arow + 4 * q), *ap2 = reinterpret_cast<const MS_GLOBAL d2_t *>(brow2 + 4 * q);
-                // the panel's own entries (what the products are subtracted from) are requested first: their round trip runs under the k loop
-                double sv[2][4];
+    double *pan = lds;                              // [(n+1)][NB]
+    double *tvec = lds + (size_t)(n + 1) * NB;      // [NB]
+    const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
+    for (int c0 = 0; c0 < n; c0 += NB) {
+        const int nb = min(NB, n - c0), m = n - c0 + 1, cnt = m * NB;
+        chol_panel_update(P, c0, nb, m, pan, wave, NW, lane);
+        __syncthreads();
+        if (wave == 0) {
+            double r[NB], di;
+            const bool ok = chol_factor_diag(pan, nb, lane, r, di);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
+            for (int c = 0; c < NB; ++c) if (lane < nb && c < nb) pan[lane * NB + c] = r[c];
+            // 1 / L[j][j], once per column: the substitutions below and the back substitution multiply instead of dividing
+            if (lane < NB) tvec[lane] = di;
+            if (lane < nb) P.dinv[c0 + lane] = di;
+            if (!ok && lane == 0) P.flag[0] = 0;
+        }
+        __syncthreads();
+        for (int i = nb + tid; i < m; i += NT) {     // rows below: x L11^T = a
+            if (env[(c0 + i) / NB] > c0 + NB - 1) continue;     // outside the envelope: structurally zero, not in the panel
+            double x[NB];
 #pragma unroll
-                    for (int which = 0; which < 2; ++which) {
-                        const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg, j = lane & 15;
-                        sv[which][reg] = (ii < m && j < nb) ? ((c0 + ii < n) ? P.S[(size_t)(c0 + ii) * n + c0 + j] : P.y[c0 + j]) : 0.0;
-                    }
-                d4_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-                int kk = max(penv, min(act1 ? e1 : 0x7fffffff, act2 ? e2 : 0x7fffffff)) & ~15;
-                for (; kk + 32 <= c0; kk += 32) {
-                    const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], a2 = ap[kk / 2 + 8], a3 = ap[kk / 2 + 9];
-                    const d2_t e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], e2 = ap2[kk / 2 + 8], e3 = ap2[kk / 2 + 9];
-                    const d2_t b0 = bp2[kk / 2], b1 = bp2[kk / 2 + 1], b2 = bp2[kk / 2 + 8], b3 = bp2[kk / 2 + 9];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.x, b0.x, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.y, b0.y, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.x, b1.x, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.y, b1.y, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2.x, b2.x, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e2.y, b2.y, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3.x, b3.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3.x, b3.x, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3.y, b3.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e3.y, b3.y, acc2, 0, 0, 0);
-                }
-                for (; kk < c0; kk += 16) {
-                    const d2_t a0 = ap[kk / 2], a1 = ap[kk / 2 + 1], e0 = ap2[kk / 2], e1 = ap2[kk / 2 + 1], b0 = bp2[kk / 2], b1 = bp2[kk / 2 + 1];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.x, b0.x, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0.y, b0.y, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.x, b1.x, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1.y, b1.y, acc2, 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {       // C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg, col = lane&15
-                    const int j = lane & 15;
-#pragma unroll
-                    for (int which = 0; which < 2; ++which) {
-                        const int ii = (which ? rt2 : rt) * 16 + (lane >> 4) + 4 * reg;
-                        if (ii < m) {
-                            pan[ii * NB + j] = sv[which][reg] - (which ? acc2[reg] : acc[reg]);
-                        }
-                    }
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    double s = pan[i * NB + j];
+                    for (int k = 0; k < j; ++k) s -= x[k] * pan[j * NB + k];
+                    x[j] = s * tvec[j];
                 }
             }
-            __syncthreads();
-            if (wave == 0) {
-                // factor the nb x nb diagonal block in REGISTERS: lane i holds row i (16 doubles), the pivot and the column
-                // entries L[c][j] are wave-uniform v_readlane broadcasts.  Same operations in the same order as the textbook
-                // loop over LDS it replaces (26.7 k -> ~4 k cycles per block); a short last block is padded with identity.
-                double r[NB];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) r[c] = (lane < nb && c < nb) ? pan[lane * NB + c] : (lane == c ? 1.0 : 0.0);
-                bool ok = true;
+            for (int j = 0; j < NB; ++j) if (j < nb) pan[i * NB + j] = x[j];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < cnt; idx += NT) {
+            const int i = idx / NB, j = idx - i * NB;
+            if (j < nb && (i >= j || i >= nb) && env[(c0 + i) / NB] <= c0 + NB - 1) {
+                if (c0 + i < n) P.S[(size_t)(c0 + i) * n + c0 + j] = pan[idx]; else P.y[c0 + j] = pan[idx];
+            }
+        }
+        __syncthreads();
+    }
+    chol_back_substitute(P, tvec + NB, tid, lane, wave);
+}
+
+// The same factorisation for systems whose panel does not fit the LDS (more than kMaxFreePoses free poses: global bundle
+// adjustment, bundle_adjuster.cpp:493-604), spread over the team: the row tiles of a panel are updated by all waves of all
+// workgroups into a panel buffer in global memory; after a team barrier EVERY workgroup factors the 16 x 16 diagonal block
+// for itself (4 k cycles of redundant work instead of a second 6 us barrier), solves its share of the rows below against it and
+// writes them straight into S.  Two team barriers per panel.  The arithmetic per entry is the same as in cholesky_solve.
+__device__ __noinline__ void cholesky_factor_team(const BaProb &P_, double *lds_) {
+    const BaProb &P = P_;
+    BA_IDS
+    const int n = P.n6;
+    double *pan = P.panG;                           // [(n+1)][NB] in global memory
+    double *sd = lds_;                              // [NB][NB] factored diagonal block
+    double *tvec = lds_ + NB * NB;                  // [NB] reciprocal pivots
+    const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
+    for (int c0 = 0; c0 < n; c0 += NB) {
+        const int nb = min(NB, n - c0), m = n - c0 + 1;
+        chol_panel_update(P, c0, nb, m, pan, gw, GW, lane);
+        team_sync(P);
+        if (wave == 0) {
+            double r[NB], di;
+            const bool ok = chol_factor_diag(pan, nb, lane, r, di);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const double d = readlane_d(r[j], j);
-                    if (j < nb && (!(d > 0) || !isfinite(d))) ok = false;
-                    const double sd = sqrt(d > 0 ? d : 1.0);
-                    r[j] = lane == j ? sd : (lane > j ? r[j] / sd : r[j]);
+            for (int c = 0; c < NB; ++c) if (lane < NB) sd[lane * NB + c] = r[c];
+            if (lane < NB) tvec[lane] = di;
+            if (rank_ == 0) {
 #pragma unroll
-                    for (int c = j + 1; c < NB; ++c) {
-                        const double lcj = readlane_d(r[j], c);
-                        if (lane >= c) r[c] -= r[j] * lcj;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < NB; ++c) if (lane < nb && c < nb) pan[lane * NB + c] = r[c];
-                // 1 / L[j][j], once per column: the substitutions below and the back substitution multiply instead of dividing
-                double di = 1.0;
-#pragma unroll
-                for (int c = 0; c < NB; ++c) if (lane == c) di = r[c];
-                di = 1.0 / di;
-                if (lane < NB) tvec[lane] = di;
+                for (int c = 0; c < NB; ++c) if (lane < nb && c <= lane) P.S[(size_t)(c0 + lane) * n + c0 + c] = r[c];
                 if (lane < nb) P.dinv[c0 + lane] = di;
                 if (!ok && lane == 0) P.flag[0] = 0;
             }
-            __syncthreads();
-            for (int i = nb + tid; i < m; i += NT) {     // rows below: x L11^T = a
-                if (env[(c0 + i) / NB] > c0 + NB - 1) continue;     // outside the envelope: structurally zero, not in the panel
-                double x[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (j < nb) {
-                        double s = pan[i * NB + j];
-                        for (int k = 0; k < j; ++k) s -= x[k] * pan[j * NB + k];
-                        x[j] = s * tvec[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) if (j < nb) pan[i * NB + j] = x[j];
-            }
-            __syncthreads();
-            for (int idx = tid; idx < cnt; idx += NT) {
-                const int i = idx / NB, j = idx - i * NB;
-                if (j < nb && (i >= j || i >= nb) && env[(c0 + i) / NB] <= c0 + NB - 1) {
-                    if (c0 + i < n) P.S[(size_t)(c0 + i) * n + c0 + j] = pan[idx]; else P.y[c0 + j] = pan[idx];
-                }
-            }
-            __syncthreads();
         }
-        // back substitution L^T x = z (z = the forward-substituted rhs, now in P.y), panels in reverse, in LDS.  Per panel: wave 0
-        // solves the 16x16 triangle as a lane recurrence (lane k owns x_k; one shuffle and one multiply by the stored reciprocal
-        // per step), then every thread k < c0 subtracts the panel's 16 rows from z_k -- rows of L are contiguous in memory, so
-        // these are coalesced, independent loads with no reduction (the column-dot formulation needed a wave sum per column).
-        double *xs = tvec + NB;                                    // [n]: z on entry, x on exit
-        for (int i = tid; i < n; i += NT) xs[i] = P.y[i];
         __syncthreads();
-        const int last = ((n - 1) / NB) * NB;
-        for (int c0 = last; c0 >= 0; c0 -= NB) {
-            const int nb = min(NB, n - c0);
-            if (wave == 0) {
-                double col[NB];                                    // lane k: column c0+k of the diagonal block, L[c0+j][c0+k] for j > k
+        for (int i = nb + gt; i < m; i += GT) {      // rows below: x L11^T = a
+            if (env[(c0 + i) / NB] > c0 + NB - 1) continue;
+            double x[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? P.S[(size_t)(c0 + j) * n + c0 + lane] : 0.0;
-                const double di = lane < nb ? P.dinv[c0 + lane] : 0.0;
-                double r = lane < nb ? xs[c0 + lane] : 0.0, xk = 0;
-#pragma unroll
-                for (int j = NB - 1; j >= 0; --j) {
-                    if (j < nb) {                                  // uniform
-                        const double xj = readlane_d(r, j) * readlane_d(di, j);
-                        if (lane == j) xk = xj;
-                        r -= col[j] * xj;                          // col[j] is zero for lanes >= j
-                    }
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    double s = pan[(size_t)i * NB + j];
+                    for (int k = 0; k < j; ++k) s -= x[k] * sd[j * NB + k];
+                    x[j] = s * tvec[j];
                 }
-                if (lane < nb) xs[c0 + lane] = xk;
             }
-            __syncthreads();
-            for (int k = (P.env16[c0 / NB] & ~15) + tid; k < c0; k += NT) {     // columns left of the panel rows' envelope hold zeros
-                double zk = xs[k];
+            double *dst = c0 + i < n ? P.S + (size_t)(c0 + i) * n + c0 : P.y + c0;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) if (j < nb) zk -= P.S[(size_t)(c0 + j) * n + k] * xs[c0 + j];
-                xs[k] = zk;
-            }
-            __syncthreads();
+            for (int j = 0; j < NB; ++j) if (j < nb) dst[j] = x[j];
         }
-        for (int i = tid; i < n; i += NT) P.dp[i] = xs[i];
-        __syncthreads();
+        team_sync(P);
     }
 }
 
@@ -854,7 +925,10 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     { const long long t1 = clock64(); cyc[6] += t1 - t0; }
     schur_segments(P, lds);
     { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
-    if (lead) cholesky_solve(P, lds);                  // the dense 6 np x 6 np factorisation stays in one workgroup (panel in LDS)
+    if (P.panG) {                                      // too large for an LDS panel: factor across the team, substitute back in one workgroup
+        cholesky_factor_team(P, lds);
+        if (lead) chol_back_substitute(P, lds, threadIdx.x, threadIdx.x & 63, threadIdx.x >> 6);
+    } else if (lead) cholesky_solve(P, lds);           // the dense 6 np x 6 np factorisation stays in one workgroup (panel in LDS)
     team_sync(P);
     { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
     const bool ok = P.flag[0] != 0;
@@ -985,7 +1059,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -996,7 +1070,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         Prep &R = prep[p];
         R.pidx.assign(Q.n_pose, -1);
         for (int i = 0; i < Q.n_pose; ++i) if (!Q.pose_fixed[i]) { R.pidx[i] = R.np_free++; R.free2pose.push_back(i); }
-        if (R.np_free > kMaxFreePoses || R.np_free > 65535) return ms_fail(c, MS_ERR_CAPACITY, "ms_ba_create: %d free poses (max %d in this version)", R.np_free, kMaxFreePoses);
+        if (R.np_free > kMaxFreePosesTeam) return ms_fail(c, MS_ERR_CAPACITY, "ms_ba_create: %d free poses (max %d in this version)", R.np_free, kMaxFreePosesTeam);
         for (int o = 0; o < Q.n_obs; ++o)
             if (Q.obs_pose[o] < 0 || Q.obs_pose[o] >= Q.n_pose || Q.obs_point[o] < 0 || Q.obs_point[o] >= Q.n_point)
                 return ms_fail(c, MS_ERR_INVALID, "ms_ba_create: observation %d of problem %d indexes outside the problem", o, p);
@@ -1089,6 +1163,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(16 * D);
         O.Y = bump(18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
         O.dinv = bump((n6 + 16) * D);
+        O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
         O.bar = bump(256); O.red = bump(2 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
     }
     ms_ba *B = new ms_ba();
@@ -1133,6 +1208,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.env16 = PTR(int32_t, env16);
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
         H.dinv = PTR(double, dinv);
+        H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
         H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1;
 #undef PTR
     }

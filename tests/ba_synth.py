@@ -53,13 +53,13 @@ def _inverse(a):
 
 
 def make_problem(n_pose=50, n_point=2000, run=10, seed=42, noise=1.0 / 500, perturb=True, fix_first=False, prior_r=100.0, prior_p=50.0, dt=0.1,
-                 outlier_frac=0.0):
+                 outlier_frac=0.0, yaw_total=0.2, z_drift=0.02):
     rng = np.random.Generator(np.random.Philox(seed))
     sf2 = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32) ** 2     # levelSigmaSq
     gt_pose = []
     for i in range(n_pose):
-        c = np.array([0.2 * i - 0.1 * (n_pose - 1), 0.05 * np.sin(0.3 * i), 0.02 * i])
-        R = _rotvec(np.array([0.0, (0.004 if n_pose <= 50 else 0.2 / n_pose) * (i - n_pose / 2), 0.0])) @ _rotvec(np.array([0.01 * np.sin(i), 0, 0]))
+        c = np.array([0.2 * i - 0.1 * (n_pose - 1), 0.05 * np.sin(0.3 * i), z_drift * i])
+        R = _rotvec(np.array([0.0, (0.004 if n_pose <= 50 else yaw_total / n_pose) * (i - n_pose / 2), 0.0])) @ _rotvec(np.array([0.01 * np.sin(i), 0, 0]))
         gt_pose.append(_pose(R, -R @ c))                      # world->camera
     gt_pose = np.array(gt_pose)
     half = 0.1 * (n_pose - 1)

@@ -106,6 +106,35 @@ def test_global_ba_sized_window(oracle, ctx):
     _check(p, ba.download(0), oracle.ba_solve(p, 12, False))
 
 
+def test_global_ba_beyond_the_lds_panel(oracle, ctx):
+    """More than 176 free poses: the Cholesky panel moves to global memory and the factorisation is spread over the team
+    (cholesky_factor_team).  220 keyframes against the oracle at several team sizes, then 420 keyframes with a loop closure
+    checked by its properties (the oracle's dense scalar Cholesky would take minutes there)."""
+    import mi355slam
+    p = ba_synth.make_problem(220, 2200, 12, seed=91, fix_first=True, yaw_total=0.05, z_drift=0.005)
+    want = oracle.ba_solve(p, 8, False)
+    for team in (0, 1, 3, 32):
+        ba = mi355slam.BundleAdjuster(ctx, [p], max_iters=8); ba.set_team(team); ba.solve()
+        _check(p, ba.download(0), want)
+        ba.close()
+    q = ba_synth.make_problem(420, 4000, 10, seed=92, fix_first=True, yaw_total=0.03, z_drift=0.003)
+    extra = np.array([[419, 3], [300, 40]], np.int32)                    # loop-closure edges far off the band
+    gp = q["gt_pose"]
+    meas = [ba_synth._compose(gp[j], ba_synth._inverse(gp[i])) for i, j in extra]
+    q["edge_i"] = np.concatenate([q["edge_i"], extra[:, 0]]); q["edge_j"] = np.concatenate([q["edge_j"], extra[:, 1]])
+    q["edge_meas"] = np.concatenate([q["edge_meas"], np.array(meas).reshape(-1, 7)]); q["edge_info"] = np.concatenate([q["edge_info"], q["edge_info"][:2]])
+    outs = []
+    for team in (0, 7):
+        ba = mi355slam.BundleAdjuster(ctx, [q], max_iters=10); ba.set_team(team); ba.solve()
+        outs.append(ba.download(0)); ba.close()
+    a, b = outs
+    assert a["stats"]["chi2_final"] < 0.02 * a["stats"]["chi2_init"]
+    r = ba_synth.residuals(q, a["pose"], a["point"])
+    assert np.sqrt((r ** 2).mean()) < 1.2 / 500                               # the noise floor
+    assert np.abs(r - ba_synth.residuals(q, b["pose"], b["point"])).max() < 1e-7  # team size does not change the solve
+    assert a["stats"]["iters"] == b["stats"]["iters"] and a["stats"]["trials"] == b["stats"]["trials"]
+
+
 def test_team_of_workgroups_matches_single_workgroup_and_oracle(oracle, ctx):
     """ms_ba_set_team: one problem spread over 1 .. 32 workgroups (grid barriers, agent-scope release / acquire) gives the
     oracle's result at every team size -- C4, a pose-only problem, a window with outliers and a batch of 3 with teams of 7."""

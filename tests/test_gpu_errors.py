@@ -54,7 +54,7 @@ def test_hamming_argument_checks(ctx):
 
 def test_ba_capacity_and_index_checks(ctx):
     import mi355slam
-    big = ba_synth.make_problem(180, 50, 5, seed=1)                          # 180 free poses > 176
+    big = ba_synth.make_problem(2060, 30, 3, seed=1, yaw_total=0.005, z_drift=0.0005)                         # 2060 free poses > 2048
     with pytest.raises(mi355slam.MsError, match="free poses"):
         mi355slam.BundleAdjuster(ctx, [big])
     bad = ba_synth.make_problem(5, 20, 3, seed=2)
