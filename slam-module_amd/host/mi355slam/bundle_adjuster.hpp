@@ -1,4 +1,4 @@
-// bundle_adjuster.hpp -- host mirror of localBundleAdjust / poseBundleAdjust (bundle_adjuster.hpp:30-45).
+// bundle_adjuster.hpp -- host mirror of localBundleAdjust / poseBundleAdjust / globalBundleAdjust (bundle_adjuster.hpp:30-45).
 //
 // The reference walks MapDB to pick the window (bundle_adjuster.cpp:156-240); that graph walk stays with the caller,
 // which hands over the window as flat arrays (BaWindow).  This file reproduces what happens between
@@ -92,6 +92,24 @@ inline bool poseBundleAdjust(Context &ctx, BaWindow &w, int poseBAIterations, ms
     ctx.check(ms_ba_solve_host(ctx.get(), &p, w.poses[0].data(), nullptr, nullptr, &r), "ms_ba_solve_host");
     if (res) *res = r;
     return true;
+}
+
+// globalBundleAdjust (bundle_adjuster.cpp:493-604): every keyframe of the map with only the current one fixed (:515), every
+// observed map point free (:531), the odometry chain (:554-571) and the loop-closure edges (:574-578), ONE optimisation of
+// parameters.globalBAIterations, then the chi2 > 5.991 outlier rule (:584-597) and the write-back of everything (:599-604).
+// `w` holds the whole map as flat arrays (w.currentKeyframe = the fixed one); up to 2048 free keyframes (the device spreads the
+// factorisation of systems beyond 176 poses over a team of workgroups).
+inline BaOutcome globalBundleAdjust(Context &ctx, BaWindow &w, int globalBAIterations) {
+    BaOutcome out;
+    std::vector<std::uint8_t> fixed(w.poses.size(), 0);
+    fixed[w.currentKeyframe] = 1;
+    std::vector<double> chi2(w.obsPose.size());
+    ms_ba_problem p = detail::as_problem(w, fixed, nullptr, globalBAIterations);
+    ctx.check(ms_ba_solve_host(ctx.get(), &p, w.poses[0].data(), w.points.empty() ? nullptr : w.points[0].data(), chi2.data(), &out.stage1), "ms_ba_solve_host");
+    out.ran = true;
+    out.outlier.resize(chi2.size());
+    for (std::size_t i = 0; i < chi2.size(); ++i) out.outlier[i] = chi2[i] > CHI2_THRESHOLD;   // :586
+    return out;
 }
 
 }  // namespace mi355slam

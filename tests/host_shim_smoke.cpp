@@ -187,6 +187,28 @@ int main(int argc, char **argv) {
     std::printf("BA stage1 chi2 %.3f -> %.3f, stage2 -> %.3f, iterations %d/%d\n", o.stage1.chi2_initial, o.stage1.chi2_final, o.stage2.chi2_final,
                 o.stage1.iterations, o.stage2.iterations);
     if (!(o.stage2.chi2_final <= o.stage1.chi2_initial)) return 4;
+    // globalBundleAdjust-sized map: 200 keyframes on a line (the current one fixed), 1500 points each seen by 8 consecutive keyframes
+    {
+        BaWindow g; g.currentKeyframe = 199;
+        unsigned rng = 99u;
+        auto uni = [&]() { rng = rng * 1664525u + 1013904223u; return (rng >> 8) / 16777216.0; };
+        for (int i = 0; i < 200; ++i) g.poses.push_back({0, 0, 0, 1, -0.2 * i + (i == 199 ? 0.0 : 0.01 * (uni() - 0.5)), 0.004 * (uni() - 0.5), 0});
+        for (int l = 0; l < 1500; ++l) {
+            const int s0 = (int)(uni() * 192);
+            const double X = 0.2 * s0 + 0.7 + 1.5 * (uni() - 0.5), Y = 2.0 * (uni() - 0.5), Z = 4.0 + 5.0 * uni();
+            g.points.push_back({X + 0.02 * (uni() - 0.5), Y + 0.02 * (uni() - 0.5), Z + 0.02 * (uni() - 0.5)});
+            for (int i = s0; i < s0 + 8; ++i) {
+                g.obsPose.push_back(i); g.obsPoint.push_back(l); g.obsUv.push_back({(X - 0.2 * i) / Z + 2e-3 * (uni() - 0.5), Y / Z + 2e-3 * (uni() - 0.5)}); g.obsInfo.push_back(250000.0);
+            }
+        }
+        for (int i = 1; i < 200; ++i) { g.edgeI.push_back(i); g.edgeJ.push_back(i - 1); g.edgeMeas.push_back({0, 0, 0, 1, 0.2, 0, 0});
+            std::array<double, 36> info{}; for (int k = 0; k < 6; ++k) info[7 * k] = 1e3; g.edgeInfo.push_back(info); }
+        BaOutcome go = globalBundleAdjust(ctx, g, 10);
+        int nOut = 0; for (auto o : go.outlier) nOut += o;
+        std::printf("global BA (199 free keyframes): chi2 %.1f -> %.1f in %d iterations, %d of %zu observations above the threshold\n",
+                    go.stage1.chi2_initial, go.stage1.chi2_final, go.stage1.iterations, nOut, go.outlier.size());
+        if (!(go.stage1.chi2_final < 0.2 * go.stage1.chi2_initial) || nOut > (int)go.outlier.size() / 20) return 10;
+    }
     std::printf("host shims ok\n");
     return 0;
 }
