@@ -116,9 +116,11 @@ __device__ __forceinline__ int resize_px(uint64_t w0, uint64_t w1, int k, int a0
     return min(max(v, 0), 255);
 }
 
-constexpr int kResizeRows = 5;   // destination rows per lane: the table fetch is paid once and 30 source dwords are in flight per lane (3..6 measured in one session: 0.571, 0.565, 0.555, 0.556 ms)
+constexpr int kResizeRows = 5;   // destination rows per lane: the table fetch is paid once and 10 source windows (30 dwords) are in flight per lane
 
 struct Window3 { uint32_t d0, d1, d2; };
+typedef uint32_t u3_t __attribute__((ext_vector_type(3)));
+typedef u3_t u3a_t __attribute__((aligned(4)));       // a 12-byte load from a dword-aligned address
 __device__ __forceinline__ Window3 window_load(const uint8_t *row, int base, int last_dword) {
     return {*reinterpret_cast<const uint32_t *>(row + min(base, last_dword)), *reinterpret_cast<const uint32_t *>(row + min(base + 4, last_dword)),
             *reinterpret_cast<const uint32_t *>(row + min(base + 8, last_dword))};
@@ -153,10 +155,25 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs R, ResizeTab T) {
             sel[i] = 0x0C010C00u + (uint32_t)(xt[i].x - sx0) * 0x00010001u;
         }
         Window3 W0[kResizeRows], W1[kResizeRows];
+        // The kernel is bound by the NUMBER of vector-memory instructions (measured: dropping the arithmetic changes nothing, halving the
+        // loads gives -36 %), so the three dwords of a window are ONE 12-byte load wherever no lane of the wave touches the row's last
+        // dwords (a 12-byte load there would run past the row, and past the caller's buffer on the last row of level 0); the wave that
+        // holds a row's right edge keeps the three clamped dword loads.
+        if (__ballot(base + 8 > last) == 0) {
 #pragma unroll
-        for (int r = 0; r < kResizeRows; ++r) {
-            W0[r] = window_load(S + (uint64_t)yt[r].x * spitch, base, last);
-            W1[r] = window_load(S + (uint64_t)yt[r].y * spitch, base, last);
+            for (int r = 0; r < kResizeRows; ++r) {
+                const uint8_t *p0 = S + (uint64_t)yt[r].x * spitch + base, *p1 = S + (uint64_t)yt[r].y * spitch + base;
+                asm volatile("" : "+v"(p0), "+v"(p1));        // keeps the compiler from folding this branch into the clamped one below (equal values, three loads each)
+                const u3_t a = *(const __attribute__((address_space(1))) u3a_t *)(p0), b = *(const __attribute__((address_space(1))) u3a_t *)(p1);   // global_load_dwordx3 (a generic pointer would become a flat load)
+                W0[r] = {a.x, a.y, a.z};
+                W1[r] = {b.x, b.y, b.z};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kResizeRows; ++r) {
+                W0[r] = window_load(S + (uint64_t)yt[r].x * spitch, base, last);
+                W1[r] = window_load(S + (uint64_t)yt[r].y * spitch, base, last);
+            }
         }
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
