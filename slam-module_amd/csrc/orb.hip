@@ -157,16 +157,26 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs R, ResizeTab T) {
         Window3 W0[kResizeRows], W1[kResizeRows];
         // The kernel is bound by the NUMBER of vector-memory instructions (measured: dropping the arithmetic changes nothing, halving the
         // loads gives -36 %), so the three dwords of a window are ONE 12-byte load wherever no lane of the wave touches the row's last
-        // dwords (a 12-byte load there would run past the row, and past the caller's buffer on the last row of level 0); the wave that
-        // holds a row's right edge keeps the three clamped dword loads.
-        if (__ballot(base + 8 > last) == 0) {
+        // dwords (a 12-byte load there would run past the row, and past the caller's buffer on the last row of level 0).
+        const bool edge = __ballot(base + 8 > last) != 0;        // wave-uniform
+        if (!edge || last >= 8) {
+            // edge wave: the 12 bytes are fetched from min(base, last - 8) and moved down by whole dwords afterwards, which reproduces the
+            // clamped dwords exactly (d_k = row[min(base + 4k, last)])
+            const int from = edge ? min(base, last - 8) : base, shift = base - from;       // shift = 0, 4 or 8 bytes
 #pragma unroll
             for (int r = 0; r < kResizeRows; ++r) {
-                const uint8_t *p0 = S + (uint64_t)yt[r].x * spitch + base, *p1 = S + (uint64_t)yt[r].y * spitch + base;
+                const uint8_t *p0 = S + (uint64_t)yt[r].x * spitch + from, *p1 = S + (uint64_t)yt[r].y * spitch + from;
                 asm volatile("" : "+v"(p0), "+v"(p1));        // keeps the compiler from folding this branch into the clamped one below (equal values, three loads each)
                 const u3_t a = *(const __attribute__((address_space(1))) u3a_t *)(p0), b = *(const __attribute__((address_space(1))) u3a_t *)(p1);   // global_load_dwordx3 (a generic pointer would become a flat load)
                 W0[r] = {a.x, a.y, a.z};
                 W1[r] = {b.x, b.y, b.z};
+            }
+            if (edge) {
+#pragma unroll
+                for (int r = 0; r < kResizeRows; ++r) {
+                    W0[r] = {shift == 0 ? W0[r].d0 : shift == 4 ? W0[r].d1 : W0[r].d2, shift == 0 ? W0[r].d1 : W0[r].d2, W0[r].d2};
+                    W1[r] = {shift == 0 ? W1[r].d0 : shift == 4 ? W1[r].d1 : W1[r].d2, shift == 0 ? W1[r].d1 : W1[r].d2, W1[r].d2};
+                }
             }
         } else {
 #pragma unroll
