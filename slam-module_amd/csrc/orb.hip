@@ -859,9 +859,12 @@ __device__ __forceinline__ int wave_sum(int v) {      // DPP inclusive scan, tot
     return __builtin_amdgcn_readlane(wave_scan_add(v), 63);
 }
 
-// Keypoints a wave works on at once.  Measured: 1 at 8 waves per SIMD = 0.60 ms, 2 side by side (5 waves) = 0.64 ms, and the older
-// build at 6 or 7 waves per SIMD also 0.60 ms: k_describe is bound by the throughput of scattered line fetches (1.75 GB of HBM
-// traffic for 0.87 GB of patch bytes), not by occupancy or by the length of a keypoint's dependent chain.
+// Keypoints a wave works on at once.  k_describe is bound by the memory system's throughput of scattered partial-line fetches: 2.0 GB
+// of HBM traffic per 256-frame launch for 0.87 GB of patch bytes, in 0.53 ms = 3.8 TB/s.  Measured without effect on its time: 6, 7
+// or 8 waves per SIMD; two keypoints side by side in a wave (0.64 ms, register pressure) or four one after another with the next
+// one's patches prefetched (0.63 ms); 16-byte row pieces (3 loads per keypoint instead of 11); all outputs in one scattered store; a
+// per-slot table that removes the slot -> counts -> coordinates -> geometry chain of dependent loads; and a quarter fewer VALU
+// instructions (the moment sums below and the degree -> radian product).
 constexpr int kDescPerWave = 1;
 
 struct DescKp { int x, y, oct, tid_out; float ox, oy; bool valid; };
@@ -878,8 +881,8 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     // A keypoint is a chain of dependent memory round trips (its slot -> coordinates -> patch -> angle -> BRIEF samples) and the
     // everything that does not depend on the keypoint is requested up front -- the lane's patch-offset table and the counts of
     // ALL levels in one batch (not one load per loop trip).
-    const uint4 ta = moment_tab[2 * lane], tb = moment_tab[2 * lane + 1];
-    const uint32_t tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+    const uint4 dm = moment_tab[lane];                       // disc mask of the lane's four patch dwords
+    const uint32_t dmask[4] = {dm.x, dm.y, dm.z, dm.w};
     int cnt[MS_MAX_LEVELS];
 #pragma unroll
     for (int l = 0; l < MS_MAX_LEVELS; ++l) cnt[l] = l < levels ? det_count[f * levels + l] : 0;
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     // 39 rows x 40 B of its blurred twin: 11 wave-wide dword loads that touch ~120 cache lines), and the 16 moment samples and 8
     // BRIEF samples of every lane are byte reads from LDS.  Gathered straight from memory the same samples were 24 byte loads that
     // touch ~400 lines per keypoint, and the texture addresser's line rate, not HBM or latency, set the kernel's pace.
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescPerWave][31 * 32 + 39 * 40];
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescPerWave][32 * 32 + 39 * 40];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
@@ -923,13 +926,15 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
         const uint8_t *corner = img + (int64_t)(K[k].y - kHalfPatch) * pitch + (K[k].x - kHalfPatch);
         uint32_t *pu = reinterpret_cast<uint32_t *>(&s_patch[wv][k][0]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                                   // 31 rows x 8 dwords
-            const int i = lane + 64 * t, r = i >> 3, c4 = i & 7;
-            if (i < 31 * 8) pu[i] = reinterpret_cast<const U32u *>(corner + (uint32_t)r * (uint32_t)pitch + 4u * c4)->v;
+        for (int t = 0; t < 4; ++t) {                                   // 31 rows x 8 dwords, everything outside the radius-15 disc zeroed on the way
+            const int i = lane + 64 * t, r = i >> 3, c4 = i & 7;        // (the mask of the 32nd row is zero: it only pads the second half's 16 rows)
+            uint32_t v = 0;
+            if (i < 31 * 8) v = reinterpret_cast<const U32u *>(corner + (uint32_t)r * (uint32_t)pitch + 4u * c4)->v;
+            pu[i] = v & dmask[t];
         }
         const int bp = g->L[K[k].oct].pitch;
         const uint8_t *bcorner = blur_ptr(src, g, f, K[k].oct) + (int64_t)(K[k].y - kPatchRadius) * bp + (K[k].x - kPatchRadius);
-        uint32_t *pb = reinterpret_cast<uint32_t *>(&s_patch[wv][k][31 * 32]);
+        uint32_t *pb = reinterpret_cast<uint32_t *>(&s_patch[wv][k][32 * 32]);
 #pragma unroll
         for (int t = 0; t < 7; ++t) {                                   // 39 rows x 10 dwords
             const int i = lane + 64 * t, r = i / 10, c4 = i - 10 * r;
@@ -938,23 +943,29 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // O1: moments.  The 961 offsets of the 31x31 box are strided over the 64 lanes (offset lane + 64 j); the (u + 15, v + 15) of each
-    // is a host-built table entry (two bytes, the centre with weight zero outside the radius-15 disc), 32 bytes per lane.
+    // O1: moments m10 = sum u I, m01 = sum v I over the disc (orb_extractor.cpp:245-275; integer sums, any order).  Lane = one column
+    // u of one half of the rows (v = -15..0 | 1..16, the 32nd row is zero): 16 byte reads at constant offsets from one address,
+    // S = sum I and J = sum j I; then m10 = u S and m01 = J + v0 S.  The disc shape is already in the data (zeros outside).
+    const int half = lane >= 31 ? 1 : 0, col = lane - 31 * half;
     float angle_deg[kDescPerWave], ca[kDescPerWave], sa[kDescPerWave];
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
-        const uint8_t *pu = &s_patch[wv][k][0];
-        int m10 = 0, m01 = 0;
+        const uint8_t *colp = &s_patch[wv][k][0] + half * (16 * 32) + col;
+        int S = 0, J = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int ub = (int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1), 8), vb = (int)__builtin_amdgcn_ubfe(tw[j >> 1], 16 * (j & 1) + 8, 8);
-            const int I = pu[vb * 32 + ub];
-            m10 += (ub - kHalfPatch) * I;
-            m01 += (vb - kHalfPatch) * I;
+            const int I = colp[j * 32];
+            S += I;
+            J += j * I;
         }
+        int m10 = lane < 62 ? (col - kHalfPatch) * S : 0;
+        int m01 = lane < 62 ? J + (half ? 1 : -kHalfPatch) * S : 0;
         m10 = wave_sum(m10); m01 = wave_sum(m01);
         angle_deg[k] = dev_fast_atan2((float)m01, (float)m10);
-        const float angle = (float)__ddiv_rn(__dmul_rn((double)angle_deg[k], M_PI), 180.0);
+        // float(angleDeg * M_PI / 180.0) in double (orb_extractor.cpp:286).  One multiplication by the double M_PI / 180.0 gives the same
+        // float for EVERY float in [0, 361] (checked exhaustively, tests/test_oracle_frontend.py::test_degree_to_radian_constant_is_exact),
+        // and it replaces a software double division per keypoint.
+        const float angle = (float)__dmul_rn((double)angle_deg[k], M_PI / 180.0);
         ca[k] = dev_cos(angle); sa[k] = dev_sin(angle);
     }
     // O2: steered BRIEF on the blurred patch; the lane's point pairs are shared by the wave's keypoints
@@ -965,7 +976,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
         const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
 #pragma unroll
         for (int k = 0; k < kDescPerWave; ++k) {
-            const uint8_t *pb = &s_patch[wv][k][31 * 32];
+            const uint8_t *pb = &s_patch[wv][k][32 * 32];
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa[k]), __fmul_rn(y1, ca[k])));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca[k]), __fmul_rn(y1, sa[k])));
             const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa[k]), __fmul_rn(y2, ca[k])));
@@ -1008,7 +1019,7 @@ struct ms_orb {
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
     bool wide[MS_MAX_LEVELS] = {false};
-    uint4 *d_moment_tab = nullptr;            // k_describe: (u, v) of the 961 patch offsets, [lane][16] int8 pairs
+    uint4 *d_moment_tab = nullptr;            // k_describe: disc mask of the orientation patch, four dwords per lane
     float4 *d_pattern_f = nullptr;            // k_describe: the 256 BRIEF point pairs as floats
     unsigned long long *d_stamps = nullptr;   // diagnostic: per-phase cycle sums of k_fast (ms_orb_fast_phase_cycles)
     // optional per-stage HIP events (ms_orb_set_profiling)
@@ -1139,19 +1150,22 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         static const int8_t pattern[1024] = {
 #include "orb_pattern.inc"
         };
-        std::vector<uint16_t> mt(64 * 16, (uint16_t)(kHalfPatch | (kHalfPatch << 8)));      // entries are (u + 15, v + 15)
+        // disc mask of the 31 x 31 orientation patch as k_describe stages it: dword i = lane + 64 t covers columns 4 (i & 7) .. + 3 of row
+        // i >> 3; a byte is kept when |u| <= u_max[|v|] (orb_extractor.cpp:174-186, :259-271), the 32nd column and row are cleared
+        std::vector<uint32_t> mt(64 * 4, 0u);
         for (int lane = 0; lane < 64; ++lane)
-            for (int k = 0; k < 16; ++k) {
-                const int i = lane + 64 * k;
-                if (i >= 31 * 31) continue;
-                const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
-                mt[lane * 16 + k] = (uint16_t)(kHalfPatch | (kHalfPatch << 8));                 // outside the disc: the centre pixel with weight (0, 0)
-                if (std::abs(u) <= G.umax[std::min(std::abs(v), 15)]) mt[lane * 16 + k] = (uint16_t)((u + kHalfPatch) | ((v + kHalfPatch) << 8));
+            for (int t = 0; t < 4; ++t) {
+                const int i = lane + 64 * t, r = i >> 3, c4 = i & 7;
+                if (r >= 31) continue;
+                for (int b = 0; b < 4; ++b) {
+                    const int u = 4 * c4 + b - kHalfPatch, v = r - kHalfPatch;
+                    if (u <= kHalfPatch && std::abs(u) <= G.umax[std::abs(v)]) mt[lane * 4 + t] |= 0xFFu << (8 * b);
+                }
             }
         std::vector<float> pf(1024);
         for (int i = 0; i < 1024; ++i) pf[i] = (float)pattern[i];
-        if (hipMalloc(reinterpret_cast<void **>(&o->d_moment_tab), mt.size() * 2) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&o->d_pattern_f), pf.size() * 4) != hipSuccess ||
-            hipMemcpy(o->d_moment_tab, mt.data(), mt.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void **>(&o->d_moment_tab), mt.size() * 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&o->d_pattern_f), pf.size() * 4) != hipSuccess ||
+            hipMemcpy(o->d_moment_tab, mt.data(), mt.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(o->d_pattern_f, pf.data(), pf.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = MS_ERR_HIP;
     }
     if (rc == MS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MS_ERR_HIP;

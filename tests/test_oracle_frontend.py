@@ -193,3 +193,33 @@ def test_min_distance_rule(oracle):
     assert list(zip(xs.tolist(), ys.tolist(), sc.tolist())) == [(40, 40, 220), (90, 60, 150)]
     xs, ys, sc = oracle.detect_level(img, 20, 10, min_dist=7)      # 180 at distance exactly 7 survives (strict <)
     assert sc.tolist() == [220, 180, 150]
+
+
+def test_degree_to_radian_constant_is_exact(tmp_path):
+    """orb_extractor.cpp:286 converts the keypoint angle with float(angleDeg * M_PI / 180.0) in double.  The device multiplies by the
+    double constant M_PI / 180.0 instead of dividing; this checks, for EVERY float in [0, 361], that both give the same float."""
+    import subprocess
+    src = tmp_path / "deg.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+int main(void) {
+    const double c = M_PI / 180.0;
+    uint32_t lo, hi; float f0 = 0.0f, f1 = 361.0f;
+    unsigned long long bad = 0, n = 0;
+    memcpy(&lo, &f0, 4); memcpy(&hi, &f1, 4);
+    for (uint32_t u = lo; u <= hi; ++u, ++n) {
+        float x; memcpy(&x, &u, 4);
+        const float a = (float)(((double)x * M_PI) / 180.0), b = (float)((double)x * c);
+        bad += memcmp(&a, &b, 4) != 0;
+    }
+    printf("%llu %llu\n", n, bad);
+    return 0;
+}
+''')
+    exe = tmp_path / "deg"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
+    n, bad = map(int, subprocess.check_output([str(exe)], text=True).split())
+    assert n > 1_100_000_000 and bad == 0
