@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileM
 //             corner iff score > threshold, so no separate mask test is needed; scores go to the LDS score tile
 //   phase C   3x3 strict-maximum NMS, dense over the corner list, against the LDS score tile; survivors leave as 32-bit keys
 //             ((255-score)<<24 | y*w+x) with ONE global atomic per tile
-constexpr int kFastSeg = 248, kFastRows = 14, kFastPosRows = kFastRows + 2, kFastRowsPerWave = kFastPosRows / 4;
+constexpr int kFastWaves = 8, kFastThreads = 64 * kFastWaves;     // waves per tile: 4 position rows each
+constexpr int kFastSeg = 248, kFastRows = 4 * kFastWaves - 2, kFastPosRows = kFastRows + 2, kFastRowsPerWave = 4;
 constexpr int kFastPositions = kFastPosRows * (kFastSeg + 2);   // scored positions of a tile: columns 3..252 of 16 rows.  Keeps LDS at 20 256 B = 8 workgroups per CU
 
 __device__ __forceinline__ bool contig9(uint32_t m) {
@@ -450,7 +451,7 @@ __device__ __forceinline__ void list_append_top_bit(uint32_t &m, uint32_t &at, u
 }
 
 template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
-__global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
+__global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
                                               unsigned long long *__restrict__ stamps, TileMap tm, TileLevels TL) {
     long long t_prev = STAMP ? clock64() : 0;
     auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPositions + 8];     // compass survivors (+ dump slot); each wave's corners overwrite its own consumed slots
     __shared__ __attribute__((aligned(16))) uint8_t s_pix[(kFastPosRows + 6) * 256]; // the tile's pixels (image rows Y0-4 .. Y0+17) for the ring reads; NMS keys afterwards
     __shared__ int s_np, s_m, s_base;
-    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pix);              // 1408 keys >= 124*7 possible NMS survivors
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pix);              // (rows + 6) * 64 keys >= 124 * rows / 2 possible NMS survivors
     int t = blockIdx.x;
     const int l = tile_level(tm, TL.levels, t);
     t -= tm.base[l];
@@ -481,11 +482,11 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
         for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
     }
     if (tid == 0) { s_np = 0; s_m = 0; }
-    for (int i = tid; i < kFastPosRows * 256 / 4; i += 256) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
+    for (int i = tid; i < kFastPosRows * 256 / 4; i += kFastThreads) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
     // the rows go to LDS as well: wave w owns tile rows 4w .. 4w+3 (image rows Y0-4+4w ..), the last wave also the six below
 #pragma unroll
     for (int r = 0; r < kFastRowsPerWave + 6; ++r)
-        if (r < kFastRowsPerWave || wave == 3) reinterpret_cast<uint32_t *>(s_pix)[(wave * kFastRowsPerWave + r) * 64 + lane] = rows[r];
+        if (r < kFastRowsPerWave || wave == kFastWaves - 1) reinterpret_cast<uint32_t *>(s_pix)[(wave * kFastRowsPerWave + r) * 64 + lane] = rows[r];
     __syncthreads();
     stamp(0);      // setup + LDS clear
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
@@ -548,10 +549,10 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     //      v_pk_min_i16 / v_pk_max_i16 levels (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
     //      The ring comes from the tile's pixels in LDS (17 byte reads with immediate offsets from one base): as 7 wide global loads per
     //      survivor the texture addresser had ~30 cache lines to look up per instruction.  A wave appends its corners IN PLACE, into the
-    //      slots of the survivor list it has already consumed (slots 64w + 256i + j belong to wave w), so no second list is needed.
+    //      slots of the survivor list it has already consumed (slots 64w + kFastThreads i + j belong to wave w), so no second list is needed.
     const int np = s_np;
     int ncw = 0;                                                         // corners of this wave so far (wave-uniform)
-    for (int i = tid; i < np; i += 256) {
+    for (int i = tid; i < np; i += kFastThreads) {
         const int e = s_pre[i], pr = e >> 8, c = e & 255;
         const uint8_t *q = s_pix + pr * 256 + (c - 3);                   // top-left of the 7x7 box: tile row pr + 3 is the centre's
         uint32_t R[9];
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
         if (corner) {
             const int slot = ncw + mbcnt64(cm);
             s_sc[pr][c] = (uint8_t)best;
-            s_pre[64 * wave + 256 * (slot >> 6) + (slot & 63)] = (uint16_t)e;
+            s_pre[64 * wave + kFastThreads * (slot >> 6) + (slot & 63)] = (uint16_t)e;
         }
         ncw += (int)__popcll(cm);
     }
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     // ---- phase C: 3x3 strict-maximum NMS, dense over the corner list (only outputs: px X0..X0+247 = columns 4..251,
     //      rows Y0..Y0+13 = position rows 1..14; the halo corners only serve as neighbours)
     for (int i = lane; i < ncw; i += 64) {                               // every wave walks its own corner sublist
-        const int e = s_pre[64 * wave + 256 * (i >> 6) + (i & 63)], pr = e >> 8, c = e & 255;
+        const int e = s_pre[64 * wave + kFastThreads * (i >> 6) + (i & 63)], pr = e >> 8, c = e & 255;
         const int px = X0 - 4 + c, y = Y0 - 1 + pr;
         if (pr < 1 || pr > kFastRows || c < 4 || c > 251 || px >= w || y >= h) continue;
         const int sc = s_sc[pr][c];
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameSrc src, const PyrGeom *g, ui
     if (tid == 0) s_base = atomicAdd(&cand_count[f * TL.levels + l], m);
     __syncthreads();
     stamp(7);      // global atomic + barrier
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += kFastThreads) {
         const int pos = s_base + i;
         if (pos < G.cand_cap) cand[(uint64_t)f * TL.cand_stride + G.cand_off + pos] = s_out[i];
     }
@@ -1300,8 +1301,8 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->tile_levels, o->blur_tiles);
     MS_KERNEL_CHECK(c, "k_blur");
     MS_STAGE_MARK();
-    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->fast_tiles, o->tile_levels);
-    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(256), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->fast_tiles, o->tile_levels);
+    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->fast_tiles, o->tile_levels);
+    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->fast_tiles, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
     if (o->cfg.min_distance > 0.f)
