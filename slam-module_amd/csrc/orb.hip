@@ -452,7 +452,7 @@ __device__ __forceinline__ void list_append_top_bit(uint32_t &m, uint32_t &at, u
 
 template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
 __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
-                                              unsigned long long *__restrict__ stamps, TileMap tm, TileLevels TL) {
+                                              unsigned long long *__restrict__ stamps, const uint32_t *__restrict__ tile_tab, TileLevels TL) {
     long long t_prev = STAMP ? clock64() : 0;
     auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
     __shared__ uint8_t s_sc[kFastPosRows][256];                                      // score tile (columns 2..253 are touched)
@@ -460,12 +460,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
     __shared__ __attribute__((aligned(16))) uint8_t s_pix[(kFastPosRows + 6) * 256]; // the tile's pixels (image rows Y0-4 .. Y0+17) for the ring reads; NMS keys afterwards
     __shared__ int s_np, s_m, s_base;
     uint32_t *s_out = reinterpret_cast<uint32_t *>(s_pix);              // (rows + 6) * 64 keys >= 124 * rows / 2 possible NMS survivors
-    int t = blockIdx.x;
-    const int l = tile_level(tm, TL.levels, t);
-    t -= tm.base[l];
+    // The scalar unit is shared by the CU's four SIMDs and every wave of a tile repeats the tile's scalar work, so that work is kept
+    // short: the tile's level, row and column come packed from a host-built table (one scalar load instead of a 15-step search and
+    // a division), and the ten row addresses of an interior wave are one 64-bit base plus the pitch (2 scalar adds per row instead
+    // of two clamps, a 64-bit multiply and an add).
+    const uint32_t te = tile_tab[blockIdx.x];
+    const int l = (int)(te & 15u);
     const TileLevel G = TL.L[l];                       // one batch of loads; everything below is arithmetic on it
-    const int trow = G.ftiles_x == 1 ? t : (int)__umulhi((uint32_t)t, G.ftiles_inv);     // t / ftiles_x without the division sequence (2^32 / 1 does not fit)
-    const int X0 = (t - trow * G.ftiles_x) * kFastSeg, Y0 = trow * kFastRows;
+    const int X0 = (int)((te >> 4) & 0xFFFu) * kFastSeg, Y0 = (int)(te >> 16) * kFastRows;
     const int f = blockIdx.y, w = G.w, h = G.h, thr = TL.fast_threshold;
     const int pitch = l == 0 ? src.lvl0_pitch : G.pitch;
     const uint8_t *img = l == 0 ? src.lvl0 + (uint64_t)f * src.lvl0_frame_stride : src.slab + (uint64_t)f * TL.slab_stride + G.img_off;
@@ -474,9 +476,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
     const int x = X0 - 4 + 4 * lane;
     uint32_t rows[kFastRowsPerWave + 6];
     const int yw = Y0 - 1 + wave * kFastRowsPerWave;
-    if (__ballot(!(x >= 0 && x + 3 < w)) == 0) {     // whole wave inside the row: plain dword loads, one uniform branch
+    if (__ballot(!(x >= 0 && x + 3 < w)) == 0 && yw >= 3 && yw + kFastRowsPerWave + 2 < h) {     // whole wave inside the image: plain dword loads, one uniform branch
+        const uint8_t *rp = img + (int64_t)(yw - 3) * pitch;
 #pragma unroll
-        for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = *reinterpret_cast<const uint32_t *>(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch + x);
+        for (int r = 0; r < kFastRowsPerWave + 6; ++r) { rows[r] = *reinterpret_cast<const uint32_t *>(rp + x); rp += pitch; }
     } else {
 #pragma unroll
         for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
@@ -1005,6 +1008,7 @@ struct ms_orb {
     PyrGeom geom{};
     PyrGeom *d_geom = nullptr;
     TileMap blur_tiles{}, fast_tiles{};
+    uint32_t *d_ftile_tab = nullptr;   // k_fast: level | column << 4 | row << 16 of every tile
     TileLevels tile_levels{};          // per-level geometry of the tiled kernels, passed by value
     uint8_t *d_slab = nullptr;
     uint32_t *d_cand = nullptr;
@@ -1147,6 +1151,16 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         };
         up(&o->d_xtab[l], xt); up(&o->d_ytab[l], yt);
     }
+    if (rc == MS_OK) {                                   // k_fast's tile table: level | column << 4 | row << 16
+        std::vector<uint32_t> tt;
+        for (int l = 0; l < cfg->levels; ++l) {
+            const int tx = G.L[l].ftiles_x, ty = ms_div_up(G.L[l].h, kFastRows);
+            if (tx > 0xFFF || ty > 0xFFFF) { rc = MS_ERR_INVALID; break; }
+            for (int r = 0; r < ty; ++r) for (int cx = 0; cx < tx; ++cx) tt.push_back((uint32_t)l | ((uint32_t)cx << 4) | ((uint32_t)r << 16));
+        }
+        if (rc == MS_OK && ((int)tt.size() != G.ftiles_total || hipMalloc(reinterpret_cast<void **>(&o->d_ftile_tab), tt.size() * 4 + 16) != hipSuccess ||
+                            hipMemcpy(o->d_ftile_tab, tt.data(), tt.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = MS_ERR_HIP;
+    }
     if (rc == MS_OK) {                                   // k_describe's lane tables
         static const int8_t pattern[1024] = {
 #include "orb_pattern.inc"
@@ -1186,6 +1200,7 @@ void ms_orb_destroy(ms_orb *o) {
     if (o->d_stamps) (void)hipFree(o->d_stamps);
     if (o->d_moment_tab) (void)hipFree(o->d_moment_tab);
     if (o->d_pattern_f) (void)hipFree(o->d_pattern_f);
+    if (o->d_ftile_tab) (void)hipFree(o->d_ftile_tab);
     for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
 
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
@@ -1301,8 +1316,8 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->tile_levels, o->blur_tiles);
     MS_KERNEL_CHECK(c, "k_blur");
     MS_STAGE_MARK();
-    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->fast_tiles, o->tile_levels);
-    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->fast_tiles, o->tile_levels);
+    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->d_ftile_tab, o->tile_levels);
+    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->d_ftile_tab, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
     if (o->cfg.min_distance > 0.f)
