@@ -291,11 +291,22 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileM
     // the column test is the same for every row of a lane: ONE wave-uniform branch picks the plain-dword path for whole waves
     // (per-load branches cost scalar instructions, and the scalar unit is shared by the CU's four SIMDs)
     if (__ballot(!(x >= 0 && x + 3 < w)) == 0) {
+        if (y0 >= 3 && y0 + kBlurRows + 2 < h) {           // no row is reflected: one 64-bit base, the pitch added per row (scalar work is shared by the CU)
+            const uint8_t *rp = img + (int64_t)(y0 - 3) * pitch;
 #pragma unroll
-        for (int r = 0; r < kBlurRows + 6; ++r) {
-            const uint32_t d = *reinterpret_cast<const uint32_t *>(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch + x);
-            e[r] = d & 0x00FF00FFu;
-            o[r] = (d >> 8) & 0x00FF00FFu;
+            for (int r = 0; r < kBlurRows + 6; ++r) {
+                const uint32_t d = *reinterpret_cast<const uint32_t *>(rp + x);
+                rp += pitch;
+                e[r] = d & 0x00FF00FFu;
+                o[r] = (d >> 8) & 0x00FF00FFu;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < kBlurRows + 6; ++r) {
+                const uint32_t d = *reinterpret_cast<const uint32_t *>(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch + x);
+                e[r] = d & 0x00FF00FFu;
+                o[r] = (d >> 8) & 0x00FF00FFu;
+            }
         }
     } else {
 #pragma unroll
