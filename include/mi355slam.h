@@ -333,6 +333,10 @@ void ms_ba_destroy(ms_ba *ba);
  * Levenberg-Marquardt loop in one workgroup, up to 64.  Results agree to rounding (sums are combined in a fixed order per
  * team size; the reference's own order is unspecified).  A single local-BA window is ~4x faster with a team. */
 int ms_ba_set_team(ms_ba *ba, int workgroups_per_problem);
+/* Of a team, the workgroups that share the distributed Cholesky factorisation of a system with more than 176 free poses
+ * (0 = automatic: one per 16 row tiles a panel touches, so a banded trajectory is factored by one workgroup without team barriers
+ * and a densely coupled map by many).  Has no effect on smaller systems. */
+int ms_ba_set_factor_team(ms_ba *ba, int workgroups);
 int ms_ba_solve(ms_ba *ba);
 /* Results of problem i (synchronises): poses [n_pose*7], points [n_point*3], per-observation chi2
  * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL. */

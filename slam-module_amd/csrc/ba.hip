@@ -42,6 +42,7 @@ constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesk
 struct BaProb {
     int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters;
     int32_t team;                            // workgroups that share this problem (1 = the whole solve in one workgroup)
+    int32_t chol_team;                       // of these, the workgroups that share the distributed Cholesky (systems beyond kMaxFreePoses)
     double huber;
     // state
     double *pose, *pose_bk, *point, *point_bk;
@@ -65,6 +66,7 @@ struct BaProb {
     const double *zrow;                      // n6 + 16 zeros
     double *dinv;                            // [n6] reciprocals of the Cholesky diagonal
     double *panG;                            // [(n6+1) x 16] Cholesky panel in global memory, only for systems beyond kMaxFreePoses (else null)
+    const int32_t *act_start, *act_blk;      // with panG: per 16-column panel the row tiles (relative to the panel) whose envelope reaches it, CSR
     const int32_t *env16;                    // [n6/16 + 2] envelope of S per 16-row block: first structurally non-zero column (0 for the rhs row's block)
     // team state (team > 1): arrival counter (monotonic, one 128-B line), per-workgroup partial sums [2][team][2], solve status
     uint32_t *bar;
@@ -299,18 +301,17 @@ __device__ double block_max(double v, double *s_red) {
     const int gt = rank_ * NT + tid, GT = T_ * NT, gw = rank_ * NW + wave, GW = T_ * NW;                         \
     (void)lane; (void)wave; (void)gt; (void)GT; (void)gw; (void)GW;
 
-__device__ __noinline__ void team_sync(const BaProb &P) {
-    if (P.team == 1) { __syncthreads(); return; }
+__device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, uint32_t T) {
+    if (T == 1) { __syncthreads(); return; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t T = (uint32_t)P.team;
-        const uint32_t a = __hip_atomic_fetch_add(P.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t a = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t target = (a / T + 1u) * T;
         int spins = 0;
-        while ((int32_t)(__hip_atomic_load(P.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(8);
             // give up after ~1 s (or as soon as another workgroup has): every later barrier then falls through at once
             if (++spins > (1 << 20) || __hip_atomic_load(P.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -323,6 +324,9 @@ __device__ __noinline__ void team_sync(const BaProb &P) {
     }
     __syncthreads();
 }
+__device__ __noinline__ void team_sync(const BaProb &P) { group_sync(P, P.bar, (uint32_t)P.team); }
+// barrier of the first P.chol_team workgroups only (the distributed factorisation), on a counter of its own (P.bar + 32: another 128-byte line)
+__device__ __noinline__ void chol_sync(const BaProb &P) { group_sync(P, P.bar + 32, (uint32_t)P.chol_team); }
 
 // Sum / maximum over the team, the same value (bit for bit) in every workgroup: partials are combined in rank order.
 // `which` alternates per call site sequence so a fast workgroup cannot overwrite partials a slow one still reads.
@@ -649,6 +653,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // Left-looking update of the 16-column panel at c0 with the finished columns [0, c0), row tiles tile0, tile0 + tstride, ...
 // (two per trip): result rows go to pan[(row - c0) * NB + col], in LDS for the single-workgroup factorisation, in global
 // memory when the tiles of a panel are spread over a team.
+template <bool LIST>   // LIST: walk the host-built list of the panel's active row tiles instead of testing every tile's envelope (large systems)
 __device__ __forceinline__ void chol_panel_update(const BaProb &P, int c0, int nb, int m, double *pan, int tile0, int tstride, int lane) {
     const int n = P.n6;
     // left-looking update of the 16-column panel with the finished columns [0, c0): a dense
@@ -665,8 +670,10 @@ __device__ __forceinline__ void chol_panel_update(const BaProb &P, int c0, int n
     const int pblk = c0 / NB, penv = env[pblk];
     const int q = lane >> 4, jb = lane & 15;
     const MS_GLOBAL d2_t *bp2 = reinterpret_cast<const MS_GLOBAL d2_t *>(((jb < nb) ? Sg + (size_t)(c0 + jb) * n : zg) + 4 * q);
-    for (int rt = tile0; rt * 16 < m; rt += 2 * tstride) {
-        const int rt2 = rt + tstride;
+    const MS_GLOBAL int32_t *al = LIST ? (const MS_GLOBAL int32_t *)P.act_blk + P.act_start[pblk] : nullptr;
+    const int n_act = LIST ? P.act_start[pblk + 1] - P.act_start[pblk] : 0, beyond = (m + 15) / 16 + 1;
+    for (int jt = tile0; LIST ? jt < n_act : jt * 16 < m; jt += 2 * tstride) {
+        const int rt = LIST ? al[jt] : jt, rt2 = LIST ? (jt + tstride < n_act ? al[jt + tstride] : beyond) : jt + tstride;
         const int e1 = env[pblk + rt], e2 = rt2 * 16 < m ? env[pblk + rt2] : 0x7fffffff;
         const bool act1 = e1 <= c0 + NB - 1, act2 = e2 <= c0 + NB - 1;
         if (!act1 && !act2) continue;                       // wave-uniform
@@ -798,7 +805,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
     const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
     for (int c0 = 0; c0 < n; c0 += NB) {
         const int nb = min(NB, n - c0), m = n - c0 + 1, cnt = m * NB;
-        chol_panel_update(P, c0, nb, m, pan, wave, NW, lane);
+        chol_panel_update<false>(P, c0, nb, m, pan, wave, NW, lane);
         __syncthreads();
         if (wave == 0) {
             double r[NB], di;
@@ -845,15 +852,16 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
 __device__ __noinline__ void cholesky_factor_team(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     BA_IDS
-    const int n = P.n6;
+    const int n = P.n6, CT = P.chol_team;            // workgroups that take part (the rest wait at the caller's team barrier)
+    if (rank_ >= CT) return;
+    const int cgt = rank_ * NT + tid, CGT = CT * NT, cgw = rank_ * NW + wave, CGW = CT * NW;
     double *pan = P.panG;                           // [(n+1)][NB] in global memory
     double *sd = lds_;                              // [NB][NB] factored diagonal block
     double *tvec = lds_ + NB * NB;                  // [NB] reciprocal pivots
-    const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
     for (int c0 = 0; c0 < n; c0 += NB) {
         const int nb = min(NB, n - c0), m = n - c0 + 1;
-        chol_panel_update(P, c0, nb, m, pan, gw, GW, lane);
-        team_sync(P);
+        chol_panel_update<true>(P, c0, nb, m, pan, cgw, CGW, lane);
+        chol_sync(P);
         if (wave == 0) {
             double r[NB], di;
             const bool ok = chol_factor_diag(pan, nb, lane, r, di);
@@ -868,8 +876,11 @@ __device__ __noinline__ void cholesky_factor_team(const BaProb &P_, double *lds_
             }
         }
         __syncthreads();
-        for (int i = nb + gt; i < m; i += GT) {      // rows below: x L11^T = a
-            if (env[(c0 + i) / NB] > c0 + NB - 1) continue;
+        const MS_GLOBAL int32_t *al = (const MS_GLOBAL int32_t *)P.act_blk + P.act_start[c0 / NB];
+        const int n_act = P.act_start[c0 / NB + 1] - P.act_start[c0 / NB];
+        for (int idx = cgt; idx < n_act * 16; idx += CGT) {      // rows below, active tiles only: x L11^T = a
+            const int i = al[idx >> 4] * 16 + (idx & 15);
+            if (i < nb || i >= m) continue;
             double x[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -883,7 +894,7 @@ __device__ __noinline__ void cholesky_factor_team(const BaProb &P_, double *lds_
 #pragma unroll
             for (int j = 0; j < NB; ++j) if (j < nb) dst[j] = x[j];
         }
-        team_sync(P);
+        chol_sync(P);
     }
 }
 
@@ -941,7 +952,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
 // before a team launch: arrival counters and the gave-up marker back to zero (the counter is monotonic within a launch)
 __global__ void k_ba_team_reset(const BaProb *probs, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { probs[i].bar[0] = 0; probs[i].flag[1] = 0; }
+    if (i < n) { probs[i].bar[0] = 0; probs[i].bar[32] = 0; probs[i].flag[1] = 0; }
 }
 
 // grid = problems x team workgroups; workgroup b works on problem b / team
@@ -1044,6 +1055,8 @@ struct ms_ba {
     char *d_arena = nullptr;
     size_t arena_bytes = 0;
     int team = 0;                      // workgroups per problem of the next launch (ms_ba_set_team; 0 = automatic)
+    int factor_team = 0;               // of these, workgroups in the distributed Cholesky of a large system (ms_ba_set_factor_team; 0 = automatic)
+    std::vector<double> chol_tiles;    // per problem: row tiles a Cholesky panel touches on average
     int cus = 0;
 };
 
@@ -1054,12 +1067,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16; int np_free = 0, n_chunks = 0, n_seg = 0; };
+    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -1143,6 +1156,19 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 for (int r = 16 * b; r < 16 * b + 16; ++r) e = r < n6i ? std::min(e, 6 * first[r / 6]) : 0;     // the rhs row (r = n6) is dense
                 R.env16[b] = std::min(e, n6i);
             }
+            // row tiles a Cholesky panel touches on average (those whose envelope reaches the panel): sizes the factorisation's sub-team
+            const int nblk = n6i / 16 + 1;
+            long long act = 0;
+            for (int pb = 0; pb * 16 < n6i; ++pb) for (int b = pb; b <= nblk; ++b) act += R.env16[(size_t)std::min(b, (int)R.env16.size() - 1)] <= pb * 16 + 15;
+            R.chol_tiles = n6i ? (double)act / ((n6i + 15) / 16) : 0.0;
+            if (np > kMaxFreePoses) {                   // the distributed factorisation walks these lists
+                R.act_start.push_back(0);
+                for (int pb = 0; pb * 16 < n6i; ++pb) {
+                    const int m_rows = n6i - pb * 16 + 1;
+                    for (int rt = 0; rt * 16 < m_rows; ++rt) if (R.env16[(size_t)std::min(pb + rt, (int)R.env16.size() - 1)] <= pb * 16 + 15) R.act_blk.push_back(rt);
+                    R.act_start.push_back((int32_t)R.act_blk.size());
+                }
+            }
         }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
@@ -1156,6 +1182,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.edge_meas = bump(7 * Q.n_pose_edge * D); O.edge_info = bump(36 * Q.n_pose_edge * D);
         O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
         O.env16 = bump(4 * R.env16.size());
+        O.act_start = bump(4 * R.act_start.size()); O.act_blk = bump(4 * R.act_blk.size());
         in_hi[p] = total;
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
@@ -1187,6 +1214,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.fstart, R.fstart.data(), 4 * (R.np_free + 1)); up(O.fobs, R.fobs.data(), 4 * R.fobs.size()); up(O.free2pose, R.free2pose.data(), 4 * R.np_free);
         up(O.chunk_items, R.chunk_items.data(), 4 * R.chunk_items.size()); up(O.seg_start, R.seg_start.data(), 4 * R.seg_start.size()); up(O.seg_pair, R.seg_pair.data(), 4 * R.seg_pair.size());
         up(O.env16, R.env16.data(), 4 * R.env16.size());
+        up(O.act_start, R.act_start.data(), 4 * R.act_start.size()); up(O.act_blk, R.act_blk.data(), 4 * R.act_blk.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
         if (hipMemcpyAsync(B->d_arena + in_lo[p], stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
@@ -1206,10 +1234,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.chi2_obs = PTR(double, chi2); H.stats = PTR(double, stats);
         H.n_chunks = R.n_chunks; H.n_seg = R.n_seg; H.chunk_items = PTR(int32_t, chunk_items); H.seg_start = PTR(int32_t, seg_start); H.seg_pair = PTR(int32_t, seg_pair);
         H.env16 = PTR(int32_t, env16);
+        H.act_start = PTR(int32_t, act_start); H.act_blk = PTR(int32_t, act_blk);
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
         H.dinv = PTR(double, dinv);
         H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
-        H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1;
+        H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1; H.chol_team = 1;
+        B->chol_tiles.push_back(R.chol_tiles);
 #undef PTR
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1236,6 +1266,12 @@ int ms_ba_set_team(ms_ba *B, int workgroups_per_problem) {
     return MS_OK;
 }
 
+int ms_ba_set_factor_team(ms_ba *B, int workgroups) {
+    if (!B || workgroups < 0 || workgroups > kMaxTeam) return MS_ERR_INVALID;
+    B->factor_team = workgroups;
+    return MS_OK;
+}
+
 int ms_ba_solve(ms_ba *B) {
     if (!B) return MS_ERR_INVALID;
     ms_ctx *c = B->ctx;
@@ -1248,7 +1284,14 @@ int ms_ba_solve(ms_ba *B) {
     for (const auto &h : B->host) most_obs = std::max(most_obs, h.n_obs);
     int team = B->team == 0 ? std::min(32, std::max(1, most_obs / 512)) : B->team;      // small problems are latency-bound on the barriers
     team = std::max(1, std::min(team, B->cus / std::max(B->n, 1)));
-    if (team != B->host[0].team) {
+    // the distributed factorisation is barrier-bound on banded systems: it gets one workgroup per 16 row tiles a panel touches
+    bool changed = team != B->host[0].team;
+    for (int i = 0; i < B->n; ++i) {
+        const int ct = std::max(1, std::min(team, B->factor_team > 0 ? B->factor_team : (int)std::ceil(B->chol_tiles[(size_t)i] / 16.0)));
+        changed |= ct != B->host[(size_t)i].chol_team;
+        B->host[(size_t)i].chol_team = ct;
+    }
+    if (changed) {
         for (auto &h : B->host) h.team = team;
         MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
     }

@@ -536,6 +536,9 @@ class BundleAdjuster:
     def set_team(self, workgroups_per_problem):
         self.ctx.check(lib().ms_ba_set_team(self._h, int(workgroups_per_problem)), "ms_ba_set_team")
 
+    def set_factor_team(self, workgroups):
+        self.ctx.check(lib().ms_ba_set_factor_team(self._h, int(workgroups)), "ms_ba_set_factor_team")
+
     def solve(self):
         self.ctx.check(lib().ms_ba_solve(self._h), "ms_ba_solve")
 

@@ -113,8 +113,8 @@ def test_global_ba_beyond_the_lds_panel(oracle, ctx):
     import mi355slam
     p = ba_synth.make_problem(220, 2200, 12, seed=91, fix_first=True, yaw_total=0.05, z_drift=0.005)
     want = oracle.ba_solve(p, 8, False)
-    for team in (0, 1, 3, 32):
-        ba = mi355slam.BundleAdjuster(ctx, [p], max_iters=8); ba.set_team(team); ba.solve()
+    for team, factor_team in ((0, 0), (1, 0), (3, 3), (32, 32), (32, 5), (16, 1)):
+        ba = mi355slam.BundleAdjuster(ctx, [p], max_iters=8); ba.set_team(team); ba.set_factor_team(factor_team); ba.solve()
         _check(p, ba.download(0), want)
         ba.close()
     q = ba_synth.make_problem(420, 4000, 10, seed=92, fix_first=True, yaw_total=0.03, z_drift=0.003)
@@ -124,8 +124,8 @@ def test_global_ba_beyond_the_lds_panel(oracle, ctx):
     q["edge_i"] = np.concatenate([q["edge_i"], extra[:, 0]]); q["edge_j"] = np.concatenate([q["edge_j"], extra[:, 1]])
     q["edge_meas"] = np.concatenate([q["edge_meas"], np.array(meas).reshape(-1, 7)]); q["edge_info"] = np.concatenate([q["edge_info"], q["edge_info"][:2]])
     outs = []
-    for team in (0, 7):
-        ba = mi355slam.BundleAdjuster(ctx, [q], max_iters=10); ba.set_team(team); ba.solve()
+    for team, factor_team in ((0, 0), (7, 7)):
+        ba = mi355slam.BundleAdjuster(ctx, [q], max_iters=10); ba.set_team(team); ba.set_factor_team(factor_team); ba.solve()
         outs.append(ba.download(0)); ba.close()
     a, b = outs
     assert a["stats"]["chi2_final"] < 0.02 * a["stats"]["chi2_init"]
