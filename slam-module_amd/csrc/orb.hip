@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t *src, uint64_
 // (12 bytes cover the <= 8-byte tap window of its 4 pixels for scale factors up to 2) and funnel-shifts
 // them into a 64-bit window; the per-column (offset, a0, a1) and per-row (row0, row1, b0, b1) tables are
 // packed so a lane needs two 16-byte table loads.  HBM-bound by design: reads level l-1, writes level l.
+// unaligned dword / qword accesses (global memory takes them)
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 typedef short s2_t __attribute__((ext_vector_type(2)));
 
@@ -403,8 +406,6 @@ __device__ __forceinline__ void fast_ring_load(const uint8_t *p, int pitch, uint
 
 // The same ring from 7 loads: rows +-3 as one dword at x-1, rows +-2 as a dwordx2 at x-2, rows 0 and +-1 as a dwordx2 at x-3
 // (global memory takes unaligned dword accesses); one v_perm_b32 per opposite pixel pair builds R[k].
-struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
-struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
 __device__ __forceinline__ void fast_ring_load_wide(const uint8_t *p, int pitch, uint32_t R[9]) {
     const uint32_t a3 = reinterpret_cast<const U32u *>(p + 3 * pitch - 1)->v, am3 = reinterpret_cast<const U32u *>(p - 3 * pitch - 1)->v;
     const U64u b2 = *reinterpret_cast<const U64u *>(p + 2 * pitch - 2), bm2 = *reinterpret_cast<const U64u *>(p - 2 * pitch - 2);
@@ -492,8 +493,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
 #pragma unroll
         for (int r = 0; r < kFastRowsPerWave + 6; ++r) { rows[r] = *reinterpret_cast<const uint32_t *>(rp + x); rp += pitch; }
     } else {
+        // a wave on the image border: still ONE dword load per row and lane (a third of all waves are such waves; per-byte loads with
+        // their branches made them cost three times an interior wave).  The address is clamped into the row, a lane that straddles the
+        // right edge shifts its pixels down, pixels outside the image are zero.
+        const int xa = min(max(x, 0), w - 4);
+        const uint32_t sh = (uint32_t)(8 * (x - xa)) & 31u, keep = (x >= 0 && x < w) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-        for (int r = 0; r < kFastRowsPerWave + 6; ++r) rows[r] = load4_zero(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch, x, w);
+        for (int r = 0; r < kFastRowsPerWave + 6; ++r)
+            rows[r] = (reinterpret_cast<const U32u *>(img + (uint64_t)min(max(yw - 3 + r, 0), h - 1) * pitch + xa)->v >> sh) & keep;
     }
     if (tid == 0) { s_np = 0; s_m = 0; }
     for (int i = tid; i < kFastPosRows * 256 / 4; i += kFastThreads) reinterpret_cast<uint32_t *>(&s_sc[0][0])[i] = 0;
