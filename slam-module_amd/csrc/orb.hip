@@ -312,9 +312,30 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileM
             }
         }
     } else {
+        // A wave on the left or right border (a third of all waves): BORDER_REFLECT_101 without per-byte loads.  Every reflected or
+        // straddling pixel of the row lies in its first or last 8 bytes, so the wave fetches those two dwords (one address for all
+        // lanes) and a border lane picks its 4 bytes out of them with ONE v_perm whose selector depends only on the lane, not on the row.
+        const int xa = min(max(x, 0), w - 4);
+        const bool is_l = x < 0, is_r = x > w - 4;
+        uint32_t sel_r = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = x + i;
+            sel_r |= (uint32_t)((p < w ? p - (w - 8) : (w + 6) - p) & 7) << (8 * i);       // byte of the window [w-8, w-1] that holds pixel reflect(p)
+        }
+        const bool wave_l = __ballot(is_l) != 0, wave_r = __ballot(is_r) != 0;
 #pragma unroll
         for (int r = 0; r < kBlurRows + 6; ++r) {
-            const uint32_t d = load4_reflect(img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch, x, w);
+            const uint8_t *row = img + (uint64_t)reflect101(y0 - 3 + r, h) * pitch;
+            uint32_t d = reinterpret_cast<const U32u *>(row + xa)->v;
+            if (wave_l) {                                        // pixels -4..-1 = pixels 4, 3, 2, 1
+                const uint32_t f0 = reinterpret_cast<const U32u *>(row)->v, f1 = reinterpret_cast<const U32u *>(row + 4)->v;
+                d = is_l ? __builtin_amdgcn_perm(f1, f0, 0x01020304u) : d;
+            }
+            if (wave_r) {
+                const uint32_t e0 = reinterpret_cast<const U32u *>(row + (w - 8))->v, e1 = reinterpret_cast<const U32u *>(row + (w - 4))->v;
+                d = is_r ? __builtin_amdgcn_perm(e1, e0, sel_r) : d;
+            }
             e[r] = d & 0x00FF00FFu;
             o[r] = (d >> 8) & 0x00FF00FFu;
         }
