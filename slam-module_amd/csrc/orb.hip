@@ -276,6 +276,7 @@ __device__ __forceinline__ int wave_scan_add(int v) {
 
 constexpr int kBlurSeg = 248;   // outputs per wave row segment
 constexpr int kBlurRows = 18;   // output rows per wave (+ 6 halo rows loaded).  Measured in one session: 8 -> 0.61 ms, 14 -> 0.53, 16 -> 0.67 (64-row tiles: row starts collide), 18 -> 0.51, 28 -> 0.51
+// (8 pixels per lane with 8-byte loads and stores -- half the memory instructions per pixel -- was built and measured: 0.60 ms against 0.51, at 6..10 rows per wave)
 
 __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileMap tm) {
     int t = blockIdx.x;
