@@ -140,11 +140,6 @@ int ms_orb_capacity(const ms_orb *orb);
 #define MS_ORB_STAGES 6
 int ms_orb_set_profiling(ms_orb *orb, int enable);
 int ms_orb_stage_ms(ms_orb *orb, float *ms /* [MS_ORB_STAGES] */);
-/* Diagnostic build of the detection kernel with in-kernel s_memtime stamps (slower; never combine with timing):
- * enable != 0 switches it on, cycles (may be NULL) receives and clears the per-phase wave-cycle sums
- * [setup, A1 work, A1 barrier, A2 work, A2 barrier, NMS work, NMS barrier, atomic+barrier]. */
-int ms_orb_fast_phase_cycles(ms_orb *orb, int enable, double *cycles /* [8] */);
-
 /* ImagePyramid::getLevel / getBlurredLevel (image_pyramid.hpp:24-25): copy one level of one frame
  * of the last batch to host, tightly packed w*h bytes (debug / parity testing). */
 int ms_orb_level_size(const ms_orb *orb, int level, int32_t *w, int32_t *h);

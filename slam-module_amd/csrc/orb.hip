@@ -237,14 +237,6 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-__device__ __forceinline__ uint32_t load4_reflect(const uint8_t *row, int x, int w) {
-    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
-    uint32_t d = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d |= (uint32_t)row[reflect101(x + i, w)] << (8 * i);
-    return d;
-}
-
 __device__ __forceinline__ uint32_t vsum7(const uint32_t *v) {   // 18,34,48,56,48,34,18 on two packed 16-bit lanes
     const us2_t k0 = {18, 18}, k1 = {34, 34}, k2 = {48, 48}, k3 = {56, 56};
     const us2_t a = __builtin_bit_cast(us2_t, v[0]) + __builtin_bit_cast(us2_t, v[6]);
@@ -379,23 +371,6 @@ constexpr int kFastWaves = 8, kFastThreads = 64 * kFastWaves;     // waves per t
 constexpr int kFastSeg = 248, kFastRows = 4 * kFastWaves - 2, kFastPosRows = kFastRows + 2, kFastRowsPerWave = 4;
 constexpr int kFastPositions = kFastPosRows * (kFastSeg + 2);   // scored positions of a tile: columns 3..252 of 16 rows.  Keeps LDS at 20 256 B = 8 workgroups per CU
 
-__device__ __forceinline__ bool contig9(uint32_t m) {
-    m |= m << 16;
-    uint32_t r = m & (m >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= m >> 8;
-    return r != 0;
-}
-
-__device__ __forceinline__ uint32_t load4_zero(const uint8_t *row, int x, int w) {
-    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);
-    uint32_t d = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (x + i >= 0 && x + i < w) d |= (uint32_t)row[x + i] << (8 * i);
-    return d;
-}
-
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
 }
@@ -415,33 +390,6 @@ __device__ __forceinline__ uint32_t compass_pass(uint32_t n, uint32_t s_, uint32
     const uint32_t a = pk_max(n, s_), b = pk_min(n, s_), c = pk_max(e, w), d = pk_min(e, w);
     const uint32_t p = pk_min(a, c), q = pk_max(b, d);                    // the two middle values of the four
     return pk_sub(hi, pk_max(p, q)) | pk_sub(pk_min(p, q), lo);
-}
-
-// Ring of one FAST candidate: R[8] = centre, R[k] = ring pixels k and k+8 in the two 16-bit lanes.
-__device__ __forceinline__ void fast_ring_load(const uint8_t *p, int pitch, uint32_t R[9]) {
-    const int rdx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    const int rdy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-    R[8] = p[0];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) R[k] = (uint32_t)p[rdy[k] * pitch + rdx[k]] | ((uint32_t)p[rdy[k + 8] * pitch + rdx[k + 8]] << 16);
-}
-
-// The same ring from 7 loads: rows +-3 as one dword at x-1, rows +-2 as a dwordx2 at x-2, rows 0 and +-1 as a dwordx2 at x-3
-// (global memory takes unaligned dword accesses); one v_perm_b32 per opposite pixel pair builds R[k].
-__device__ __forceinline__ void fast_ring_load_wide(const uint8_t *p, int pitch, uint32_t R[9]) {
-    const uint32_t a3 = reinterpret_cast<const U32u *>(p + 3 * pitch - 1)->v, am3 = reinterpret_cast<const U32u *>(p - 3 * pitch - 1)->v;
-    const U64u b2 = *reinterpret_cast<const U64u *>(p + 2 * pitch - 2), bm2 = *reinterpret_cast<const U64u *>(p - 2 * pitch - 2);
-    const U64u c1 = *reinterpret_cast<const U64u *>(p + pitch - 3), cm1 = *reinterpret_cast<const U64u *>(p - pitch - 3);
-    const U64u c0 = *reinterpret_cast<const U64u *>(p - 3);
-    R[0] = __builtin_amdgcn_perm(am3, a3, 0x0C050C01u);          // ( 0,+3) | ( 0,-3)
-    R[1] = __builtin_amdgcn_perm(am3, a3, 0x0C040C02u);          // (+1,+3) | (-1,-3)
-    R[2] = __builtin_amdgcn_perm(bm2.lo, b2.hi, 0x0C040C00u);    // (+2,+2) | (-2,-2)
-    R[3] = __builtin_amdgcn_perm(cm1.lo, c1.hi, 0x0C040C02u);    // (+3,+1) | (-3,-1)
-    R[4] = __builtin_amdgcn_perm(c0.lo, c0.hi, 0x0C040C02u);     // (+3, 0) | (-3, 0)
-    R[5] = __builtin_amdgcn_perm(c1.lo, cm1.hi, 0x0C040C02u);    // (+3,-1) | (-3,+1)
-    R[6] = __builtin_amdgcn_perm(b2.lo, bm2.hi, 0x0C040C00u);    // (+2,-2) | (-2,+2)
-    R[7] = __builtin_amdgcn_perm(a3, am3, 0x0C040C02u);          // (+1,-3) | (-1,+3)
-    R[8] = c0.lo >> 24;
 }
 
 // FAST score = max over the 16 arcs of 9 of min(c - r) and of min(r - c), on packed 16-bit lanes: P[k] = (d[k], d[k+8]) with
@@ -484,11 +432,8 @@ __device__ __forceinline__ void list_append_top_bit(uint32_t &m, uint32_t &at, u
                  : "vcc", "memory");
 }
 
-template <bool STAMP>   // STAMP: diagnostic build that adds up s_memtime deltas per phase (ms_orb_fast_phase_cycles); never used in production
 __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGeom *g, uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
-                                              unsigned long long *__restrict__ stamps, const uint32_t *__restrict__ tile_tab, TileLevels TL) {
-    long long t_prev = STAMP ? clock64() : 0;
-    auto stamp = [&](int slot) { if (STAMP) { const long long t = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[slot], (unsigned long long)(t - t_prev)); t_prev = t; } };
+                                              const uint32_t *__restrict__ tile_tab, TileLevels TL) {
     __shared__ uint8_t s_sc[kFastPosRows][256];                                      // score tile (columns 2..253 are touched)
     __shared__ __attribute__((aligned(16))) uint16_t s_pre[kFastPositions + 8];     // compass survivors (+ dump slot); each wave's corners overwrite its own consumed slots
     __shared__ __attribute__((aligned(16))) uint8_t s_pix[(kFastPosRows + 6) * 256]; // the tile's pixels (image rows Y0-4 .. Y0+17) for the ring reads; NMS keys afterwards
@@ -531,7 +476,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
     for (int r = 0; r < kFastRowsPerWave + 6; ++r)
         if (r < kFastRowsPerWave || wave == kFastWaves - 1) reinterpret_cast<uint32_t *>(s_pix)[(wave * kFastRowsPerWave + r) * 64 + lane] = rows[r];
     __syncthreads();
-    stamp(0);      // setup + LDS clear
     // ---- phase A1: position rows pr = wave*4 .. wave*4+3  <->  image rows Y0-1+pr; columns X0-4+4*lane .. +3
     {
         const uint32_t T2 = (uint32_t)thr * 0x00010001u;
@@ -584,9 +528,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    stamp(1);      // A1 own work
     __syncthreads();
-    stamp(2);      // A1 barrier wait
     // ---- phase A2 + B: the survivors are SCORED directly (corner <=> score > threshold), on packed 16-bit lanes:
     //      P[k] = (d[k], d[k+8]) with d = centre - ring pixel; the sliding min / max of 9 over the circular ring is four
     //      v_pk_min_i16 / v_pk_max_i16 levels (windows 2, 4, 8, 9) with lane swaps providing the wrap-around.
@@ -617,9 +559,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
         ncw += (int)__popcll(cm);
     }
     ncw = __builtin_amdgcn_readfirstlane(ncw);          // lanes that left the loop early missed the last updates; lane 0 stays to the end
-    stamp(3);      // A2 own work
     __syncthreads();
-    stamp(4);      // A2 barrier wait
     // ---- phase C: 3x3 strict-maximum NMS, dense over the corner list (only outputs: px X0..X0+247 = columns 4..251,
     //      rows Y0..Y0+13 = position rows 1..14; the halo corners only serve as neighbours)
     for (int i = lane; i < ncw; i += 64) {                               // every wave walks its own corner sublist
@@ -631,14 +571,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
                           sc > s_sc[pr][c + 1] && sc > s_sc[pr + 1][c - 1] && sc > s_sc[pr + 1][c] && sc > s_sc[pr + 1][c + 1];
         if (keep) s_out[atomicAdd(&s_m, 1)] = ((uint32_t)(255 - sc) << 24) | (uint32_t)(y * w + px);
     }
-    stamp(5);      // NMS own work
     __syncthreads();
-    stamp(6);      // NMS barrier wait
     const int m = s_m;
     if (m == 0) return;
     if (tid == 0) s_base = atomicAdd(&cand_count[f * TL.levels + l], m);
     __syncthreads();
-    stamp(7);      // global atomic + barrier
     for (int i = tid; i < m; i += kFastThreads) {
         const int pos = s_base + i;
         if (pos < G.cand_cap) cand[(uint64_t)f * TL.cand_stride + G.cand_off + pos] = s_out[i];
@@ -1066,7 +1003,6 @@ struct ms_orb {
     bool wide[MS_MAX_LEVELS] = {false};
     uint4 *d_moment_tab = nullptr;            // k_describe: disc mask of the orientation patch, four dwords per lane
     float4 *d_pattern_f = nullptr;            // k_describe: the 256 BRIEF point pairs as floats
-    unsigned long long *d_stamps = nullptr;   // diagnostic: per-phase cycle sums of k_fast (ms_orb_fast_phase_cycles)
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
     hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
@@ -1237,7 +1173,6 @@ void ms_orb_destroy(ms_orb *o) {
                     o->d_det_score, o->d_mask, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_track_xy,
                     o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (o->d_stamps) (void)hipFree(o->d_stamps);
     if (o->d_moment_tab) (void)hipFree(o->d_moment_tab);
     if (o->d_pattern_f) (void)hipFree(o->d_pattern_f);
     if (o->d_ftile_tab) (void)hipFree(o->d_ftile_tab);
@@ -1258,21 +1193,6 @@ int ms_orb_set_profiling(ms_orb *o, int enable) {
     if (enable && !o->ev[0])
         for (int i = 0; i <= MS_ORB_STAGES; ++i) MS_HIP(c, hipEventCreate(&o->ev[i]));
     o->profiling = enable != 0;
-    return MS_OK;
-}
-
-int ms_orb_fast_phase_cycles(ms_orb *o, int enable, double *cycles) {
-    if (!o) return MS_ERR_INVALID;
-    ms_ctx *c = o->ctx;
-    MS_HIP(c, hipStreamSynchronize(c->stream));
-    if (enable && !o->d_stamps) { MS_HIP(c, hipMalloc(reinterpret_cast<void **>(&o->d_stamps), 8 * sizeof(unsigned long long))); MS_HIP(c, hipMemset(o->d_stamps, 0, 64)); }
-    if (cycles && o->d_stamps) {
-        unsigned long long h[8];
-        MS_HIP(c, hipMemcpy(h, o->d_stamps, sizeof(h), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 8; ++i) cycles[i] = (double)h[i];
-        MS_HIP(c, hipMemset(o->d_stamps, 0, 64));
-    }
-    if (!enable && o->d_stamps) { MS_HIP(c, hipFree(o->d_stamps)); o->d_stamps = nullptr; }
     return MS_OK;
 }
 
@@ -1356,8 +1276,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->tile_levels, o->blur_tiles);
     MS_KERNEL_CHECK(c, "k_blur");
     MS_STAGE_MARK();
-    if (o->d_stamps) hipLaunchKernelGGL(k_fast<true>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_stamps, o->d_ftile_tab, o->tile_levels);
-    else hipLaunchKernelGGL(k_fast<false>, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, nullptr, o->d_ftile_tab, o->tile_levels);
+    hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_ftile_tab, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
     if (o->cfg.min_distance > 0.f)
