@@ -33,8 +33,8 @@ struct LevelGeom {
     int32_t min_dist;                 // per-level minimum keypoint distance (0/1 = none), feature_detector.cpp:79-82
     int32_t det_base;                 // first slot of this level in det arrays (prefix of quotas)
     int32_t cand_cap;                 // capacity of this level's candidate list (entries)
-    int32_t btiles_x, btile_base;     // k_blur tile table (248 x 32 tiles: 4 waves x 8 rows)
-    int32_t ftiles_x, ftile_base;     // k_fast tile table (248 x 14 tiles)
+    int32_t btiles_x, btile_base;     // k_blur tile table (248 x 72 tiles: 4 waves x kBlurRows rows)
+    int32_t ftiles_x, ftile_base;     // k_fast tile table (248 x 30 tiles: 8 waves x 4 position rows, 2 of them halo)
     uint32_t btiles_inv, ftiles_inv;  // ceil(2^32 / tiles_x): row of a tile = mulhi(t, inv), exact for t < 2^16
     uint64_t img_off, blur_off;       // byte offsets inside a frame slab
     uint64_t cand_off;                // entry offset inside a frame's candidate buffer
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileM
 // ------------------------------------------------------------------------------------------------
 // D1: FAST-9/16 corners + score + 3x3 strict NMS (this build's detector behind
 // feature_detector.cpp:89-98).  One launch covers every level of every frame.
-// Tile = 248 x 14 outputs; 256 x 16 score positions (1 px NMS halo, rounded to dwords): small tiles keep
-// the LDS footprint at 20 KB so 8 workgroups (32 waves) share a CU -- the kernel is latency-bound (dependent loads,
+// Tile = 248 x 30 outputs; 256 x 32 score positions (1 px NMS halo, rounded to dwords), 4 position rows per wave, 8 waves:
+// 34 KB of LDS, so 4 workgroups (32 waves) share a CU -- the kernel is latency-bound (dependent loads,
 // five barriers, one returning atomic per tile), not ALU-bound, and needs the occupancy.
 //   phase A1  compass pre-test on EVERY position, in registers, two pixels per instruction: a lane owns
 //             one dword (4 pixels) of a row, the even/odd bytes are two 16-bit lanes; the sign bits of
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileM
 //             ((255-score)<<24 | y*w+x) with ONE global atomic per tile
 constexpr int kFastWaves = 8, kFastThreads = 64 * kFastWaves;     // waves per tile: 4 position rows each
 constexpr int kFastSeg = 248, kFastRows = 4 * kFastWaves - 2, kFastPosRows = kFastRows + 2, kFastRowsPerWave = 4;
-constexpr int kFastPositions = kFastPosRows * (kFastSeg + 2);   // scored positions of a tile: columns 3..252 of 16 rows.  Keeps LDS at 20 256 B = 8 workgroups per CU
+constexpr int kFastPositions = kFastPosRows * (kFastSeg + 2);   // scored positions of a tile: columns 3..252 of its position rows
 
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
