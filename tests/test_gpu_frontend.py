@@ -164,10 +164,11 @@ def test_min_distance_suppression(oracle, ctx):
 
 
 def test_tile_edge_geometries(oracle, ctx):
-    """Widths / heights around the 248 x 14 detector tiles, the 248 x 32 blur tiles and the 4-row resize groups, on noise
-    (corners everywhere, including the last valid columns where the ring falls back to byte loads)."""
+    """Widths / heights around the 248 x 30 detector tiles, the 248 x 72 blur tiles and the 5-row resize groups, on noise
+    (corners everywhere, including the first and last columns and rows, where the border waves clamp, shift or reflect their loads)."""
     rng = np.random.default_rng(31)
-    for (w, h) in [(248, 56), (249, 57), (252, 49), (496, 70), (497, 71), (500, 50), (744, 53), (745, 85), (1000, 59)]:
+    for (w, h) in [(248, 56), (249, 57), (252, 49), (496, 70), (497, 71), (500, 50), (744, 53), (745, 85), (1000, 59),
+                   (247, 60), (251, 61), (253, 89), (254, 90), (255, 91), (495, 72), (499, 73), (743, 144), (992, 145)]:
         img = rng.integers(0, 256, (1, h, w), dtype=np.uint8)
         img[0, :, : w // 2] = (img[0, :, : w // 2] // 64) * 64                      # flat patches with sharp steps on one half
         _, got, want = _extract_both(oracle, ctx, img, levels=2, scale_factor=1.2, fast_threshold=12, max_kpts=3000)
