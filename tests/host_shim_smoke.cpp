@@ -2,6 +2,8 @@
 // extraction, one triangulation match and one two-stage local BA end to end (used by tests/test_host_shims.py).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <cmath>
 #include "mi355slam/orb_extractor.hpp"
 #include "mi355slam/keyframe_matcher.hpp"
@@ -15,6 +17,29 @@ int main(int argc, char **argv) {
     params.maxTracks = 16;
     StaticSettings settings(params);
     if (settings.maxNumberOfKeypointsPerLevel().front() != 434) { std::printf("quota mismatch\n"); return 2; }
+    {   // VocabularyTree::loadFromTextFile: DBoW2's text format ("k L scoring weighting", then "parent isLeaf 32 bytes weight" per node)
+        const char *tmp = std::getenv("TMPDIR");
+        const std::string path = std::string(tmp ? tmp : "/tmp") + "/mi355slam_vocab_test.txt";
+        {
+            std::ofstream f(path);
+            f << "3 2 0 0\n";
+            int id = 0;
+            for (int p = 0; p < 3; ++p) {                     // three inner nodes under the root, then three leaves under each (ids 1..3, 4..12)
+                f << 0 << " " << 0; for (int b = 0; b < 32; ++b) f << " " << ((b * 7 + p) & 255); f << " " << 0.0 << "\n"; ++id;
+            }
+            for (int p = 1; p <= 3; ++p) for (int c = 0; c < 3; ++c) {
+                f << p << " " << 1; for (int b = 0; b < 32; ++b) f << " " << ((b * 13 + 5 * p + c) & 255); f << " " << (0.5 * p + c) << "\n"; ++id;
+            }
+        }
+        const VocabularyTree T = VocabularyTree::loadFromTextFile(path);
+        std::remove(path.c_str());
+        bool ok = T.size() == 13 && T.branchingFactor == 3 && T.depthLevels == 2 && T.parent[5] == 1 && T.parent[12] == 3 && T.wordId[3] == -1 && T.wordId[4] == 0 &&
+                  T.wordId[12] == 8 && T.weight[7] == 1.0 && T.weight[12] == 3.5;
+        // byte b of node 4 (parent 1, child 0) is (13 b + 5) & 255; word k of the descriptor holds bytes 4k .. 4k+3, lowest first
+        const std::uint32_t w2 = T.descriptor[8 * 4 + 2];
+        ok = ok && w2 == (std::uint32_t)(((13 * 8 + 5) & 255) | (((13 * 9 + 5) & 255) << 8) | (((13 * 10 + 5) & 255) << 16) | (((13 * 11 + 5) & 255) << 24));
+        if (!ok) { std::printf("vocabulary text file mismatch\n"); return 11; }
+    }
     if (argc > 1 && std::string(argv[1]) == "--no-gpu") { std::printf("link ok\n"); return 0; }
     Context ctx(0);
     const int W = 320, H = 240;
