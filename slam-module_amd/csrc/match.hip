@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
         if (qi < nq) { lo = Q[2 * qi]; hi = Q[2 * qi + 1]; }
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int s = 0; s < 8; ++s)                   // lane half h holds bits 4h+j (+8, +16, +24) of word s in dword j, as +1 / -1
+        for (int s = 0; s < 8; ++s)                   // lane half h holds bits 4h+j (+8, +16, +24) of word s in dword j, as +16 / -16
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bq[n][s][j] = (int)((((w[s] >> (4 * h + j)) & 0x01010101u) * 0xFEu) | 0x01010101u);
+            for (int j = 0; j < 4; ++j) bq[n][s][j] = (int)((((w[s] >> (4 * h + j)) & 0x01010101u) * 0xE0u) ^ 0x10101010u);   // bit 0 -> +16, bit 1 -> -16: the accumulators come out as 16 * dot, ready to take a 4-bit row tag
         popq[n] = 0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) popq[n] += __popc(w[s]);
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t both = __builtin_amdgcn_perm((uint32_t)acc[1][r], (uint32_t)acc[0][r], 0x05040100u);   // low halves: (acc0, acc1)
-                    const us2_t sixteen = {16, 16}, bias = {(unsigned short)(4096 + r), (unsigned short)(4096 + r)};
-                    const us2_t key = __builtin_bit_cast(us2_t, both) * sixteen + bias;
+                    const us2_t bias = {(unsigned short)(4096 + r), (unsigned short)(4096 + r)};
+                    const us2_t key = __builtin_bit_cast(us2_t, both) + bias;
                     const us2_t lo = __builtin_elementwise_min(lb, key), hi = __builtin_elementwise_max(lb, key);
                     ls = __builtin_elementwise_min(ls, hi);
                     lb = lo;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + (r & 3) + 8 * (r >> 2);
-                        const uint32_t key = (((uint32_t)acc[n][r] + 256u) << 20) + (uint32_t)row;
+                        const uint32_t key = (((uint32_t)acc[n][r] + 4096u) << 16) + (uint32_t)row;        // (dot + 256) << 20
                         best2_push(best[n], second[n], row < nt ? key : kNone);
                     }
             }
