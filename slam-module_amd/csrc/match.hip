@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
         for (int s = 0; s < 8; ++s) popq[n] += __popc(w[s]);
     }
     uint32_t best[2] = {kNone, kNone}, second[2] = {kNone, kNone};
+    v16i_t tag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tag[r] = 4096 + r;
     for (int base = 0; base < nt; base += kHmStage) {
         __syncthreads();
         {   // expand this stage's targets: thread -> target tid & 127, words 4*(tid>>7) .. +3 (one 16-byte load)
@@ -172,15 +175,15 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
         __syncthreads();
         const int mtiles = min(kHmStage / 32, (nt - base + 31) >> 5);
         for (int m = 0; m < mtiles; ++m) {
-            v16i_t acc[2] = {};
+            v16i_t acc[2];
             v4i_t a[8];                                               // all eight fragments of the tile are requested before the first MFMA waits
 #pragma unroll
             for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const v4i_t *>(&s_a[(m * 8 + s) * 256 + lane * 4]);
             __builtin_amdgcn_sched_barrier(0);                        // keep the reads ahead of the chain (the scheduler would re-serialise them to save registers)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[0][s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[1][s], acc[1], 0, 0, 0);
+            for (int s = 0; s < 8; ++s) {          // the chain starts from the row tags (4096 + register index), so no add follows it
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[0][s], s == 0 ? tag : acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[1][s], s == 0 ? tag : acc[1], 0, 0, 0);
             }
             const int row0 = base + m * 32 + 4 * h;                   // this lane's rows: row0 + (reg & 3) + 8 * (reg >> 2)
             if (base + m * 32 + 32 <= nt) {                           // full tile (uniform)
@@ -190,8 +193,7 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t both = __builtin_amdgcn_perm((uint32_t)acc[1][r], (uint32_t)acc[0][r], 0x05040100u);   // low halves: (acc0, acc1)
-                    const us2_t bias = {(unsigned short)(4096 + r), (unsigned short)(4096 + r)};
-                    const us2_t key = __builtin_bit_cast(us2_t, both) + bias;
+                    const us2_t key = __builtin_bit_cast(us2_t, both);
                     const us2_t lo = __builtin_elementwise_min(lb, key), hi = __builtin_elementwise_max(lb, key);
                     ls = __builtin_elementwise_min(ls, hi);
                     lb = lo;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + (r & 3) + 8 * (r >> 2);
-                        const uint32_t key = (((uint32_t)acc[n][r] + 4096u) << 16) + (uint32_t)row;        // (dot + 256) << 20
+                        const uint32_t key = (((uint32_t)acc[n][r] - (uint32_t)r) << 16) + (uint32_t)row;  // (dot + 256) << 20
                         best2_push(best[n], second[n], row < nt ? key : kNone);
                     }
             }
