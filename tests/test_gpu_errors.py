@@ -61,6 +61,12 @@ def test_ba_capacity_and_index_checks(ctx):
     bad["obs_point"] = bad["obs_point"].copy(); bad["obs_point"][3] = 999
     with pytest.raises(mi355slam.MsError, match="outside"):
         mi355slam.BundleAdjuster(ctx, [bad])
+    small = mi355slam.BundleAdjuster(ctx, [bad | dict(obs_point=ba_synth.make_problem(5, 20, 3, seed=2)["obs_point"])])
+    with pytest.raises(mi355slam.MsError):
+        small.set_factor_team(65)                                            # more workgroups than a team can have
+    small.set_factor_team(3); small.set_team(2); small.solve()               # a factor team on a small system is ignored
+    assert small.download(0)["stats"]["chi2_final"] <= small.download(0)["stats"]["chi2_init"]
+    small.close()
     ok = ba_synth.make_problem(176, 400, 8, seed=3)                          # exactly at the limit works
     ba = mi355slam.BundleAdjuster(ctx, [ok], max_iters=3); ba.solve()
     out = ba.download(0)
