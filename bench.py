@@ -1,227 +1,484 @@
 #!/usr/bin/env python3
-"""bench.py -- ORB extract + match throughput on synthetic 720p frames (BASELINE.json config C2 + C3 policy).
+"""bench.py -- ORB extract + match throughput on synthetic 720p frames (BASELINE.json configs C2 + C3 policy), with the local-BA
+(C4) and independent-sequences (C5) legs beside it.
 
-One "step" = one pass of the hot path over one batch of 256 synthetic 1280x720 frames that are already
-resident in HBM: pyramid (8 levels x1.2) -> FAST -> top-2000 selection -> orientation -> 256-bit steered
-BRIEF, then brute-force Hamming best/second-best + ratio test of every frame's descriptors against the
-previous frame's (256 pairs, up to 2000x2000 each).  Multi-GPU: one process per GPU, every rank runs its
-own batch (independent sequences, no data-path collective); RCCL is used only to agree on the timing.
+One "step" = one pass of the hot path over one batch of 256 synthetic 1280x720 frames that are already resident in HBM: pyramid
+(8 levels x1.2) -> FAST -> top-2000 selection -> orientation -> 256-bit steered BRIEF, then brute-force Hamming best/second-best +
+ratio test of every frame's descriptors against the previous frame's (256 pairs, up to 2000x2000 each).
 
-Prints ONE JSON line (see the contract in the task statement).  `roofline` is computed for the dominant
-kernel from HIP-event durations taken inside the timed region; `cpu_baseline` times the CPU oracle (port of
-the reference algorithm, test infrastructure) on a bounded sample of the same workload on rank 0 at N=1.
+Multi-GPU: one process per GPU, every rank runs its own batch (independent units, no data-path collective); RCCL is
+used for the barriers and the MAX / SUM of (time, units) only.
+  * `python bench.py --gpus N` with no RANK in the environment is the LAUNCHER: it starts N child processes of this file (one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything touches the GPU (torch is not even imported in the parent),
+    relays rank 0's JSON line and exits non-zero if any child fails.  Children are started with subprocess, never exec.
+  * under `python -m torch.distributed.run ... bench.py --gpus N` (RANK set) the process is a rank.
+  * `--plumbing` replaces the GPU work by a sleep and the backend by gloo: the launcher / rendezvous / aggregation path on a CPU box
+    (tests/test_bench_launcher.py).  Its line carries "plumbing": true and is not a measurement.
+
+Prints ONE JSON line (contract in the task statement).  `roofline` is computed for the dominant kernel from HIP-event durations
+taken inside the timed region on the stream the kernels run on; `cpu_baseline` times the CPU oracle (port of the reference
+algorithm, test infrastructure) on a bounded sample of the same workload on rank 0 at N=1, with 1 thread and with all cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "slam-module_amd"))
+for _p in ("slam-module_amd", "tools", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, _p))
 
 W, H, LEVELS, SCALE, MAX_KPTS, FAST_THR, BATCH = 1280, 720, 8, 1.2, 2000, 20, 256
 LOWE_RATIO = 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")      # HBM bytes / instruction counts per launch of the committed build
+N_SEQ = 8                      # C5: independent sequences of the whole job
 
 
-def synth_batch(n, base_seed):
-    """8 sequences of n/8 frames: frame i = synth(seed, shift=(2k, k)) so consecutive frames really match."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import mso                                  # generator only (integer synthetic frames)
-    import numpy as np
-    per = max(n // 8, 1)
-    return np.stack([mso.synth_frame(W, H, base_seed + i // per, 2 * (i % per), i % per) for i in range(n)])
-
-
-def cpu_baseline(frames, n_sample):
-    """CPU oracle (port) on the first n_sample frames: extract each + match against the previous one; 1 thread."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import mso
-    cfg = mso.cfg(levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR)
-    t0 = time.perf_counter()
-    prev = None
-    for f in range(n_sample):
-        kp = mso.orb_extract(cfg, frames[f])
-        if prev is not None:
-            mso.hamming_best2(kp["desc"], prev["desc"])
-        else:
-            mso.hamming_best2(kp["desc"], kp["desc"])
-        prev = kp
-    dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d synthetic 720p frames (extract + 2000x2000 Hamming best2), oracle/libmso.so, 1 thread" % (n_sample, BATCH)}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sparse-corner input and the PCIe-inclusive legs")
+    ap.add_argument("--only-headline", action="store_true", help="C2+C3 leg only (profiling runs)")
     ap.add_argument("--ba-batch", type=int, default=256)
     ap.add_argument("--ba-steps", type=int, default=3)
-    args = ap.parse_args()
+    ap.add_argument("--c5-frames", type=int, default=40, help="frames per sequence in the C5 leg")
+    ap.add_argument("--c5-keyframe-every", type=int, default=5)
+    ap.add_argument("--plumbing", action="store_true", help="no GPU work: launcher / rendezvous / aggregation only (gloo)")
+    ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="with --plumbing: this rank exits with code 3 (launcher test)")
+    ap.add_argument("--master-port", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.only_headline:
+        a.no_ba = a.no_c5 = a.no_extra = a.no_cpu_baseline = True
+    return a
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import numpy as np
-    import torch                                   # plumbing: device memory for the inputs + torch.distributed
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    import mi355slam                                # after torch: both must share one HIP runtime
 
-    ctx = mi355slam.Context(local_rank)
-    frames_np = synth_batch(BATCH, 1000 + 8 * rank)
-    frames = torch.from_numpy(frames_np).cuda()     # inputs resident in HBM before the timed region
-    ex = mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=BATCH)
-    cap = ex.capacity
-    view = None
-    pair_q = torch.arange(BATCH, dtype=torch.int32, device="cuda")
-    pair_t = torch.roll(pair_q, 1)                  # frame f against frame f-1 (frame 0 against the last one)
-    best_idx = torch.empty(BATCH * cap, dtype=torch.int32, device="cuda")
-    best_dist = torch.empty(BATCH * cap, dtype=torch.int16, device="cuda")
-    second_dist = torch.empty(BATCH * cap, dtype=torch.int16, device="cuda")
-    match = torch.empty(BATCH * cap, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+# ------------------------------------------------------------------------------------------------------------------ launcher
+def launch(args, argv):
+    """Parent of an N-rank run: no GPU call, no torch import.  One child per GPU; rank 0's stdout carries the JSON line."""
+    import socket
+    port = args.master_port
+    if not port:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()))      # drain rank 0's pipe while the ranks run
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):            # one rank failed: the others would wait for it in a barrier forever
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(20)
+                    except subprocess.TimeoutExpired:
+                        p.kill(); codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join()
+    out0 = (chunks[0] if chunks else b"").decode()
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if any(c != 0 for c in codes) or line is None:
+        sys.stderr.write("bench.py launcher: rank exit codes %s%s\n" % (codes, "" if line else "; rank 0 printed no result line"))
+        if line:
+            sys.stderr.write("rank 0 said: %s\n" % line)
+        return 1
+    print(line, flush=True)
+    return 0
 
-    def step(profile_match=False):
-        nonlocal view
-        ex.extract(frames.data_ptr(), n_frames=BATCH, frame_stride=W * H, row_stride=W)
-        if view is None:
-            view = ex.device_view()
-        if profile_match:
-            ctx.event_mark(0)
-        mi355slam.hamming_best2_sets(ctx, view.desc, cap, view.count, view.desc, cap, view.count, pair_q.data_ptr(), pair_t.data_ptr(),
-                                     BATCH, best_idx.data_ptr(), best_dist.data_ptr(), second_dist.data_ptr())
-        if profile_match:
-            ctx.event_mark(1)
-        mi355slam.ratio_test_device(ctx, best_idx.data_ptr(), best_dist.data_ptr(), second_dist.data_ptr(), BATCH * cap, LOWE_RATIO, 50, match.data_ptr())
 
+# ------------------------------------------------------------------------------------------------------------------ CPU baseline (oracle)
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mso                                   # the checker: imported only here, for the cpu_baseline leg
+    mso.build()
+    return mso
+
+
+def host_cores():
+    """Host threads this process may really use: CPU affinity, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(n, 1)
+
+
+def _pool_rate(fn, items, threads):
+    """items/s of fn over items with `threads` host threads (ctypes releases the GIL inside the oracle's C code)."""
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    if threads == 1:
+        for it in items:
+            fn(it)
+    else:
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(fn, items))
+    return len(items) / (time.perf_counter() - t0)
+
+
+def cpu_baseline_frames(frames):
+    mso = _oracle()
+    cfg = mso.cfg(levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR)
+    cores = host_cores()
+
+    RUN = 8                                      # a task = a run of 8 consecutive frames: extract each, match it against the previous one
+
+    def one(f0):
+        prev = None
+        for f in range(f0, f0 + RUN):
+            kp = mso.orb_extract(cfg, frames[f])
+            mso.hamming_best2(kp["desc"], (prev if prev is not None else kp)["desc"])
+            prev = kp
+    n1 = 96
+    r1 = _pool_rate(one, list(range(0, n1, RUN)), 1) * RUN
+    nall = min(len(frames), max(cores * 2 * RUN, 64)) // RUN * RUN
+    rall = _pool_rate(one, list(range(0, nall, RUN)), cores) * RUN
+    return {"value": round(r1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d synthetic 720p frames (extract + 2000x2000 Hamming best2 per frame), oracle/libmso.so (gcc -O2, scalar), 1 thread" % (n1, BATCH),
+            "all_cores": {"value": round(rall, 2), "unit": "frames/s", "cores": cores,
+                          "sample": "%d frames in runs of 8 over %d host threads (the oracle's C code runs outside the GIL)" % (nall, cores)}}
+
+
+def cpu_baseline_ba(problems):
+    mso = _oracle()
+    cores = host_cores()
+    n1 = 32
+    r1 = _pool_rate(lambda p: mso.ba_solve(p, 10, False), [problems[i % len(problems)] for i in range(n1)], 1)
+    nall = max(cores * 4, 32)
+    rall = _pool_rate(lambda p: mso.ba_solve(p, 10, False), [problems[i % len(problems)] for i in range(nall)], cores)
+    return {"value": round(r1, 2), "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": "%d solves of distinct C4 windows, oracle/libmso.so (Schur + dense Cholesky, fp64), 1 thread" % n1,
+            "all_cores": {"value": round(rall, 2), "unit": "solves/s", "cores": cores, "sample": "%d solves over %d host threads" % (nall, cores)}}
+
+
+# ------------------------------------------------------------------------------------------------------------------ rank
+class Rank:
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        import torch                                   # plumbing: device memory for the inputs + torch.distributed
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.device = "cpu" if args.plumbing else "cuda"
+        if not args.plumbing:
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.plumbing:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+
+    def barrier(self):
+        if not self.args.plumbing:
+            self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def aggregate(self, units, seconds):
+        from mi355slam import shard
+        return shard.aggregate(self.dist if self.world > 1 else None, self.torch, units, seconds, device=self.device)
+
+    def gather(self, value):
+        """Every rank's float, in rank order (reported per GPU; a few bytes)."""
+        if self.world == 1:
+            return [float(value)]
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
+        outs = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [float(o.item()) for o in outs]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def base_line(R, args, value, dt):
+    return {"metric": "frames/sec ORB extract+match (720p)", "value": round(value, 1), "unit": "frames/s", "n_gpus": R.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+
+
+def run_plumbing(R, args):
+    """The N-rank skeleton without a GPU: same barriers, same aggregation, a sleep for the hot path."""
+    if args.plumbing_fail_rank == R.rank:
+        sys.exit(3)
     for _ in range(args.warmup):
-        step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # ---- timed region: exactly K steps; per-kernel HIP events ride along on the context stream ----
-    ex.set_profiling(True)
-    stage_sum = {}
-    match_ms = 0.0
+        time.sleep(0.001)
+    R.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(profile_match=True)
-        for k, v in ex.stage_ms().items():          # reading the events waits for this step (steps are serial anyway)
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-        match_ms += ctx.event_elapsed_ms(0, 1)
-    ctx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        time.sleep(0.002 * (1 + R.rank))            # uneven ranks: the reported time must be the slowest rank's
+    R.barrier()
     dt = time.perf_counter() - t0
+    units, dt = R.aggregate(BATCH * args.steps, dt)
     from mi355slam import shard
-    frames_total, dt = shard.aggregate(dist if world > 1 else None, torch, BATCH * args.steps, dt, device="cuda")
+    out = base_line(R, args, units / dt, dt)
+    out.update({"plumbing": True, "data": "none (plumbing run: no GPU work)", "config": {"workload": "launcher / rendezvous / aggregation only"},
+                "units_total": units, "per_gpu_units": R.gather(BATCH * args.steps),
+                "c5": {"sequences_of_rank": [[s for s in range(N_SEQ) if shard.sequence_of(s, R.world) == r] for r in range(R.world)]}})
+    if R.rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+class Headline:
+    """C2 + C3: the 256-frame batch step and its per-kernel HIP-event times."""
+
+    def __init__(self, R, ctx, frames_np):
+        import mi355slam
+        torch = R.torch
+        self.R, self.ctx, self.ms = R, ctx, mi355slam
+        self.frames = torch.from_numpy(frames_np).cuda()        # inputs resident in HBM before any timed region
+        self.ex = mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=BATCH)
+        cap = self.cap = self.ex.capacity
+        self.view = None
+        self.pair_q = torch.arange(BATCH, dtype=torch.int32, device="cuda")
+        self.pair_t = torch.roll(self.pair_q, 1)                # frame f against frame f-1 (frame 0 against the last one)
+        self.best_idx = torch.empty(BATCH * cap, dtype=torch.int32, device="cuda")
+        self.best_dist = torch.empty(BATCH * cap, dtype=torch.int16, device="cuda")
+        self.second_dist = torch.empty(BATCH * cap, dtype=torch.int16, device="cuda")
+        self.match = torch.empty(BATCH * cap, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+
+    def set_frames(self, frames_np):
+        self.frames.copy_(self.R.torch.from_numpy(frames_np))
+        self.R.torch.cuda.synchronize()
+
+    def search(self):
+        v, cap = self.view, self.cap
+        self.ms.hamming_best2_sets(self.ctx, v.desc, cap, v.count, v.desc, cap, v.count, self.pair_q.data_ptr(), self.pair_t.data_ptr(),
+                                   BATCH, self.best_idx.data_ptr(), self.best_dist.data_ptr(), self.second_dist.data_ptr())
+
+    def step(self, images=None, mark=False):
+        if images is None:
+            self.ex.extract(self.frames.data_ptr(), n_frames=BATCH, frame_stride=W * H, row_stride=W)
+        else:
+            self.ex.extract(images)                             # host frames: the H2D copies are part of the call
+        if self.view is None:
+            self.view = self.ex.device_view()
+        if mark:
+            self.ctx.event_mark(0)
+        self.search()
+        if mark:
+            self.ctx.event_mark(1)
+        self.ms.ratio_test_device(self.ctx, self.best_idx.data_ptr(), self.best_dist.data_ptr(), self.second_dist.data_ptr(), BATCH * self.cap,
+                                  LOWE_RATIO, 50, self.match.data_ptr())
+
+    def timed(self, steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between barrier + synchronize; returns (seconds, per-kernel ms)."""
+        R, ctx = self.R, self.ctx
+        for _ in range(warmup):
+            self.step()
+        ctx.sync()
+        R.barrier()
+        self.ex.set_profiling(True)
+        stage_sum, match_ms = {}, 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(mark=True)
+            for k, v in self.ex.stage_ms().items():          # reading the events waits for this step (steps are serial anyway)
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+            match_ms += ctx.event_elapsed_ms(0, 1)
+        ctx.sync()
+        R.barrier()
+        dt = time.perf_counter() - t0
+        self.ex.set_profiling(False)
+        avg = {k: v / steps for k, v in stage_sum.items()}
+        avg["hamming"] = match_ms / steps
+        return dt, avg
+
+    def counts(self):
+        import numpy as np
+        n_kp = np.frombuffer(ctx_download(self.ctx, self.view.count, 4 * BATCH), dtype=np.int32)
+        n_match = int((self.match.view(BATCH, self.cap) >= 0).sum().item())
+        return n_kp, n_match
+
+
+def kernel_table(avg_ms, n_kp):
+    """Per kernel: ms per launch and algorithmic GB/s (bytes per frame from SURVEY 8d / DESIGN.md 5, x 256 frames per launch)."""
+    import numpy as np
+    import mi355slam
+    ws, hs = mi355slam.level_sizes(LEVELS, SCALE, W, H)
+    P = int((ws.astype(np.int64) * hs).sum()); N0 = W * H; K = float(n_kp.mean())
+    alg = {"resize": (P - int(ws[-1]) * int(hs[-1])) + (P - N0),      # read levels 0..n-2, write levels 1..n-1
+           "blur": 2 * P, "fast": P, "select": 4 * K, "tracks": 0, "describe": 1821 * K, "hamming": 32 * 2 * K + 8 * K}
+    kernels = {k: {"ms_per_launch": round(avg_ms[k], 4), "alg_GBs": round(alg[k] * BATCH / (avg_ms[k] * 1e-3) / 1e9, 1) if avg_ms[k] > 0 else None}
+               for k in avg_ms}
+    return kernels, alg, P, K
+
+
+def pmc_of(kernel):
+    """HBM bytes and instruction counts per launch from the committed PMC passes of this build (tools/profile_set.sh); None if absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"][kernel]
+    except Exception:
+        return None
+
+
+def run_gpu(R, args):
+    import numpy as np
+    import mi355slam                                # after torch: both must share one HIP runtime
+    import synth
+    torch = R.torch
+    ctx = mi355slam.Context(R.local_rank)
+    frames_np = synth.synth_sequences(BATCH, W, H, 1000 + N_SEQ * R.rank)
+    hl = Headline(R, ctx, frames_np)
+
+    # ---- headline: exactly K steps between barrier + synchronize, MAX over ranks ----
+    dt, avg_ms = hl.timed(args.steps, args.warmup)
+    frames_total, dt = R.aggregate(BATCH * args.steps, dt)
+    value = frames_total / dt
+    n_kp, n_match = hl.counts()
+    kernels, alg, P, K = kernel_table(avg_ms, n_kp)
 
     # outside the timed region: the same 256 searches on the popcount kernel (v_xor / v_bcnt), for comparison with the matrix-core one
-    mi355slam.lib().ms_hamming_set_path(1)
+    ctx.set_hamming_path(1)
     for rep in range(3):
         if rep == 1:
             ctx.event_mark(2)
-        mi355slam.hamming_best2_sets(ctx, view.desc, cap, view.count, view.desc, cap, view.count, pair_q.data_ptr(), pair_t.data_ptr(),
-                                     BATCH, best_idx.data_ptr(), best_dist.data_ptr(), second_dist.data_ptr())
+        hl.search()
     ctx.event_mark(3)
-    popcount_ms = ctx.event_elapsed_ms(2, 3) / 2
-    mi355slam.lib().ms_hamming_set_path(0)
-    n_kp = np.frombuffer(ctx_download(ctx, view.count, 4 * BATCH), dtype=np.int32)
-    n_match = int((match.view(BATCH, cap) >= 0).sum().item())
-    value = frames_total / dt
-
-    # ---- roofline of the dominant kernel (algorithmic bytes per launch, SURVEY 8d / DESIGN.md) ----
-    ws, hs = mi355slam.level_sizes(LEVELS, SCALE, W, H)
-    P = int((ws.astype(np.int64) * hs).sum()); N0 = W * H; K = float(n_kp.mean())
-    alg = {   # bytes per frame
-        "resize": (P - int(ws[-1]) * int(hs[-1])) + (P - N0),      # read levels 0..n-2, write levels 1..n-1
-        "blur": 2 * P, "fast": P, "select": 4 * K, "tracks": 0, "describe": 1821 * K,
-        "hamming": 32 * 2 * K + 8 * K,
-    }
-    avg_ms = {k: v / args.steps for k, v in stage_sum.items()}
-    avg_ms["hamming"] = match_ms / args.steps
-    dom = max(avg_ms, key=avg_ms.get)
-    kernels = {k: {"ms_per_launch": round(avg_ms[k], 4), "alg_GBs": round(alg[k] * BATCH / (avg_ms[k] * 1e-3) / 1e9, 1) if avg_ms[k] > 0 else None}
-               for k in avg_ms}
-    kernels["hamming"]["popcount_kernel_ms"] = round(popcount_ms, 4)
+    kernels["hamming"]["popcount_kernel_ms"] = round(ctx.event_elapsed_ms(2, 3) / 2, 4)
+    ctx.set_hamming_path(0)
     # the unmasked search is an i8 matrix product (1 multiply-add per descriptor bit and pair): its own roofline is the dense i8 MFMA peak
     pair_ops = 2.0 * 256 * float((n_kp.astype(np.float64) * np.roll(n_kp, 1).astype(np.float64)).sum())
     kernels["hamming"]["mfma"] = {"bound": "mfma", "achieved": round(pair_ops / (avg_ms["hamming"] * 1e-3) / 1e12, 1), "peak": 5000.0, "unit": "Top/s (i8)",
                                   "frac": round(pair_ops / (avg_ms["hamming"] * 1e-3) / 1e12 / 5000.0, 4)}
+    # ---- roofline of the dominant kernel: algorithmic bytes per launch / HIP-event duration measured above ----
+    dom = max(avg_ms, key=avg_ms.get)
     achieved = alg[dom] * BATCH / (avg_ms[dom] * 1e-3) / 1e9
-    # From the committed PMC passes (profiles/r01_pmc_traffic.json, tools/pmc_summary.py): HBM bytes per launch and the
-    # wave-level VALU instruction count.  The front-end kernels are bound by VALU ISSUE, not by HBM: almost all their
-    # instructions are VOP3 / packed forms that issue once per ~4 cycles per SIMD (profiles/r01_e_valu_issue_rates.txt), so
-    # valu_issue_frac = count / 1024 SIMDs x 4 cycles / 2.4 GHz / (measured launch time) is the fraction of that limit in use.
-    traffic = valu = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        kname = {"hamming": "k_hamming_mfma"}.get(dom, "k_" + dom)
-        traffic = pmc[kname]["hbm_bytes_per_step"]
-        valu = pmc[kname]["SQ_INSTS_VALU_per_step"]
-    except Exception:
-        pass
+    pmc = pmc_of({"hamming": "k_hamming_mfma"}.get(dom, "k_" + dom))
+    traffic = pmc.get("hbm_bytes_per_step") if pmc else None
+    valu = pmc.get("SQ_INSTS_VALU_per_step") if pmc else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": (PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, tools/profile_set.sh; not measured in this run)") if pmc else None,
+                # the front-end kernels are bound by VALU issue (VOP3 / packed forms issue once per ~4 cycles per SIMD, profiles/r01_e_valu_issue_rates.txt)
                 "valu_insts": valu, "valu_issue_frac": round(valu / 1024 * 4 / 2.4e9 / (avg_ms[dom] * 1e-3), 3) if valu else None,
                 "whole_step_alg_GBs": round((4 * P + 1821 * K + 72 * K) * BATCH * args.steps / dt / 1e9, 1)}
-    out = {
-        "metric": "frames/sec ORB extract+match (720p)", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "C2+C3: ORB extract 1280x720, 8 levels x1.2, 2000 kpts/frame, FAST thr 20, batch 256 synthetic frames/GPU, "
-                               "+ Hamming brute-force best2 + ratio 0.75 of each frame vs the previous (256 pairs, <=2000x2000)",
-                   "batch_per_gpu": BATCH, "keypoints_per_frame": round(K, 1), "ratio_matches_per_frame": round(n_match / BATCH, 1)},
-        "roofline": roofline, "kernels": kernels,
-    }
-    # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 windows per launch, device-resident ----
+    out = base_line(R, args, value, dt)
+    out["config"] = {"workload": "C2+C3: ORB extract 1280x720, 8 levels x1.2, 2000 kpts/frame, FAST thr 20, batch 256 synthetic frames/GPU, "
+                                 "+ Hamming brute-force best2 + ratio 0.75 of each frame vs the previous (256 pairs, <=2000x2000)",
+                     "batch_per_gpu": BATCH, "keypoints_per_frame": round(K, 1), "ratio_matches_per_frame": round(n_match / BATCH, 1),
+                     "corner_density": "7-9 % of pixels (tools/synth.py defaults)"}
+    out["per_gpu_frames_per_s"] = [round(v, 1) for v in R.gather(BATCH * args.steps / dt)]
+    out["roofline"] = roofline
+    out["kernels"] = kernels
+
+    if not args.no_extra:
+        # ---- the same step on frames with the corner density of camera images (1-2 % instead of 7-9 %) ----
+        sparse_np = synth.synth_sequences(BATCH, W, H, 1000 + N_SEQ * R.rank, sparse=True)
+        hl.set_frames(sparse_np)
+        sdt, savg = hl.timed(max(args.steps // 2, 1), 1)
+        s_total, sdt = R.aggregate(BATCH * max(args.steps // 2, 1), sdt)
+        skp, smatch = hl.counts()
+        out["sparse_input"] = {"value": round(s_total / sdt, 1), "unit": "frames/s", "corner_density": "~2 % of pixels (tools/synth.py sparse=True)",
+                               "keypoints_per_frame": round(float(skp.mean()), 1), "ratio_matches_per_frame": round(smatch / BATCH, 1),
+                               "ms_per_launch": {k: round(v, 4) for k, v in savg.items()}}
+        # ---- PCIe-inclusive: frames start in pinned HOST memory, keypoints + descriptors end in host memory ----
+        hl.set_frames(frames_np)
+        out["value_pcie_inclusive"] = pcie_inclusive(R, hl, frames_np, max(args.steps // 4, 2))
+
+    # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 distinct windows per launch, device-resident ----
     if not args.no_ba:
-        out["local_ba"] = bench_ba(ctx, args, world, rank, dist if world > 1 else None, torch)
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_np, 128)
+        out["local_ba"] = bench_ba(R, ctx, args)
+    # ---- C5: 8 independent sequences, sequence s on GPU s mod N, frame by frame ----
+    if not args.no_c5:
+        del hl
+        out["c5"] = bench_c5(R, args)
+    if R.rank == 0:
+        if R.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_frames(frames_np)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     ctx.close()
 
 
-def bench_ba(ctx, args, world, rank, dist, torch):
-    """C4: 50 keyframes x 2000 points x 20000 observations, 10 LM iterations, Huber sqrt(5.991), 49 odometry edges."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def pcie_inclusive(R, hl, frames_np, steps):
+    """frames/s with the H2D copy of the 256 input frames and the D2H copy of every frame's keypoints inside the timed region."""
+    import numpy as np
+    torch, ctx = R.torch, hl.ctx
+    import mi355slam
+    host = torch.from_numpy(frames_np).pin_memory()
+    cap = hl.cap
+    v = None
+    outs = None
+    hl.step(images=host.numpy()); ctx.sync()
+    v = hl.view
+    sizes = {"count": 4 * BATCH, "x": 4 * BATCH * cap, "y": 4 * BATCH * cap, "angle": 4 * BATCH * cap, "octave": 4 * BATCH * cap, "desc": 32 * BATCH * cap,
+             "match": 4 * BATCH * cap}
+    outs = {k: torch.empty(n, dtype=torch.uint8).pin_memory() for k, n in sizes.items()}
+    ptr = {"count": v.count, "x": v.x, "y": v.y, "angle": v.angle, "octave": v.octave, "desc": v.desc, "match": hl.match.data_ptr()}
+    import ctypes as C
+
+    def d2h():
+        for k, n in sizes.items():
+            ctx.check(mi355slam.lib().ms_dev_download(ctx._h, C.c_void_p(outs[k].data_ptr()), C.c_void_p(ptr[k]), C.c_size_t(n)), "ms_dev_download")
+    hl.step(images=host.numpy()); d2h()
+    R.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        hl.step(images=host.numpy())
+        d2h()
+    ctx.sync()
+    R.barrier()
+    dt = time.perf_counter() - t0
+    total, dt = R.aggregate(BATCH * steps, dt)
+    bytes_step = frames_np.nbytes + sum(sizes.values())
+    return {"value": round(total / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "host_bytes_per_step": int(bytes_step), "host_GBs": round(bytes_step * steps * R.world / dt / 1e9, 1),
+            "note": "pinned host frames -> device (one 2-D copy per frame inside ms_orb_extract), step, all SoA outputs + matches -> pinned host; "
+                    "copies and kernels serial on the context stream (no double buffering)"}
+
+
+def bench_ba(R, ctx, args):
+    """C4: 50 keyframes x 2000 points x 20000 observations, 10 LM iterations, Huber sqrt(5.991), 49 odometry edges; 256 DISTINCT windows."""
     import ba_synth
     import mi355slam
-    distinct = [ba_synth.make_problem(50, 2000, 10, seed=42 + 8 * rank + i) for i in range(4)]
-    probs = [distinct[i % len(distinct)] for i in range(args.ba_batch)]
+    probs = [ba_synth.make_problem_fast(50, 2000, 10, seed=42 + 1000 * R.rank + i) for i in range(args.ba_batch)]
     ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=10)
     ba.solve(); ctx.sync()                                   # warm-up
-    if dist is not None:
-        dist.barrier()
+    R.barrier()
     t0 = time.perf_counter()
     ctx.event_mark(2)
     for _ in range(args.ba_steps):
         ba.solve()
     ctx.event_mark(3)
     ctx.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    R.barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ctx.event_elapsed_ms(2, 3) / args.ba_steps
-    from mi355slam import shard
-    solves_total, dt = shard.aggregate(dist, torch, args.ba_batch * args.ba_steps, dt, device="cuda")
-    st = ba.download(0)["stats"]
-    # single-window latency (one workgroup on one CU)
+    solves_total, dt = R.aggregate(args.ba_batch * args.ba_steps, dt)
+    stats = [ba.download(i)["stats"] for i in range(0, args.ba_batch, max(args.ba_batch // 16, 1))]
+    iters = sum(s["iters"] for s in stats) / len(stats)
+    trials = sum(s["trials"] for s in stats) / len(stats)
     # latency of ONE window (what a sequential SLAM pipeline sees): a team of workgroups shares the problem (automatic size);
     # one_cu = the same solve confined to a single workgroup, as every window of the 256-window launch above runs
     one = mi355slam.BundleAdjuster(ctx, probs[:1], max_iters=10)
@@ -231,23 +488,128 @@ def bench_ba(ctx, args, world, rank, dist, torch):
     one.set_team(1); one.solve(); ctx.sync()
     ctx.event_mark(4); one.solve(); ctx.event_mark(5)
     single_one_cu_ms = ctx.event_elapsed_ms(4, 5)
-    alg_bytes_per_solve = 6.61e6 * st["iters"]               # 6.61 MB per LM iteration at C4
+    # what a keyframe pays when the window is new: create (host index build + upload) + solve + download + destroy
+    t1 = time.perf_counter()
+    n_new = 8
+    for i in range(n_new):
+        b = mi355slam.BundleAdjuster(ctx, [probs[i % len(probs)]], max_iters=10); b.solve(); b.download(0); b.close()
+    new_window_ms = (time.perf_counter() - t1) / n_new * 1e3
+    alg_bytes_per_launch = 6.61e6 * trials * args.ba_batch    # 6.61 MB per LM iteration (= per damped solve) at C4
+    achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    pmc = pmc_of("k_ba_lm")
     res = {"metric": "local-BA solves/sec (50 KF x 2000 pts x 20k obs, 10 LM iters)", "value": round(solves_total / dt, 1),
-           "unit": "solves/s", "windows_per_launch": args.ba_batch, "ms_per_launch": round(kernel_ms, 3), "lm_iterations": st["iters"],
-           "lm_trials": st["trials"], "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
-           "single_window_one_cu_ms": round(single_one_cu_ms, 3),
-           "alg_GBs": round(alg_bytes_per_solve * args.ba_batch / (kernel_ms * 1e-3) / 1e9, 1), "dtype": "f64"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import mso
-        t1 = time.perf_counter()
-        n_cpu = 48
-        for i in range(n_cpu):
-            mso.ba_solve(distinct[i % 4], 10, False)
-        res["cpu_baseline"] = {"value": round(n_cpu / (time.perf_counter() - t1), 2), "unit": "solves/s", "cores": 1, "kind": "port",
-                               "sample": "%d solves of C4 windows (4 distinct), oracle/libmso.so (Schur + dense Cholesky), 1 thread" % n_cpu}
+           "unit": "solves/s", "windows_per_launch": args.ba_batch, "distinct_windows": len(probs), "ms_per_launch": round(kernel_ms, 3),
+           "lm_iterations": round(iters, 2), "lm_trials": round(trials, 2),
+           "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1), "single_window_one_cu_ms": round(single_one_cu_ms, 3),
+           "new_window_ms": round(new_window_ms, 3), "dtype": "f64",
+           "roofline": {"kernel": "k_ba_lm", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                        "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes of this build over the 256-window launch, tools/pmc_ba.sh)") if pmc else None}}
+    if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_ba(probs[:32])
     ba.close(); one.close()
     return res
+
+
+class SequenceRunner(threading.Thread):
+    """One SLAM sequence as its backend thread drives it (mapper_helpers.cpp:1011-1131 order): per frame extract -> match against the
+    previous frame -> ratio test; on every k-th frame (a keyframe) one local BA of a NEW C4-shaped window (create + solve + download).
+    Own context (stream) and handles; nothing is batched across frames."""
+
+    def __init__(self, device, seq_id, frames_np, windows, kf_every, start_evt, on_frame=None):
+        super().__init__()
+        self.device, self.seq_id, self.frames_np, self.windows, self.kf_every, self.start_evt = device, seq_id, frames_np, windows, kf_every, start_evt
+        self.on_frame = on_frame                                 # tests only: called after every frame with the device results (synchronises)
+        self.frames_done = self.ba_done = self.matches = 0
+        self.error = None
+        self.seconds = 0.0
+        self.ready = threading.Event()
+
+    def run(self):
+        try:
+            import mi355slam
+            ctx = mi355slam.Context(self.device)
+            n = len(self.frames_np)
+            buf = ctx.upload(self.frames_np)
+            ex = [mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=1) for _ in range(2)]
+            cap = ex[0].capacity
+            bi, bd, sd, match = ctx.alloc(4 * cap + 16), ctx.alloc(2 * cap + 16), ctx.alloc(2 * cap + 16), ctx.alloc(4 * cap + 16)
+            views = [None, None]
+
+            def frame(i, count):
+                e = ex[i & 1]
+                e.extract(buf.ptr + i * W * H, n_frames=1, frame_stride=W * H, row_stride=W)
+                if views[i & 1] is None:
+                    views[i & 1] = e.device_view()
+                if i:
+                    q, t = views[i & 1], views[(i - 1) & 1]
+                    mi355slam.hamming_best2_sets(ctx, q.desc, cap, q.count, t.desc, cap, t.count, None, None, 1, bi, bd, sd)
+                    mi355slam.ratio_test_device(ctx, bi, bd, sd, cap, LOWE_RATIO, 50, match)
+                ba_out = None
+                if i % self.kf_every == 0 and self.windows:
+                    b = mi355slam.BundleAdjuster(ctx, [self.windows[(i // self.kf_every) % len(self.windows)]], max_iters=10)
+                    b.solve(); ba_out = b.download(0); b.close()
+                    if count:
+                        self.ba_done += 1
+                if self.on_frame is not None and count:
+                    ctx.sync()
+                    self.on_frame(i, e, (bi, bd, sd, match) if i else None, ba_out)
+            for i in range(min(2, n)):
+                frame(i, False)                                  # warm-up: lazily built state, first launches
+            ctx.sync()
+            self.ready.set()
+            self.start_evt.wait()
+            t0 = time.perf_counter()
+            for i in range(n):
+                frame(i, True)
+                self.frames_done += 1
+            ctx.sync()
+            self.seconds = time.perf_counter() - t0
+            import numpy as np
+            self.matches = int((match.download(np.int32, (cap,)) >= 0).sum())
+            ctx.close()
+        except Exception as e:                                   # noqa: BLE001 -- reported by the parent
+            self.error = e
+            self.ready.set()
+
+
+def bench_c5(R, args):
+    """BASELINE config 5: 8 independent synthetic sequences, sequence s on GPU s mod N (shard.sequence_of), one host thread + context per
+    sequence.  The job's total work is fixed (8 sequences), so across N this leg is STRONG scaling; `value` above stays weak scaling."""
+    import ba_synth
+    import synth
+    from mi355slam import shard
+    mine = [s for s in range(N_SEQ) if shard.sequence_of(s, R.world) == R.rank]
+    F = args.c5_frames
+    start = threading.Event()
+    runners = []
+    for s in mine:
+        g = synth.SequenceSynth(W, H, 2000 + s, 2 * (F - 1), F - 1)
+        import numpy as np
+        frames = np.stack([g.frame(2 * i, i) for i in range(F)])
+        windows = [] if args.no_ba else [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + 16 * s + k) for k in range(4)]
+        runners.append(SequenceRunner(R.local_rank, s, frames, windows, args.c5_keyframe_every, start))
+    for r in runners:
+        r.start()
+    for r in runners:
+        r.ready.wait()
+    R.barrier()
+    t0 = time.perf_counter()
+    start.set()
+    for r in runners:
+        r.join()
+    R.barrier()
+    dt = time.perf_counter() - t0
+    errs = [r.error for r in runners if r.error]
+    if errs:
+        raise errs[0]
+    frames_total, dt_max = R.aggregate(sum(r.frames_done for r in runners), dt)
+    ba_total, _ = R.aggregate(sum(r.ba_done for r in runners), dt)
+    return {"workload": "8 independent 720p sequences x %d frames; per frame extract -> match vs previous -> ratio test; every %d-th frame a local BA of a new "
+                        "C4 window (create + solve + download); sequence s on GPU s mod N, one host thread + context per sequence" % (F, args.c5_keyframe_every),
+            "scaling": "strong (8 sequences in total)", "frames_per_s": round(frames_total / dt_max, 1), "ba_per_s": round(ba_total / dt_max, 1),
+            "seconds": round(dt_max, 4), "per_gpu": [round(v, 1) for v in R.gather(sum(r.frames_done for r in runners) / dt)],
+            "sequences_per_gpu": R.gather(len(mine)), "last_frame_matches": [r.matches for r in runners]}
 
 
 def ctx_download(ctx, dev_ptr, nbytes):
@@ -256,6 +618,23 @@ def ctx_download(ctx, dev_ptr, nbytes):
     buf = (C.c_char * nbytes)()
     ctx.check(mi355slam.lib().ms_dev_download(ctx._h, buf, C.c_void_p(dev_ptr), C.c_size_t(nbytes)), "ms_dev_download")
     return bytes(buf)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args, argv))                  # the parent never touches the GPU
+    R = Rank(args)
+    if R.world != args.gpus and R.rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d; reporting n_gpus = WORLD_SIZE\n" % (args.gpus, R.world))
+    try:
+        if args.plumbing:
+            run_plumbing(R, args)
+        else:
+            run_gpu(R, args)
+    finally:
+        R.close()
 
 
 if __name__ == "__main__":

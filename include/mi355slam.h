@@ -93,7 +93,8 @@ typedef struct {
                                   floor(min_distance * min(w,h)/720 * 0.8 + 0.5) pixels apart; 0 = no suppression */
 } ms_orb_config;
 
-/* Per-frame outputs, structure-of-arrays, `capacity` = max_tracks + max_kpts slots per frame.
+/* Per-frame outputs, structure-of-arrays, `capacity` = max_tracks + max(max_kpts, sum of the per-level quotas) slots per frame
+ * (ms_orb_capacity; the quotas are rounded level by level, static_settings.cpp:52, and may add up to a few more than max_kpts).
  * Frame f's keypoint i is element f*capacity + i of each array (desc: 8 words per slot).
  * Order inside a frame: tracker features first, then detected points level-major
  * (orb_extractor.cpp:136-162); each level ordered by (FAST score desc, y*w+x asc). */
@@ -152,10 +153,10 @@ int ms_orb_download_detections(ms_orb *orb, int frame, int level, int32_t *x, in
  * Descriptor matching -- the scoring core of keyframe_matcher.cpp (compute_descriptor_distance_32,
  * openvslam/match_base.h:18-39) as device primitives.
  * ------------------------------------------------------------------------------------------- */
-/* Process-wide choice of the kernel behind the UNMASKED searches: 0 = automatic (the i8 matrix-core kernel), 1 = the popcount
+/* Per-context choice of the kernel behind the UNMASKED searches: 0 = automatic (the i8 matrix-core kernel), 1 = the popcount
  * kernel (v_xor / v_bcnt, wave reductions) that the masked searches always use.  Both give identical results; the switch exists to
  * cross-check one against the other and to time them side by side (bench.py reports both). */
-int ms_hamming_set_path(int path);
+int ms_hamming_set_path(ms_ctx *ctx, int path);
 
 /* Brute-force best / second-best of every query against every target, for `n_pairs` independent
  * (query set, target set) pairs laid out back to back: pair p uses q + p*nq*8 and t + p*nt*8.
@@ -333,8 +334,18 @@ int ms_ba_set_team(ms_ba *ba, int workgroups_per_problem);
  * and a densely coupled map by many).  Has no effect on smaller systems. */
 int ms_ba_set_factor_team(ms_ba *ba, int workgroups);
 int ms_ba_solve(ms_ba *ba);
+/* Team launches (more than one workgroup per problem) synchronise their workgroups with spin barriers, which need every workgroup
+ * of the launch resident: problems x team <= CUs is enforced, and the team launches of one process are chained per device (each
+ * waits for the previous one, whichever context issued it), so two contexts -- the front end's poseBundleAdjust beside the back
+ * end's localBundleAdjust, mapper.cpp:379-390 vs :268-269 -- may solve at the same time.  If a barrier still gives up (no progress
+ * for ~1 s: CUs held by another PROCESS), ms_ba_download repeats the solve with one workgroup per problem before it returns;
+ * ms_ba_team_fallbacks counts those repeats.  ms_ba_debug_fail_team_barriers(ba, 1) makes every team barrier of the following
+ * launches give up at once (test hook for that path). */
+int ms_ba_team_fallbacks(const ms_ba *ba);
+int ms_ba_debug_fail_team_barriers(ms_ba *ba, int on);
 /* Results of problem i (synchronises): poses [n_pose*7], points [n_point*3], per-observation chi2
- * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL. */
+ * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL.  The status is read first: on
+ * MS_ERR_NUMERIC (non-finite state) none of the caller's arrays is written (res, when given, is filled). */
 int ms_ba_download(ms_ba *ba, int i, double *pose, double *point, double *chi2_per_obs, ms_ba_result *res);
 /* create + solve + download + destroy for one problem. */
 int ms_ba_solve_host(ms_ctx *ctx, const ms_ba_problem *problem, double *pose_out, double *point_out,

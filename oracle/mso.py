@@ -183,7 +183,7 @@ def orb_descriptor(blur, x, y, angle_deg):
 def orb_extract(config, img, valid_mask=None, track_xy=None, track_id=None):
     img = np.ascontiguousarray(img, np.uint8)
     nt = 0 if track_xy is None else len(track_xy)
-    cap = config.max_kpts + nt + 8
+    cap = config.max_kpts + nt + 16          # the rounded per-level quotas can add up to a few more than max_kpts
     out = dict(x=np.zeros(cap, np.float32), y=np.zeros(cap, np.float32), angle=np.zeros(cap, np.float32),
                octave=np.zeros(cap, np.int32), desc=np.zeros((cap, 8), np.uint32), track_id=np.zeros(cap, np.int32))
     kp = Keypoints(0, _p(out["x"], f32p), _p(out["y"], f32p), _p(out["angle"], f32p), _p(out["octave"], i32p),

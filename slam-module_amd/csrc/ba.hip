@@ -27,6 +27,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -950,9 +951,9 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
 }
 
 // before a team launch: arrival counters and the gave-up marker back to zero (the counter is monotonic within a launch)
-__global__ void k_ba_team_reset(const BaProb *probs, int n) {
+__global__ void k_ba_team_reset(const BaProb *probs, int n, int gave_up) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { probs[i].bar[0] = 0; probs[i].bar[32] = 0; probs[i].flag[1] = 0; }
+    if (i < n) { probs[i].bar[0] = 0; probs[i].bar[32] = 0; probs[i].flag[1] = gave_up; }
 }
 
 // grid = problems x team workgroups; workgroup b works on problem b / team
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     if (gt == 0) {
         const bool hung = P.team > 1 && P.flag[1] != 0;        // a team barrier gave up: the result is not to be trusted
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
-        P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = 0;
+        P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = hung ? 1 : 0;
         for (int k = 0; k < 5; ++k) P.stats[8 + k] = (double)cyc[k];
         P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5]; P.stats[15] = (double)cyc[6];
     }
@@ -1058,7 +1059,14 @@ struct ms_ba {
     int factor_team = 0;               // of these, workgroups in the distributed Cholesky of a large system (ms_ba_set_factor_team; 0 = automatic)
     std::vector<double> chol_tiles;    // per problem: row tiles a Cholesky panel touches on average
     int cus = 0;
+    int launched_team = 1;             // team size of the last launch
+    int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
+    int team_fallbacks = 0;            // launches repeated with one workgroup per problem after a team barrier gave up
 };
+
+static std::mutex g_team_mu;           // team launches of this process are chained per device (see ms_ba_solve)
+static hipEvent_t g_team_ev[64] = {nullptr};
+#define MS_TRY_BA(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
 
 extern "C" {
 
@@ -1296,11 +1304,39 @@ int ms_ba_solve(ms_ba *B) {
         MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
     }
     // A plain launch: every workgroup needs more than half a CU's LDS and problems x team <= CUs, so all of a team's workgroups
-    // become resident as soon as CUs are free (other kernels drain on their own; nothing in this library runs beside it on the
-    // stream).  The cooperative-launch API would assert the same thing, but rocprofv3 crashes at process exit after one.
-    if (team > 1) hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, c->stream, B->d_probs, B->n);
-    hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
+    // become resident as soon as CUs are free.  What the spin barriers additionally need is that no OTHER team launch holds CUs
+    // while waiting for its own missing workgroups (two half-resident teams would wait for each other until the give-up): team
+    // launches of one process are therefore chained on one event per device -- each waits for the previous one, whatever stream
+    // (context) it came from.  Launches without a team (one workgroup per problem: every batch) are not chained.  A kernel of
+    // another stream that keeps CUs busy only delays the team; should a barrier still give up (~1 s without progress),
+    // ms_ba_download solves the batch again with one workgroup per problem.
+    if (team > 1) {
+        std::lock_guard<std::mutex> lk(g_team_mu);
+        hipEvent_t &ev = g_team_ev[c->device & 63];
+        if (!ev) MS_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else MS_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+        hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, c->stream, B->d_probs, B->n, B->debug_fail_barriers);
+        hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
+        MS_KERNEL_CHECK(c, "k_ba_lm");
+        MS_HIP(c, hipEventRecord(ev, c->stream));
+    } else {
+        hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
+        MS_KERNEL_CHECK(c, "k_ba_lm");
+    }
+    B->launched_team = team;
+    return MS_OK;
+}
+
+// one workgroup per problem, no team barriers: the fallback after a team barrier gave up
+static int ba_relaunch_single(ms_ba *B) {
+    ms_ctx *c = B->ctx;
+    for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
+    MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
     MS_KERNEL_CHECK(c, "k_ba_lm");
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    B->launched_team = 1;
+    ++B->team_fallbacks;
     return MS_OK;
 }
 
@@ -1309,19 +1345,27 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
     ms_ctx *c = B->ctx;
     MS_HIP(c, hipStreamSynchronize(c->stream));
     const BaProb &H = B->host[i];
-    if (pose) MS_HIP(c, hipMemcpy(pose, H.pose, 7 * (size_t)H.n_pose * sizeof(double), hipMemcpyDeviceToHost));
-    if (point && H.n_point) MS_HIP(c, hipMemcpy(point, H.point, 3 * (size_t)H.n_point * sizeof(double), hipMemcpyDeviceToHost));
-    if (chi2_per_obs && H.n_obs) MS_HIP(c, hipMemcpy(chi2_per_obs, H.chi2_obs, (size_t)H.n_obs * sizeof(double), hipMemcpyDeviceToHost));
-    if (res) {
-        double st[16];
+    // status first: a failed solve must not overwrite the caller's arrays (the host mirrors pass the window itself as output)
+    double st[16];
+    MS_HIP(c, hipMemcpy(st, H.stats, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[7] != 0 && B->launched_team > 1) {            // a team barrier gave up: solve again without a team, then look again
+        MS_TRY_BA(ba_relaunch_single(B));
         MS_HIP(c, hipMemcpy(st, H.stats, sizeof(st), hipMemcpyDeviceToHost));
+    }
+    if (res) {
         for (int k = 0; k < 8; ++k) res->phase_cycles[k] = st[8 + k];
         res->iterations = (int)st[0]; res->trials = (int)st[1]; res->stopped_early = (int)st[2]; res->final_lambda = st[3];
         res->chi2_initial = st[4]; res->chi2_final = st[5];
-        if (st[6] == 0) return ms_fail(c, MS_ERR_NUMERIC, "ms_ba_download: problem %d ended in a non-finite state", i);
     }
+    if (st[6] == 0) return ms_fail(c, MS_ERR_NUMERIC, "ms_ba_download: problem %d ended in a non-finite state", i);
+    if (pose) MS_HIP(c, hipMemcpy(pose, H.pose, 7 * (size_t)H.n_pose * sizeof(double), hipMemcpyDeviceToHost));
+    if (point && H.n_point) MS_HIP(c, hipMemcpy(point, H.point, 3 * (size_t)H.n_point * sizeof(double), hipMemcpyDeviceToHost));
+    if (chi2_per_obs && H.n_obs) MS_HIP(c, hipMemcpy(chi2_per_obs, H.chi2_obs, (size_t)H.n_obs * sizeof(double), hipMemcpyDeviceToHost));
     return MS_OK;
 }
+
+int ms_ba_team_fallbacks(const ms_ba *B) { return B ? B->team_fallbacks : MS_ERR_INVALID; }
+int ms_ba_debug_fail_team_barriers(ms_ba *B, int on) { if (!B) return MS_ERR_INVALID; B->debug_fail_barriers = on ? 1 : 0; return MS_OK; }
 
 int ms_ba_solve_host(ms_ctx *c, const ms_ba_problem *problem, double *pose_out, double *point_out, double *chi2_per_obs, ms_ba_result *res) {
     ms_ba *B = nullptr;

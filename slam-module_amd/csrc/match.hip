@@ -537,8 +537,6 @@ __global__ __launch_bounds__(64) void k_match_greedy(GreedyArgs A) {
 
 extern "C" {
 
-static int g_hamming_path = 0;        // 0 = automatic, 1 = popcount kernel for everything (cross-check and comparison; ms_hamming_set_path)
-
 static int launch_hamming(ms_ctx *c, const HamArgs &A, int n_pairs) {
     if (A.nq < 0 || A.nt < 0 || n_pairs < 0 || A.nt >= (1 << 20) || n_pairs > 65535 || A.q_stride < A.nq || A.t_stride < A.nt)
         return ms_fail(c, MS_ERR_INVALID, "hamming search: size out of range");
@@ -549,15 +547,15 @@ static int launch_hamming(ms_ctx *c, const HamArgs &A, int n_pairs) {
     MS_HIP(c, hipSetDevice(c->device));
     dim3 grid(ms_div_up(A.q_stride, 256), n_pairs);
     if (A.qb || A.tv) hipLaunchKernelGGL(k_hamming_best2<true>, grid, dim3(256), 0, c->stream, A);
-    else if (g_hamming_path == 1) hipLaunchKernelGGL(k_hamming_best2<false>, grid, dim3(256), 0, c->stream, A);
+    else if (c->hamming_path == 1) hipLaunchKernelGGL(k_hamming_best2<false>, grid, dim3(256), 0, c->stream, A);
     else hipLaunchKernelGGL(k_hamming_mfma, grid, dim3(256), 0, c->stream, A);
     MS_KERNEL_CHECK(c, "k_hamming_best2");
     return MS_OK;
 }
 
-int ms_hamming_set_path(int path) {
-    if (path < 0 || path > 1) return MS_ERR_INVALID;
-    g_hamming_path = path;
+int ms_hamming_set_path(ms_ctx *c, int path) {
+    if (!c || path < 0 || path > 1) return MS_ERR_INVALID;
+    c->hamming_path = path;
     return MS_OK;
 }
 

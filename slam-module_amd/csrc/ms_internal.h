@@ -16,6 +16,7 @@ struct ms_ctx {
     int n_cu = 0;
     void *scratch = nullptr;      // growable device scratch for small per-call argument tables
     size_t scratch_bytes = 0;
+    int hamming_path = 0;         // 0 = automatic (matrix-core kernel for unmasked searches), 1 = popcount kernel for everything (ms_hamming_set_path)
     char err[512] = {0};
 };
 

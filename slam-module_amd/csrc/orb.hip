@@ -43,6 +43,8 @@ struct LevelGeom {
 
 struct PyrGeom {
     int32_t levels, lk_level, fast_threshold, max_kpts, max_tracks, capacity;
+    int32_t det_stride;               // per-frame stride of the det arrays = max(max_kpts, sum of the level quotas): the quotas are rounded per level
+                                      // (static_settings.cpp:52) and can add up to more than max_kpts (e.g. 15 levels / 160 keypoints -> 161)
     int32_t width, height, btiles_total, ftiles_total;
     uint64_t slab_stride, cand_stride;     // per frame: bytes / entries
     int32_t umax[16];
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
         }
         const int run = s_run;
         if (ok) {
-            const uint64_t slot = (uint64_t)f * g->max_kpts + G.det_base + run + s_scan[tid] - 1;
+            const uint64_t slot = (uint64_t)f * g->det_stride + G.det_base + run + s_scan[tid] - 1;
             det_x[slot] = (int16_t)x; det_y[slot] = (int16_t)y; det_score[slot] = (uint8_t)sc;
         }
         __syncthreads();
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
 #pragma unroll
             for (int l = 0; l < MS_MAX_LEVELS; ++l)
                 if (level < 0 && l < levels) { if (idx < cnt[l]) level = l; else idx -= cnt[l]; }
-            const uint64_t s2 = (uint64_t)f * g->max_kpts + g->L[level].det_base + idx;
+            const uint64_t s2 = (uint64_t)f * g->det_stride + g->L[level].det_base + idx;
             K[k].x = det_x[s2]; K[k].y = det_y[s2]; K[k].oct = level; K[k].tid_out = -1;
             K[k].ox = __fmul_rn((float)K[k].x, g->L[level].scale);     // orb_extractor.cpp:156
             K[k].oy = __fmul_rn((float)K[k].y, g->L[level].scale);
@@ -1038,7 +1040,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     o->cfg = *cfg;
     PyrGeom &G = o->geom;
     G.levels = cfg->levels; G.lk_level = cfg->lk_track_level; G.fast_threshold = cfg->fast_threshold;
-    G.max_kpts = cfg->max_kpts; G.max_tracks = cfg->max_tracks; G.capacity = cfg->max_kpts + cfg->max_tracks;
+    G.max_kpts = cfg->max_kpts; G.max_tracks = cfg->max_tracks;
     G.width = cfg->width; G.height = cfg->height;
     int32_t w[MS_MAX_LEVELS], h[MS_MAX_LEVELS], quota[MS_MAX_LEVELS];
     float sf[MS_MAX_LEVELS];
@@ -1073,6 +1075,8 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         L.btiles_inv = (uint32_t)(((1ull << 32) + L.btiles_x - 1) / L.btiles_x); L.ftiles_inv = (uint32_t)(((1ull << 32) + L.ftiles_x - 1) / L.ftiles_x);
     }
     G.btiles_total = bt; G.ftiles_total = ft;
+    G.det_stride = std::max(cfg->max_kpts, det_base);       // the reference keeps per-level vectors, so a frame can hold sum(quota) > maxKeypoints points
+    G.capacity = G.det_stride + cfg->max_tracks;
     for (int l = 0; l < cfg->levels; ++l) {
         const LevelGeom &L = G.L[l];
         o->tile_levels.L[l] = TileLevel{L.w, L.h, L.pitch, L.btiles_x, L.ftiles_x, L.cand_cap, L.btiles_inv, L.ftiles_inv, L.img_off, L.blur_off, L.cand_off};
@@ -1093,9 +1097,9 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     A(dev_calloc(ctx, &o->d_cand_count, B * MS_MAX_LEVELS));
     A(dev_calloc(ctx, &o->d_det_count, B * MS_MAX_LEVELS));
     A(dev_calloc(ctx, &o->d_trk_count, B));
-    A(dev_calloc(ctx, &o->d_det_x, B * cfg->max_kpts));
-    A(dev_calloc(ctx, &o->d_det_y, B * cfg->max_kpts));
-    A(dev_calloc(ctx, &o->d_det_score, B * cfg->max_kpts));
+    A(dev_calloc(ctx, &o->d_det_x, B * (size_t)G.det_stride));
+    A(dev_calloc(ctx, &o->d_det_y, B * (size_t)G.det_stride));
+    A(dev_calloc(ctx, &o->d_det_score, B * (size_t)G.det_stride));
     const size_t T = (size_t)std::max(cfg->max_tracks, 1);
     A(dev_calloc(ctx, &o->d_trk_x, B * T)); A(dev_calloc(ctx, &o->d_trk_y, B * T));
     A(dev_calloc(ctx, &o->d_trk_px, B * T)); A(dev_calloc(ctx, &o->d_trk_py, B * T));
@@ -1355,7 +1359,7 @@ int ms_orb_download_detections(ms_orb *o, int frame, int level, int32_t *x, int3
     MS_HIP(c, hipStreamSynchronize(c->stream));
     int32_t cnt = 0;
     MS_HIP(c, hipMemcpy(&cnt, o->d_det_count + frame * o->geom.levels + level, 4, hipMemcpyDeviceToHost));
-    const size_t b = (size_t)frame * o->cfg.max_kpts + o->geom.L[level].det_base;
+    const size_t b = (size_t)frame * o->geom.det_stride + o->geom.L[level].det_base;
     std::vector<int16_t> hx(cnt), hy(cnt); std::vector<uint8_t> hs(cnt);
     if (cnt) {
         MS_HIP(c, hipMemcpy(hx.data(), o->d_det_x + b, cnt * 2, hipMemcpyDeviceToHost));

@@ -4,6 +4,7 @@
 // parent project that is not part of the reference tree, so these mirrors use the minimal plain-data
 // equivalents below; INTEGRATION.md shows the glue that maps the reference's types onto them.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <memory>

@@ -39,14 +39,13 @@ public:
             ctx_.check(ms_orb_create(ctx_.get(), &c, &orb_), "ms_orb_create");
             cap_ = ms_orb_capacity(orb_);
             x_.resize(cap_); y_.resize(cap_); a_.resize(cap_); o_.resize(cap_); t_.resize(cap_); d_.resize(8 * (std::size_t)cap_);
+            xy_.assign(2 * (std::size_t)p.maxTracks, 0.f); ids_.assign(p.maxTracks, 0);      // workspace, like orb_extractor.cpp:217-219: nothing is allocated per frame
         }
         if (mask != mask_) { ctx_.check(ms_orb_set_valid_mask(orb_, mask), "ms_orb_set_valid_mask"); mask_ = mask; }
-        std::vector<float> xy(2 * (std::size_t)p.maxTracks, 0.f);
-        std::vector<std::int32_t> ids(p.maxTracks, 0);
         const std::int32_t nt = (std::int32_t)std::min<std::size_t>(tracks.size(), p.maxTracks);
-        for (int i = 0; i < nt; ++i) { xy[2 * i] = tracks[i].x; xy[2 * i + 1] = tracks[i].y; ids[i] = tracks[i].id; }
+        for (int i = 0; i < nt; ++i) { xy_[2 * i] = tracks[i].x; xy_[2 * i + 1] = tracks[i].y; ids_[i] = tracks[i].id; }
         ctx_.check(ms_orb_extract(orb_, img.data, img.onDevice ? 1 : 0, 1, img.stride * (std::size_t)img.height, img.stride,
-                                  p.maxTracks ? xy.data() : nullptr, p.maxTracks ? ids.data() : nullptr, p.maxTracks ? &nt : nullptr),
+                                  p.maxTracks ? xy_.data() : nullptr, p.maxTracks ? ids_.data() : nullptr, p.maxTracks ? &nt : nullptr),
                    "ms_orb_extract");
         std::int32_t n = 0;
         ctx_.check(ms_orb_download(orb_, 0, x_.data(), y_.data(), a_.data(), o_.data(), d_.data(), t_.data(), &n), "ms_orb_download");
@@ -74,7 +73,7 @@ public:
         const unsigned L = settings_.parameters.orbScaleLevels;
         perLevel.assign(L, {});
         std::size_t total = 0;
-        std::vector<std::int32_t> x(settings_.parameters.maxKeypoints), y(x.size()), s(x.size());
+        std::vector<std::int32_t> x((std::size_t)std::max(cap_, 1)), y(x.size()), s(x.size());
         for (unsigned l = 0; l < L; ++l) {
             std::int32_t n = 0;
             ctx_.check(ms_orb_download_detections(orb_, 0, (int)l, x.data(), y.data(), s.data(), &n), "ms_orb_download_detections");
@@ -90,8 +89,8 @@ private:
     ms_orb *orb_ = nullptr;
     const std::uint8_t *mask_ = nullptr;
     int cap_ = 0;
-    std::vector<float> x_, y_, a_;
-    std::vector<std::int32_t> o_, t_;
+    std::vector<float> x_, y_, a_, xy_;
+    std::vector<std::int32_t> o_, t_, ids_;
     std::vector<std::uint32_t> d_;
 };
 }  // namespace detail

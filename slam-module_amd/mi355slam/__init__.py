@@ -109,6 +109,10 @@ class Context:
         self.check(lib().ms_event_elapsed_ms(self._h, a, b, C.byref(ms)), "ms_event_elapsed_ms")
         return ms.value
 
+    def set_hamming_path(self, path):
+        """0 = automatic (matrix-core kernel for unmasked searches), 1 = popcount kernel for everything."""
+        self.check(lib().ms_hamming_set_path(self._h, int(path)), "ms_hamming_set_path")
+
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
 
@@ -278,7 +282,7 @@ class OrbExtractor:
         return out
 
     def download_detections(self, frame, level):
-        q = self.cfg.max_kpts
+        q = self.capacity
         x, y, s = np.zeros(q, np.int32), np.zeros(q, np.int32), np.zeros(q, np.int32)
         n = C.c_int32()
         self.ctx.check(lib().ms_orb_download_detections(self._h, frame, level, _vp(x), _vp(y), _vp(s), C.byref(n)), "ms_orb_download_detections")
@@ -541,6 +545,12 @@ class BundleAdjuster:
 
     def solve(self):
         self.ctx.check(lib().ms_ba_solve(self._h), "ms_ba_solve")
+
+    def team_fallbacks(self):
+        return lib().ms_ba_team_fallbacks(self._h)
+
+    def debug_fail_team_barriers(self, on=True):
+        self.ctx.check(lib().ms_ba_debug_fail_team_barriers(self._h, int(on)), "ms_ba_debug_fail_team_barriers")
 
     def download(self, i):
         npz, nl, no = self.dims[i]

@@ -107,3 +107,48 @@ def residuals(prob, pose, point):
         p = Rs[i] @ point[l] + pose[i, 4:]
         out[o] = prob["obs_uv"][o] - p[:2] / p[2]
     return out
+
+
+def make_problem_fast(n_pose=50, n_point=2000, run=10, seed=42, noise=1.0 / 500, prior_r=100.0, prior_p=50.0, dt=0.1):
+    """The same window as make_problem (same trajectory, point box, run-of-`run` visibility, noise, octaves, odometry chain,
+    perturbations), generated with vectorised draws: a different random stream, ~50x faster.  bench.py builds its 256 DISTINCT
+    C4 windows with it."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    sf2 = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32) ** 2
+    gt_pose = np.empty((n_pose, 7)); Rs = np.empty((n_pose, 3, 3))
+    for i in range(n_pose):
+        c = np.array([0.2 * i - 0.1 * (n_pose - 1), 0.05 * np.sin(0.3 * i), 0.02 * i])
+        R = _rotvec(np.array([0.0, (0.004 if n_pose <= 50 else 0.2 / n_pose) * (i - n_pose / 2), 0.0])) @ _rotvec(np.array([0.01 * np.sin(i), 0, 0]))
+        gt_pose[i] = _pose(R, -R @ c); Rs[i] = _R_from_quat(gt_pose[i, :4])
+    half = 0.1 * (n_pose - 1)
+    gt_point = np.stack([rng.uniform(-half - 1, half + 1, n_point), rng.uniform(-2, 2, n_point), rng.uniform(4, 10, n_point)], 1)
+    run = min(run, n_pose)
+    start = rng.integers(0, n_pose - run + 1, n_point)
+    obs_point = np.repeat(np.arange(n_point, dtype=np.int32), run)
+    obs_pose = (start[:, None] + np.arange(run)[None, :]).reshape(-1).astype(np.int32)
+    p = np.einsum("oij,oj->oi", Rs[obs_pose], gt_point[obs_point]) + gt_pose[obs_pose, 4:]
+    assert (p[:, 2] > 0.5).all()
+    uv = p[:, :2] / p[:, 2:3] + rng.normal(0, noise, (len(p), 2))
+    info = 500.0 ** 2 / sf2[rng.integers(0, 8, len(p))].astype(np.float64)
+    W = np.diag([prior_r ** 2] * 3 + [prior_p ** 2] * 3) * (0.26667 / dt)
+    edge_meas = np.empty((n_pose - 1, 7))
+    odo = np.concatenate([rng.normal(0, 0.001, (n_pose - 1, 3)), rng.normal(0, 0.002, (n_pose - 1, 3))], 1)
+    for i in range(1, n_pose):
+        M = _compose(gt_pose[i - 1], _inverse(gt_pose[i]))
+        edge_meas[i - 1] = _compose(_pose(_rotvec(odo[i - 1, :3]), odo[i - 1, 3:]), M)
+    pose = gt_pose.copy()
+    dr, dtv = rng.normal(0, np.radians(0.5) / np.sqrt(3), (n_pose, 3)), rng.normal(0, 0.02 / np.sqrt(3), (n_pose, 3))
+    for i in range(n_pose):
+        pose[i] = _compose(_pose(_rotvec(dr[i]), dtv[i]), pose[i])
+    point = gt_point + rng.normal(0, 0.02 / np.sqrt(3), gt_point.shape)
+    return dict(pose=pose, point=point, pose_fixed=np.zeros(n_pose, np.uint8), point_fixed=None, obs_pose=obs_pose, obs_point=obs_point,
+                obs_uv=uv, obs_info=info, huber_delta=HUBER_DELTA, edge_i=np.arange(1, n_pose, dtype=np.int32),
+                edge_j=np.arange(0, n_pose - 1, dtype=np.int32), edge_meas=edge_meas, edge_info=np.tile(W.reshape(1, 36), (n_pose - 1, 1)),
+                gt_pose=gt_pose, gt_point=gt_point)
+
+
+def residuals_fast(prob, pose, point):
+    """Vectorised residuals(): the same numbers."""
+    Rs = np.stack([_R_from_quat(p[:4]) for p in pose])
+    p = np.einsum("oij,oj->oi", Rs[prob["obs_pose"]], point[prob["obs_point"]]) + pose[prob["obs_pose"], 4:]
+    return prob["obs_uv"] - p[:, :2] / p[:, 2:3]

@@ -56,6 +56,39 @@ def test_product_never_imports_the_oracle():
                 assert "mso.h" not in txt and "import mso" not in txt and "libmso" not in txt, os.path.join(dirpath, fn)
 
 
+def test_bench_and_tools_touch_the_oracle_only_as_the_cpu_baseline():
+    """bench.py may import oracle/ in its cpu_baseline leg only (its inputs come from the neutral tools/synth.py and tests/ba_synth.py);
+    the input generators themselves never do."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("import mso") == 1 and "def _oracle():" in src
+    body = src[src.index("def _oracle():"):]
+    assert body.index("import mso") < body.index("def host_cores")                   # the one import sits inside _oracle()
+    callers = [ln for ln in src.splitlines() if "_oracle()" in ln and "def " not in ln]
+    assert callers and all("mso = _oracle()" in ln for ln in callers)
+    for fn in ("cpu_baseline_frames", "cpu_baseline_ba"):
+        seg = src[src.index("def %s(" % fn):]
+        assert "_oracle()" in seg[:seg.index("\ndef ", 5)]
+    assert len(callers) == 2
+    for rel in ("tools/synth.py", "tests/ba_synth.py"):
+        txt = open(os.path.join(ROOT, rel)).read()
+        assert "import mso" not in txt and "libmso" not in txt
+
+
+def test_synthetic_frames_of_the_bench_equal_the_oracles_generator(oracle):
+    """tools/synth.py (numpy, used by bench.py and the GPU tests) and oracle/frontend.c hold the same integer generator."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    for (w, h, seed, sx, sy) in [(640, 480, 1000, 0, 0), (1280, 720, 1003, 14, 7), (331, 257, 5, 2, 1), (200, 120, 77, 30, 40)]:
+        assert np.array_equal(synth.synth_frame(w, h, seed, sx, sy), oracle.synth_frame(w, h, seed, sx, sy))
+    seq = synth.synth_sequences(24, 320, 200, 50, n_seq=3)
+    for i in (0, 7, 8, 23):
+        assert np.array_equal(seq[i], oracle.synth_frame(320, 200, 50 + i // 8, 2 * (i % 8), i % 8))
+    sparse = synth.synth_frame(640, 480, 1000, sparse=True)
+    dense = synth.synth_frame(640, 480, 1000)
+    assert (oracle.fast_score_map(sparse, 20) > 20).mean() < 0.4 * (oracle.fast_score_map(dense, 20) > 20).mean()
+
+
 def test_angle_check_host_function(oracle):
     """A1 (match_angle_checker.h:60-134) is host arithmetic in the product too: compare with the oracle on the CPU."""
     import mi355slam

@@ -184,6 +184,70 @@ def test_team_barriers_hold_beside_a_saturating_front_end_batch(oracle):
     ba.close(); ca.close(); cb.close()
 
 
+def test_two_contexts_solve_with_teams_at_the_same_time(oracle):
+    """SURVEY 8(b) threading: poseBundleAdjust on the front-end thread beside localBundleAdjust on the back-end thread
+    (mapper.cpp:379-390 vs :268-269) = two handles on two contexts, both with teams whose grids together exceed the chip
+    (2 x 4 x 40 workgroups of one per CU > 256).  Team launches of a process are chained per device, so neither may give up."""
+    import threading
+    import mi355slam
+    ca, cb = mi355slam.Context(0), mi355slam.Context(0)
+    probs = [ba_synth.make_problem(30, 600, 8, seed=300 + i) for i in range(4)]
+    want = [oracle.ba_solve(p, 8, False) for p in probs]
+    bas = [mi355slam.BundleAdjuster(c, probs, max_iters=8) for c in (ca, cb)]
+    for b in bas: b.set_team(40)
+    errs = []
+
+    def run(b, c):
+        try:
+            for _ in range(6):
+                b.solve()
+            c.sync()
+        except Exception as e:                                      # noqa: BLE001 -- reported below
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(b, c)) for b, c in zip(bas, (ca, cb))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for b in bas:
+        for i in range(4):
+            _check(probs[i], b.download(i), want[i])
+        assert b.team_fallbacks() == 0
+        b.close()
+    ca.close(); cb.close()
+
+
+def test_team_barrier_give_up_falls_back_to_one_workgroup(oracle, ctx):
+    """A team barrier that gives up (test hook: every barrier of the launch falls through at once, so the team's result is
+    garbage) must not reach the caller: ms_ba_download repeats the solve with one workgroup per problem and returns that."""
+    import mi355slam
+    probs = [ba_synth.make_problem(20, 400, 6, seed=210 + i) for i in range(2)]
+    ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=8)
+    ba.set_team(8); ba.debug_fail_team_barriers(True); ba.solve()
+    for i in range(2):
+        _check(probs[i], ba.download(i), oracle.ba_solve(probs[i], 8, False))
+    assert ba.team_fallbacks() == 1
+    ba.debug_fail_team_barriers(False); ba.solve()                  # the next launch uses the team again
+    _check(probs[0], ba.download(0), oracle.ba_solve(probs[0], 8, False))
+    assert ba.team_fallbacks() == 1
+    ba.close()
+
+
+def test_failed_solve_leaves_the_callers_arrays_untouched(ctx):
+    """ms_ba_download reads the status first: MS_ERR_NUMERIC must not overwrite pose / point (the host mirrors pass the window's
+    own arrays as outputs).  A point observed once from one pose with zero damping room: NaN measurement -> non-finite state."""
+    import ctypes as C
+    import mi355slam
+    p = ba_synth.make_problem(4, 30, 3, seed=5)
+    p["obs_uv"] = p["obs_uv"].copy(); p["obs_uv"][0, 0] = np.nan
+    ba = mi355slam.BundleAdjuster(ctx, [p], max_iters=3)
+    ba.solve()
+    pose, point = np.full((4, 7), 7.5), np.full((30, 3), -2.5)
+    rc = mi355slam.lib().ms_ba_download(ba._h, 0, pose.ctypes.data_as(C.c_void_p), point.ctypes.data_as(C.c_void_p), None, None)
+    assert rc == -5                                                  # MS_ERR_NUMERIC, also without a result struct
+    assert (pose == 7.5).all() and (point == -2.5).all()
+    ba.close()
+
+
 def test_envelope_with_loop_closure_and_scattered_covisibility(oracle, ctx):
     """The Cholesky skips what lies outside the envelope of the reduced camera matrix; a loop-closure edge between far keyframes,
     points seen by scattered keyframes and fixed poses in the middle must all widen / shift it correctly (batch and team)."""

@@ -95,6 +95,27 @@ def test_random_noise_saturates_quota(oracle, ctx):
     _assert_same_keypoints(got[0], want[0])
 
 
+def test_quotas_that_sum_past_max_kpts(oracle, ctx):
+    """The per-level quotas are rounded one by one (static_settings.cpp:52): 15 levels / 160 keypoints add up to 161.  The reference
+    keeps per-level vectors, so a saturated frame returns all 161; here that needs the per-frame slot stride to be the quota sum
+    (frame f's last level must not land in frame f+1's first slots)."""
+    import mi355slam
+    q = mi355slam.level_quotas(15, 1.2, 160)
+    assert int(q.sum()) == 161
+    rng = np.random.default_rng(11)
+    imgs = rng.integers(0, 256, (3, 600, 720), dtype=np.uint8)
+    ex, got, want = _extract_both(oracle, ctx, imgs, levels=15, max_kpts=160)
+    assert ex.capacity == 161
+    for f in range(3):
+        assert len(want[f]["x"]) == 161
+        _assert_same_keypoints(got[f], want[f])
+    _, got, want = _extract_both(oracle, ctx, imgs[:2], levels=8, max_kpts=7, max_tracks=3, tracks=[[(100.5, 80.25)], [(300.0, 200.0), (50.0, 60.0)]],
+                                 track_ids=[[7], [8, 9]])
+    for f in range(2):
+        assert len(want[f]["x"]) == 8 + 1 + f
+        _assert_same_keypoints(got[f], want[f])
+
+
 def test_odd_sizes_and_thresholds(oracle, ctx):
     for (w, h, thr, levels, sf) in [(331, 257, 10, 5, 1.2), (200, 120, 35, 3, 1.5), (97, 83, 20, 2, 1.1), (400, 300, 20, 2, 2.5), (250, 250, 15, 3, 2.0)]:
         img = oracle.synth_frame(w, h, 5 + w)

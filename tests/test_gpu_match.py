@@ -254,10 +254,10 @@ def test_matrix_core_search_equals_popcount_search(ctx):
             q = rng.integers(0, 2**32, (nq, 8), dtype=np.uint64).astype(np.uint32)
             t = rng.integers(0, 2**32, (nt, 8), dtype=np.uint64).astype(np.uint32)
             t[: nq // 2] = q[: nq // 2] ^ np.uint32(1 << 7)              # near copies: small distances and ties
-            assert L.ms_hamming_set_path(0) == 0
+            assert L.ms_hamming_set_path(ctx._h, 0) == 0
             a = mi355slam.hamming_best2(ctx, q, t)
-            assert L.ms_hamming_set_path(1) == 0
+            assert L.ms_hamming_set_path(ctx._h, 1) == 0
             b = mi355slam.hamming_best2(ctx, q, t)
             for x, y in zip(a, b): assert np.array_equal(x, y)
     finally:
-        L.ms_hamming_set_path(0)
+        L.ms_hamming_set_path(ctx._h, 0)
