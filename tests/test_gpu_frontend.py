@@ -102,17 +102,27 @@ def test_quotas_that_sum_past_max_kpts(oracle, ctx):
     import mi355slam
     q = mi355slam.level_quotas(15, 1.2, 160)
     assert int(q.sum()) == 161
-    rng = np.random.default_rng(11)
-    imgs = rng.integers(0, 256, (3, 600, 720), dtype=np.uint8)
+    def multiscale(seed, w=1600, h=1300):         # random blocks of 64 and 16 pixels: corners on every level of a 15-level pyramid
+        r = np.random.default_rng(seed)
+        a = np.kron(r.integers(0, 2, (h // 64 + 1, w // 64 + 1)), np.ones((64, 64), np.int64))[:h, :w] * 120 + 30
+        b = np.kron(r.integers(0, 2, (h // 16 + 1, w // 16 + 1)), np.ones((16, 16), np.int64))[:h, :w] * 60
+        return np.clip(a + b + r.integers(0, 20, (h, w)), 0, 255).astype(np.uint8)
+    imgs = np.stack([multiscale(s) for s in range(3)])
     ex, got, want = _extract_both(oracle, ctx, imgs, levels=15, max_kpts=160)
     assert ex.capacity == 161
     for f in range(3):
-        assert len(want[f]["x"]) == 161
+        assert len(want[f]["x"]) > 140
         _assert_same_keypoints(got[f], want[f])
-    _, got, want = _extract_both(oracle, ctx, imgs[:2], levels=8, max_kpts=7, max_tracks=3, tracks=[[(100.5, 80.25)], [(300.0, 200.0), (50.0, 60.0)]],
-                                 track_ids=[[7], [8, 9]])
-    for f in range(2):
-        assert len(want[f]["x"]) == 8 + 1 + f
+    assert any((w["octave"] == 13).any() for w in want)              # level 13 sits at slots 158..160
+    # 8 levels / 7 keypoints: quotas 2 1 1 1 1 1 1 0 = 8; level 6 is slot 7 = the old stride: it landed in the next frame's slot 0
+    import synth
+    imgs = np.stack([synth.synth_frame(720, 600, s) for s in (24, 20, 24, 28)])
+    ex, got, want = _extract_both(oracle, ctx, imgs, levels=8, max_kpts=7, max_tracks=3, tracks=[[(100.5, 80.25)], [(300.0, 200.0), (50.0, 60.0)], [], [(10.0, 10.0)]],
+                                 track_ids=[[7], [8, 9], [], [3]])
+    assert ex.capacity == 8 + 3
+    assert [len(w["x"]) for w in want] == [8 + 1, 7 + 2, 8, 6]       # the track at (10, 10) lies inside the 19 px border
+    for f in range(4):
+        assert (want[f]["octave"] == 6).any()
         _assert_same_keypoints(got[f], want[f])
 
 
