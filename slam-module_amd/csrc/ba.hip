@@ -40,6 +40,22 @@ constexpr int kMaxFreePosesTeam = 2048;   // ... and the factorisation is spread
 constexpr int kMaxTeam = 64;         // workgroups that may share one problem
 constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
 
+// One set of passes of the fused Schur phase.  A pass owns the free-pose rows [row0, row1) of S: their envelope part lives in an
+// LDS tile while every point that observes one of these poses adds its block products; points are packed into batches of
+// whole points with at most 64 observations (one per lane), and each batch lists its (observation a, observation b) pairs.
+struct FsSet {
+    int32_t n_pass;
+    const int32_t *row0, *row1;              // [n_pass]
+    const int32_t *batch_start;              // [n_pass + 1] first batch of a pass
+    const int32_t *b_obs_start, *b_run_start;    // [n_batch + 1]: lane slots / pair chunks of a batch
+    const int32_t *pobs;                     // per lane slot: observation, pose vertex, point, free pose index (int4)
+    const int32_t *wave_b;                   // [n_pass][NW + 1] batch range of every wave, balanced by estimated cost
+    const uint16_t *pairs;                   // chunks of 8 pairs (a_lane | b_lane << 8, 0xFFFF = none): the pairs of a chunk fall into the same block (pose a,
+                                             // pose b); a batch's chunks are sorted by block
+    const int32_t *rowoff;                   // [np_free] offset (doubles) of pose row fa inside its pass's tile
+    const int32_t *yoff;                     // [n_pass] offset of the pass's rhs segment (6 doubles per row) = size of its matrix part
+};
+
 struct BaProb {
     int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters;
     int32_t team;                            // workgroups that share this problem (1 = the whole solve in one workgroup)
@@ -73,6 +89,11 @@ struct BaProb {
     uint32_t *bar;
     double *red;
     int32_t *flag;
+    // fused Schur pass (schur_fused): two pass sets -- [0] coarse (as few passes as the LDS tile allows: one workgroup walks them
+    // all), [1] fine (about one pose row per pass: the workgroups of a team take them round-robin); null when the problem uses the
+    // record-based path (a point with more than 64 free observations, or a pose row wider than the LDS tile)
+    FsSet fs[2];
+    const int32_t *fs_cs;                    // [np_free] first scalar column of pose row fa held in the tile (<= 6 * first coupled pose, 16-aligned envelope)
     // results
     double *stats;                           // [16]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -, then cycles per phase:
                                              //       8 eval, 9 linearise, 10 Schur, 11 Cholesky+backsub, 12 points+update, 13 total
@@ -84,6 +105,8 @@ struct BaProb {
 #define MS_LDS __attribute__((address_space(3)))
 typedef double d2_t __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space (HIP's double2 struct is not)
 typedef int i2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- SE3 helpers (g2o / Eigen conventions)
 __device__ __forceinline__ void q_normalize(double *q) {
@@ -394,7 +417,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
                 for (int a = 0; a < 3; ++a) b[a] += -(Jl[a] * e[0] + Jl[3 + a] * e[1]) * wi;
                 H[0] += wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); H[1] += wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); H[2] += wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
                 H[3] += wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); H[4] += wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); H[5] += wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
-                if (P.pidx[pi] >= 0) {
+                if (P.pidx[pi] >= 0 && !P.fs[0].row0) {      // the record-based Schur path keeps Hpl; the fused pass recomputes it
                     double W[18];
 #pragma unroll
                     for (int a = 0; a < 6; ++a)
@@ -645,6 +668,212 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
                     for (int c = 0; c < 6; ++c) Sp[(size_t)(6 * fa + 3 * half + r) * n + 6 * fb + c] -= acc[6 * r + c];
             }
         }
+    }
+    team_sync(P);
+}
+
+// ---------------------------------------------------------------- fused Schur pass (point-major, S accumulated in LDS)
+// S = Hpp + lambda I - sum_l W_l (Hll_l + lambda I)^-1 W_l^T and y = bp - sum_l W_l (Hll_l + lambda I)^-1 bl_l without ever
+// writing the per-observation records to memory.  The record-based path above re-fetches every 144-byte record ~10 times
+// (once per partner observation of its point): 32 MB per damped solve at C4, 7x the algorithmic bytes, which is what bounds a
+// batch of 256 windows.  Here a pass keeps the envelope part of a range of pose rows of S in an LDS tile; every point that
+// observes one of these poses is visited once: a wave takes a batch of whole points (<= 64 observations, one per lane), each
+// lane recomputes its observation's Jacobians and writes Z_a = W_a L^-T (Hll + lambda I = L L^T, 3x3) into the wave's LDS
+// slab, then the lanes take the batch's (a, b) pairs and subtract Z_a Z_b^T (= W_a (Hll + lambda I)^-1 W_b^T) from block
+// (pose a, pose b) of the tile with LDS atomics.  Per damped solve the pass reads the 32 bytes of every observation (once per
+// pass its point touches) instead of 288 bytes per PAIR.  The sums are no longer in a fixed order (LDS atomics), like the SE3-edge sums.
+constexpr int FS_OB = 64;                                        // observations (lanes) per batch
+constexpr int kFsStageDoubles = NW * FS_OB * 18;                 // Z slabs of the 8 waves: 73,728 B
+constexpr int kFsMetaDoubles = NW * FS_OB / 2;                   // free-pose index per lane: 2,048 B
+constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles;     // 9,728 doubles = 76 KB
+
+__device__ __forceinline__ void lds_sub(MS_LDS double *p, double v) {
+    (void)__hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // ds_add_f64
+}
+
+__device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double *lds_, long long *cyc) {
+    const BaProb &P = P_;
+    BA_IDS
+    const int n = P.n6;
+    const FsSet &F = P.fs[T_ > 1 ? 1 : 0];
+    MS_LDS double *stage = (MS_LDS double *)lds_ + (size_t)wave * (FS_OB * 18);
+    MS_LDS int32_t *meta = (MS_LDS int32_t *)((MS_LDS double *)lds_ + kFsStageDoubles) + wave * FS_OB;
+    MS_LDS double *tile = (MS_LDS double *)lds_ + kFsStageDoubles + kFsMetaDoubles;
+    const MS_GLOBAL int32_t *cs = (const MS_GLOBAL int32_t *)P.fs_cs, *rowoff = (const MS_GLOBAL int32_t *)F.rowoff, *env = (const MS_GLOBAL int32_t *)P.env16;
+    const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)F.pobs;
+    const MS_GLOBAL u4_t *chunks = (const MS_GLOBAL u4_t *)F.pairs;
+    const MS_GLOBAL int32_t *b_obs = (const MS_GLOBAL int32_t *)F.b_obs_start, *b_run = (const MS_GLOBAL int32_t *)F.b_run_start;
+    const MS_GLOBAL double *Hpp = (const MS_GLOBAL double *)P.Hpp;
+    MS_GLOBAL double *Sg = (MS_GLOBAL double *)P.S;
+    for (int pass = rank_; pass < F.n_pass; pass += T_) {
+        const int r0 = F.row0[pass], r1 = F.row1[pass], yoff = F.yoff[pass];
+        const long long tp0 = clock64();
+        // tile <- Hpp (the envelope part of the pass's rows) + lambda I, rhs segment <- bp
+        for (int rr = wave; rr < 6 * (r1 - r0); rr += NW) {
+            const int fa = r0 + rr / 6, i = rr - 6 * (rr / 6), row = 6 * fa + i, c0 = cs[fa], len = 6 * fa + 6 - c0;
+            MS_LDS double *trow = tile + rowoff[fa] + i * len;
+            const MS_GLOBAL double *hrow = Hpp + (size_t)row * n + c0;
+            for (int c = lane; c < len; c += 64) trow[c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
+        }
+        for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = P.bp[6 * r0 + i];
+        __syncthreads();
+        const long long tp1 = clock64();
+        cyc[5] += tp1 - tp0;
+        // every wave takes a contiguous range of the pass's batches (balanced by the host): the pass's points are sorted by their set of
+        // poses, so consecutive batches mostly repeat the same blocks and a lane keeps the sum of "its" block in registers from batch
+        // to batch (LDS fp64 atomics retire ~2 lanes per cycle: one flush per block change instead of one per pair makes them affordable).
+        // Index data is read one batch ahead (lane records) resp. before the Jacobians (the lane's first run), so their latency hides.
+        const int b_lo = F.wave_b[pass * (NW + 1) + wave], b_hi = F.wave_b[pass * (NW + 1) + wave + 1];
+        double acc[36];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) acc[q] = 0;
+        int key = -1;                                              // fa << 16 | fb of the block held in acc
+        i4_t rec = {0, 0, 0, -1};
+        int o0 = 0, nobs = 0;
+        if (b_lo < b_hi) { o0 = b_obs[b_lo]; nobs = b_obs[b_lo + 1] - o0; if (lane < nobs) rec = pobs4[o0 + lane]; }
+        for (int b = b_lo; b < b_hi; ++b) {
+            const bool act = lane < nobs;
+            const int o = rec.x, pi = rec.y, l = rec.z, fa = rec.w;
+            double pose[7], X[3], uv[2], H[6], blv[3], info = 0;
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) pose[q] = P.pose[7 * (size_t)pi + q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { X[q] = P.point[3 * (size_t)l + q]; blv[q] = P.bl[3 * (size_t)l + q]; }
+                load6(P.Hll + 6 * (size_t)l, H);
+                uv[0] = P.obs_uv[2 * (size_t)o]; uv[1] = P.obs_uv[2 * (size_t)o + 1]; info = P.obs_info[o];
+            }
+            // behind the gathers: this batch's run table entry and first pair chunk, the next batch's lane records
+            const int run_lo = b_run[b], run_hi = b_run[b + 1];
+            u4_t pk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (run_lo + lane < run_hi) pk = chunks[run_lo + lane];
+            i4_t rec_n = {0, 0, 0, -1};
+            int o0_n = 0, nobs_n = 0;
+            if (b + 1 < b_hi) { o0_n = b_obs[b + 1]; nobs_n = b_obs[b + 2] - o0_n; if (lane < nobs_n) rec_n = pobs4[o0_n + lane]; }
+            if (act) {
+                double e[2], Jp[12], Jl[6];
+                proj_edge<true>(pose, X, uv, e, Jp, Jl);
+                const double chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+                double rho, w;
+                huber(chi2, P.huber, rho, w);
+                const double wi = w * info;
+                // Hll + lambda I = L L^T
+                const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
+                const double l11 = sqrt(a), i11 = 1.0 / l11, l21 = H[1] * i11, l31 = H[2] * i11;
+                const double d2 = d - l21 * l21, l22 = sqrt(d2), i22 = 1.0 / l22, l32 = (H[4] - l31 * l21) * i22;
+                const double d3 = f - l31 * l31 - l32 * l32, l33 = sqrt(d3), i33 = 1.0 / l33;
+                if (!(a > 0) || !(d2 > 0) || !(d3 > 0) || !isfinite(i11 * i22 * i33)) P.flag[0] = 0;
+                const double u0 = blv[0] * i11, u1 = (blv[1] - l21 * u0) * i22, u2 = (blv[2] - l31 * u0 - l32 * u1) * i33;      // L^-1 bl
+                const bool mine = fa >= r0 && fa < r1;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double w0 = wi * (Jp[r] * Jl[0] + Jp[6 + r] * Jl[3]), w1 = wi * (Jp[r] * Jl[1] + Jp[6 + r] * Jl[4]), w2 = wi * (Jp[r] * Jl[2] + Jp[6 + r] * Jl[5]);
+                    const double z0 = w0 * i11, z1 = (w1 - z0 * l21) * i22, z2 = (w2 - z0 * l31 - z1 * l32) * i33;               // row r of W L^-T
+                    stage[lane * 18 + 3 * r] = z0; stage[lane * 18 + 3 * r + 1] = z1; stage[lane * 18 + 3 * r + 2] = z2;
+                    if (mine) lds_sub(tile + yoff + 6 * (fa - r0) + r, z0 * u0 + z1 * u1 + z2 * u2);                            // W (Hll + lambda I)^-1 bl
+                }
+                meta[lane] = fa;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int run = run_lo + lane; run < run_hi; run += 64) {
+                u4_t nx = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (run + 64 < run_hi) nx = chunks[run + 64];
+                {
+                    const unsigned ab = pk.x & 0xFFFFu;
+                    const int k2 = (meta[ab & 255u] << 16) | meta[ab >> 8];
+                    if (k2 != key) {
+                        if (key >= 0) {
+                            const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
+                            MS_LDS double *blk = tile + rowoff[fa2] + 6 * fb2 - c0;
+#pragma unroll
+                            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                                for (int j = 0; j < 6; ++j) { lds_sub(blk + i * len + j, acc[6 * i + j]); acc[6 * i + j] = 0; }
+                        }
+                        key = k2;
+                    }
+                }
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned wd = k < 2 ? pk.x : (k < 4 ? pk.y : (k < 6 ? pk.z : pk.w));
+                    const unsigned ab = (k & 1) ? wd >> 16 : wd & 0xFFFFu;
+                    if (ab == 0xFFFFu) break;
+                    const MS_LDS double *za = stage + (ab & 255u) * 18, *zb = stage + (ab >> 8) * 18;
+                    double A[18], B[18];
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) { A[q] = za[q]; B[q] = zb[q]; }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[6 * i + j] += A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+                }
+                pk = nx;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            rec = rec_n; o0 = o0_n; nobs = nobs_n;
+        }
+        if (key >= 0) {
+            const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
+            MS_LDS double *blk = tile + rowoff[fa2] + 6 * fb2 - c0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) lds_sub(blk + i * len + j, acc[6 * i + j]);
+        }
+        const long long tp2 = clock64();
+        __syncthreads();
+        cyc[6] += clock64() - tp2;
+        // flush: the rows' envelope part to S, zeros between the 16-row block's envelope (where the factorisation starts reading) and it
+        for (int rr = wave; rr < 6 * (r1 - r0); rr += NW) {
+            const int fa = r0 + rr / 6, i = rr - 6 * (rr / 6), row = 6 * fa + i, c0 = cs[fa], len = 6 * fa + 6 - c0, z0 = env[row >> 4] & ~15;
+            const MS_LDS double *trow = tile + rowoff[fa] + i * len;
+            MS_GLOBAL double *srow = Sg + (size_t)row * n;
+            for (int c = z0 + lane; c < c0; c += 64) srow[c] = 0.0;
+            for (int c = lane; c < len; c += 64) srow[c0 + c] = trow[c];
+        }
+        for (int i = tid; i < 6 * (r1 - r0); i += NT) P.y[6 * r0 + i] = tile[yoff + i];
+        __syncthreads();
+    }
+    team_sync(P);
+}
+
+// dl = (Hll + lambda I)^-1 (bl - sum_a W_a^T dp_a) with W_a = w info Jp^T Jl recomputed from the (unchanged) state:
+// W_a^T x = w info (Jl_row0 (Jp_row0 . x) + Jl_row1 (Jp_row1 . x))
+__device__ __noinline__ void point_backsub_fused(const BaProb &P_, double lambda) {
+    const BaProb &P = P_;
+    BA_IDS
+    for (int l = gt; l < P.n_point; l += GT) {
+        double *dq = P.dl + 3 * (size_t)l;
+        if (P.point_fixed && P.point_fixed[l]) { dq[0] = dq[1] = dq[2] = 0; continue; }
+        double r[3] = {P.bl[3 * (size_t)l], P.bl[3 * (size_t)l + 1], P.bl[3 * (size_t)l + 2]};
+        const double X[3] = {P.point[3 * (size_t)l], P.point[3 * (size_t)l + 1], P.point[3 * (size_t)l + 2]};
+        for (int ii = P.pt_start[l]; ii < P.pt_start[l + 1]; ++ii) {
+            const int o = P.pt_obs[ii], pi = P.obs_pose[o], fa = P.pidx[pi];
+            if (fa < 0) continue;
+            double e[2], Jp[12], Jl[6], x[6];
+            proj_edge<true>(P.pose + 7 * (size_t)pi, X, P.obs_uv + 2 * (size_t)o, e, Jp, Jl);
+            const double info = P.obs_info[o], chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+            double rho, w;
+            huber(chi2, P.huber, rho, w);
+            const double wi = w * info;
+            load6(P.dp + 6 * fa, x);
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { s0 += Jp[a] * x[a]; s1 += Jp[6 + a] * x[a]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] -= wi * (Jl[c] * s0 + Jl[3 + c] * s1);
+        }
+        double H[6];
+        load6(P.Hll + 6 * (size_t)l, H);
+        const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e2 = H[4], f = H[5] + lambda;
+        const double A = d * f - e2 * e2, B = c * e2 - b * f, C = b * e2 - c * d;
+        const double id = 1.0 / (a * A + b * B + c * C);
+        const double h0 = A * id, h1 = B * id, h2 = C * id, h3 = (a * f - c * c) * id, h4 = (b * c - a * e2) * id, h5 = (a * d - b * b) * id;
+        dq[0] = h0 * r[0] + h1 * r[1] + h2 * r[2];
+        dq[1] = h1 * r[0] + h3 * r[1] + h4 * r[2];
+        dq[2] = h2 * r[0] + h4 * r[1] + h5 * r[2];
     }
     team_sync(P);
 }
@@ -933,9 +1162,13 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     const bool lead = P.team == 1 || blockIdx.x % (unsigned)P.team == 0;
     if (lead && threadIdx.x == 0) P.flag[0] = 1;
     team_sync(P);
-    schur_prepare(P, lambda);
-    { const long long t1 = clock64(); cyc[6] += t1 - t0; }
-    schur_segments(P, lds);
+    const bool fused = P.fs[0].row0 != nullptr;
+    if (fused) schur_fused(P, lambda, lds, cyc);
+    else {
+        schur_prepare(P, lambda);
+        { const long long t1 = clock64(); cyc[6] += t1 - t0; }
+        schur_segments(P, lds);
+    }
     { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
     if (P.panG) {                                      // too large for an LDS panel: factor across the team, substitute back in one workgroup
         cholesky_factor_team(P, lds);
@@ -945,7 +1178,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
     const bool ok = P.flag[0] != 0;
     if (!ok) return false;
-    point_backsub(P);
+    if (fused) point_backsub_fused(P, lambda); else point_backsub(P);
     cyc[4] += clock64() - t0;
     return true;
 }
@@ -1075,12 +1308,14 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
+    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, pobs, rowoff, yoff, wave_b; std::vector<uint16_t> pairs; std::vector<double> cost; };
+    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
+                  bool fused = false; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], fs_waveb[2]; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -1178,6 +1413,115 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 }
             }
         }
+        {   // fused Schur pass (schur_fused): pose rows -> passes whose envelope part fits the LDS tile, points -> batches of <= 64 observations
+            const int np = R.np_free;
+            std::vector<int> first(np);
+            for (int f = 0; f < np; ++f) first[f] = f;
+            for (int32_t pr : R.seg_pair) { const int fa = pr >> 16, fb = pr & 0xFFFF; first[fa] = std::min(first[fa], fb); }
+            for (int k = 0; k < Q.n_pose_edge; ++k) {
+                const int fi = R.pidx[Q.edge_i[k]], fj = R.pidx[Q.edge_j[k]];
+                if (fi >= 0 && fj >= 0) first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj));
+            }
+            R.fs_cs.resize(np);
+            bool ok = np > 0;
+            for (int f = 0; f < np; ++f) { R.fs_cs[f] = 6 * first[f]; if (36 * (f - first[f] + 1) + 6 > kFsTileDoubles) ok = false; }
+            // free observations of every free point, in pose order (the order of pt_obs is observation order; pairs need fb <= fa only by value)
+            for (int l = 0; l < Q.n_point && ok; ++l) {
+                if (Q.point_fixed && Q.point_fixed[l]) continue;
+                int kk = 0;
+                for (int ii = R.pt_start[l]; ii < R.pt_start[l + 1]; ++ii) kk += R.pidx[Q.obs_pose[R.pt_obs[ii]]] >= 0;
+                if (kk > FS_OB) ok = false;
+            }
+            R.fused = ok;
+            for (int set = 0; set < 2 && ok; ++set) {
+                FsHost &F = R.fs[set];
+                const int max_rows = set == 0 ? np : (np + 63) / 64;      // fine set: about one pose row per pass, at most 64 passes' worth per row group
+                F.rowoff.assign(np, 0);
+                int r = 0;
+                while (r < np) {                                          // greedy row ranges under the tile budget
+                    int r1 = r, used = 0;
+                    while (r1 < np && r1 - r < max_rows) {
+                        const int need = 36 * (r1 - first[r1] + 1) + 6;
+                        if (used + need > kFsTileDoubles) break;
+                        used += need; ++r1;
+                    }
+                    F.row0.push_back(r); F.row1.push_back(r1);
+                    int off2 = 0;
+                    for (int f = r; f < r1; ++f) { F.rowoff[f] = off2; off2 += 36 * (f - first[f] + 1); }
+                    F.yoff.push_back(off2);
+                    r = r1;
+                }
+                F.batch_start.push_back(0); F.b_obs_start.push_back(0); F.b_run_start.push_back(0);
+                std::vector<int32_t> stamp(Q.n_point, -1);
+                struct Pt { int32_t l; std::vector<int32_t> f, o; };
+                std::vector<Pt> pts;
+                std::vector<std::pair<int32_t, uint16_t>> bp2;           // (block key, pair) of the open batch
+                for (size_t ps = 0; ps < F.row0.size(); ++ps) {
+                    const int r0 = F.row0[ps], r1 = F.row1[ps];
+                    pts.clear();
+                    for (int fa = r0; fa < r1; ++fa)
+                        for (int ii = R.fstart[fa]; ii < R.fstart[fa + 1]; ++ii) {
+                            const int l = Q.obs_point[R.fobs[ii]];
+                            if (stamp[l] == (int32_t)ps || (Q.point_fixed && Q.point_fixed[l])) continue;
+                            stamp[l] = (int32_t)ps;
+                            Pt q; q.l = l;      // the point's free observations on poses < r1 (later poses have no pair with a row of this pass)
+                            for (int jj = R.pt_start[l]; jj < R.pt_start[l + 1]; ++jj) {
+                                const int o = R.pt_obs[jj], f = R.pidx[Q.obs_pose[o]];
+                                if (f >= 0 && f < r1) { q.f.push_back(f); q.o.push_back(o); }
+                            }
+                            pts.push_back(std::move(q));
+                        }
+                    // points with the same set of poses next to each other: their pairs fall into the same blocks
+                    std::stable_sort(pts.begin(), pts.end(), [](const Pt &x, const Pt &y) { return x.f < y.f; });
+                    int in_batch = 0;
+                    auto close_batch = [&]() {
+                        if (in_batch == 0) return;
+                        std::stable_sort(bp2.begin(), bp2.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                        // chunks of <= 8 pairs of one block; when the batch has few pairs the chunks get shorter so that more lanes share them
+                        const size_t cap = std::min<size_t>(8, std::max<size_t>(1, (bp2.size() + 63) / 64));
+                        auto pad = [&]() { while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF); };
+                        size_t in_chunk = 0;
+                        for (size_t i = 0; i < bp2.size(); ++i) {
+                            if (i && (bp2[i].first != bp2[i - 1].first || in_chunk == cap)) { pad(); in_chunk = 0; }
+                            F.pairs.push_back(bp2[i].second); ++in_chunk;
+                        }
+                        pad();
+                        F.cost.push_back(2000.0 + 20.0 * in_batch + 30.0 * (double)bp2.size());      // rough cycles: Jacobians + pair products (64 lanes share them)
+                        bp2.clear();
+                        F.b_obs_start.push_back((int32_t)(F.pobs.size() / 4)); F.b_run_start.push_back((int32_t)(F.pairs.size() / 8));
+                        in_batch = 0;
+                    };
+                    for (const Pt &q : pts) {
+                        const int kk = (int)q.o.size();
+                        if (in_batch + kk > FS_OB) close_batch();
+                        const int base = in_batch;
+                        for (int a = 0; a < kk; ++a) { F.pobs.push_back(q.o[a]); F.pobs.push_back(Q.obs_pose[q.o[a]]); F.pobs.push_back(q.l); F.pobs.push_back(q.f[a]); }
+                        for (int a = 0; a < kk; ++a) {
+                            if (q.f[a] < r0) continue;
+                            for (int b2 = 0; b2 < kk; ++b2)
+                                if (q.f[b2] <= q.f[a]) bp2.emplace_back((q.f[a] << 16) | q.f[b2], (uint16_t)((base + a) | ((base + b2) << 8)));
+                        }
+                        in_batch += kk;
+                    }
+                    close_batch();
+                    F.batch_start.push_back((int32_t)F.b_obs_start.size() - 1);
+                    {   // the pass's batches in NW contiguous ranges of about equal cost
+                        const int b0 = F.batch_start[ps], b1 = F.batch_start[ps + 1];
+                        double tot = 0;
+                        for (int b2 = b0; b2 < b1; ++b2) tot += F.cost[b2];
+                        double run_c = 0; int w = 1;
+                        F.wave_b.push_back(b0);
+                        for (int b2 = b0; b2 < b1 && w < NW; ++b2) {
+                            run_c += F.cost[b2];
+                            while (w < NW && run_c >= tot * w / NW) { F.wave_b.push_back(b2 + 1); ++w; }
+                        }
+                        while (w++ < NW) F.wave_b.push_back(b1);
+                        F.wave_b.push_back(b1);
+                    }
+                }
+                F.b_obs_start.push_back(F.b_obs_start.back());                   // the prefetch of "the next batch" may look one entry further
+            }
+        }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
         // inputs first, contiguous: they go up in ONE host->device copy per problem
@@ -1191,12 +1535,19 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
         O.env16 = bump(4 * R.env16.size());
         O.act_start = bump(4 * R.act_start.size()); O.act_blk = bump(4 * R.act_blk.size());
+        O.fs_cs = bump(4 * R.fs_cs.size());
+        for (int set = 0; set < 2; ++set) {
+            const FsHost &F = R.fs[set];
+            O.fs_row0[set] = bump(4 * F.row0.size()); O.fs_row1[set] = bump(4 * F.row1.size()); O.fs_batch[set] = bump(4 * F.batch_start.size());
+            O.fs_bobs[set] = bump(4 * F.b_obs_start.size()); O.fs_brun[set] = bump(4 * F.b_run_start.size()); O.fs_pobs[set] = bump(4 * F.pobs.size());
+            O.fs_pairs[set] = bump(2 * F.pairs.size() + 16); O.fs_rowoff[set] = bump(4 * F.rowoff.size()); O.fs_yoff[set] = bump(4 * F.yoff.size()); O.fs_waveb[set] = bump(4 * F.wave_b.size());
+        }
         in_hi[p] = total;
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
-        O.Hll = bump(6 * Q.n_point * D); O.bl = bump(3 * Q.n_point * D); O.Hinv = bump(6 * Q.n_point * D); O.Hpl = bump(18 * ((size_t)Q.n_obs + 1) * D);
+        O.Hll = bump(6 * Q.n_point * D); O.bl = bump(3 * Q.n_point * D); O.Hinv = bump(6 * Q.n_point * D); O.Hpl = bump(R.fused ? 8 : 18 * ((size_t)Q.n_obs + 1) * D);
         O.dl = bump(3 * Q.n_point * D); O.chi2 = bump(Q.n_obs * D); O.stats = bump(16 * D);
-        O.Y = bump(18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
+        O.Y = bump(R.fused ? 8 : 18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
         O.dinv = bump((n6 + 16) * D);
         O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
         O.bar = bump(256); O.red = bump(2 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
@@ -1223,6 +1574,14 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.chunk_items, R.chunk_items.data(), 4 * R.chunk_items.size()); up(O.seg_start, R.seg_start.data(), 4 * R.seg_start.size()); up(O.seg_pair, R.seg_pair.data(), 4 * R.seg_pair.size());
         up(O.env16, R.env16.data(), 4 * R.env16.size());
         up(O.act_start, R.act_start.data(), 4 * R.act_start.size()); up(O.act_blk, R.act_blk.data(), 4 * R.act_blk.size());
+        up(O.fs_cs, R.fs_cs.data(), 4 * R.fs_cs.size());
+        for (int set = 0; set < 2; ++set) {
+            const FsHost &F = R.fs[set];
+            up(O.fs_row0[set], F.row0.data(), 4 * F.row0.size()); up(O.fs_row1[set], F.row1.data(), 4 * F.row1.size()); up(O.fs_batch[set], F.batch_start.data(), 4 * F.batch_start.size());
+            up(O.fs_bobs[set], F.b_obs_start.data(), 4 * F.b_obs_start.size()); up(O.fs_brun[set], F.b_run_start.data(), 4 * F.b_run_start.size());
+            up(O.fs_pobs[set], F.pobs.data(), 4 * F.pobs.size()); up(O.fs_pairs[set], F.pairs.data(), 2 * F.pairs.size());
+            up(O.fs_rowoff[set], F.rowoff.data(), 4 * F.rowoff.size()); up(O.fs_yoff[set], F.yoff.data(), 4 * F.yoff.size()); up(O.fs_waveb[set], F.wave_b.data(), 4 * F.wave_b.size());
+        }
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
         if (hipMemcpyAsync(B->d_arena + in_lo[p], stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
@@ -1243,6 +1602,15 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.n_chunks = R.n_chunks; H.n_seg = R.n_seg; H.chunk_items = PTR(int32_t, chunk_items); H.seg_start = PTR(int32_t, seg_start); H.seg_pair = PTR(int32_t, seg_pair);
         H.env16 = PTR(int32_t, env16);
         H.act_start = PTR(int32_t, act_start); H.act_blk = PTR(int32_t, act_blk);
+        H.fs_cs = PTR(int32_t, fs_cs);
+        for (int set = 0; set < 2; ++set) {
+            FsSet &F = H.fs[set];
+            if (!R.fused) { std::memset(&F, 0, sizeof(F)); continue; }
+            F.n_pass = (int32_t)R.fs[set].row0.size();
+            F.row0 = PTR(int32_t, fs_row0[set]); F.row1 = PTR(int32_t, fs_row1[set]); F.batch_start = PTR(int32_t, fs_batch[set]);
+            F.b_obs_start = PTR(int32_t, fs_bobs[set]); F.b_run_start = PTR(int32_t, fs_brun[set]); F.pobs = PTR(int32_t, fs_pobs[set]);
+            F.pairs = PTR(uint16_t, fs_pairs[set]); F.rowoff = PTR(int32_t, fs_rowoff[set]); F.yoff = PTR(int32_t, fs_yoff[set]); F.wave_b = PTR(int32_t, fs_waveb[set]);
+        }
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
         H.dinv = PTR(double, dinv);
         H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
