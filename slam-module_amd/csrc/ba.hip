@@ -93,6 +93,11 @@ struct BaProb {
     // all), [1] fine (about one pose row per pass: the workgroups of a team take them round-robin); null when the problem uses the
     // record-based path (a point with more than 64 free observations, or a pose row wider than the LDS tile)
     FsSet fs[2];
+    // windowed Cholesky (cholesky_window): the active front of the factorisation as W x W tiles of 16 x 16 in LDS; 0 = front too wide
+    int32_t cw_W;
+    const int32_t *cw_slot;                  // [nblk] LDS slot (row and column index in the tile grid) of 16-row block b while it is active
+    const int32_t *cw_act_start, *cw_act;    // per panel p: the other active blocks (block | slot << 16), ascending
+    const int32_t *cw_load_start, *cw_load;  // per panel p: tiles that enter the window (bi | si << 16, bj | sj << 16)
     const int32_t *fs_cs;                    // [np_free] first scalar column of pose row fa held in the tile (<= 6 * first coupled pose, 16-aligned envelope)
     // results
     double *stats;                           // [16]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -, then cycles per phase:
@@ -958,29 +963,32 @@ __device__ __forceinline__ void chol_panel_update(const BaProb &P, int c0, int n
 
 // Factor the nb x nb diagonal block held as pan[row * NB + col] in the registers of one wave; returns false when a pivot is not
 // positive.  On return lane i holds row i of L in r[], di = 1 / L[i][i].
+template <int LD = NB>
 __device__ __forceinline__ bool chol_factor_diag(const double *pan, int nb, int lane, double (&r)[NB], double &di) {
     // factor the nb x nb diagonal block in REGISTERS: lane i holds row i (16 doubles), the pivot and the column
     // entries L[c][j] are wave-uniform v_readlane broadcasts.  Same operations in the same order as the textbook
     // loop over LDS it replaces (26.7 k -> ~4 k cycles per block); a short last block is padded with identity.
 #pragma unroll
-    for (int c = 0; c < NB; ++c) r[c] = (lane < nb && c < nb) ? pan[lane * NB + c] : (lane == c ? 1.0 : 0.0);
+    for (int c = 0; c < NB; ++c) r[c] = (lane < nb && c < nb) ? pan[lane * LD + c] : (lane == c ? 1.0 : 0.0);
     bool ok = true;
+    di = 1.0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const double d = readlane_d(r[j], j);
         if (j < nb && (!(d > 0) || !isfinite(d))) ok = false;
-        const double sd = sqrt(d > 0 ? d : 1.0);
-        r[j] = lane == j ? sd : (lane > j ? r[j] / sd : r[j]);
+        // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision to ~1 ulp; sqrt + division were 2/3 of this chain)
+        const double dd = d > 0 ? d : 1.0;
+        double y = __builtin_amdgcn_rsq(dd);
+        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
+        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
+        r[j] = lane == j ? dd * y : (lane > j ? r[j] * y : r[j]);
+        if (lane == j) di = y;
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) {
             const double lcj = readlane_d(r[j], c);
             if (lane >= c) r[c] -= r[j] * lcj;
         }
     }
-    di = 1.0;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) if (lane == c) di = r[c];
-    di = 1.0 / di;
     return ok;
 }
 
@@ -1072,6 +1080,163 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
         __syncthreads();
     }
     chol_back_substitute(P, tvec + NB, tid, lane, wave);
+}
+
+// ---------------------------------------------------------------- windowed right-looking Cholesky (the whole front in LDS)
+// The left-looking factorisation above feeds every panel update from L2 (operands straight from memory) and spends ~36 k cycles per
+// 16-column panel, most of it waiting.  A sliding window's reduced camera matrix is banded (C4: half-bandwidth 60 of 300), so the part
+// of the matrix a right-looking factorisation is working on -- the 16-row blocks whose envelope has reached the current panel and
+// that are not factored yet -- is a handful of blocks: they are kept as W x W tiles of 16 x 16 doubles in LDS (slots assigned by the
+// host, a block keeps its slot while it is active), every tile is read from S once when its later block enters, updated in LDS
+// (v_mfma_f64_16x16x4_f64, operands from LDS), and written once when its column is factored.  The rhs is forward-substituted along.
+constexpr int CT_LD = 18;                 // doubles per tile row (16 + 2: the 32-byte operand reads of 16 rows fall into different banks)
+constexpr int CT = 16 * CT_LD;            // doubles per tile
+__device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
+    const BaProb &P = P_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6, W = P.cw_W, nblk = (n + 15) / 16;
+    MS_LDS double *tiles = (MS_LDS double *)lds_;
+    MS_LDS double *z = tiles + W * W * CT;                    // [n] rhs, becomes L^-1 y
+    MS_LDS double *tvec = z + ((n + 15) & ~15);               // [16] reciprocal pivots of the current panel
+    const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S;
+    MS_GLOBAL double *Sw = (MS_GLOBAL double *)P.S;
+    const MS_GLOBAL int32_t *slot = (const MS_GLOBAL int32_t *)P.cw_slot, *act_start = (const MS_GLOBAL int32_t *)P.cw_act_start, *act = (const MS_GLOBAL int32_t *)P.cw_act,
+                            *load_start = (const MS_GLOBAL int32_t *)P.cw_load_start, *loads = (const MS_GLOBAL int32_t *)P.cw_load;
+    for (int i = tid; i < n; i += NT) z[i] = P.y[i];
+    auto fetch_tiles = [&](int pnl) {                         // tiles entering the window at panel pnl: S -> LDS, one tile per wave and trip (waves 1..7; wave 0 factors)
+        for (int e = load_start[pnl] + wave - 1; e < load_start[pnl + 1]; e += NW - 1) {
+            const int ea = loads[2 * e], eb = loads[2 * e + 1], bi = ea & 0xFFFF, si = ea >> 16, bj = eb & 0xFFFF, sj = eb >> 16;
+            MS_LDS double *t = tiles + (si * W + sj) * CT;
+            const int c = lane & 15, gc = 16 * bj + c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = (lane >> 4) + 4 * k, gr = 16 * bi + r;
+                t[r * CT_LD + c] = (gr < n && gc < n) ? Sg[(size_t)gr * n + gc] : 0.0;
+            }
+        }
+    };
+    // factor the diagonal tile of panel pnl (wave 0): L11 back into the tile, reciprocal pivots to tvec / dinv
+    auto factor_diag = [&](int pnl) {
+        const int c0 = 16 * pnl, nb = min(16, n - c0), sp = slot[pnl];
+        MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
+        double r[NB], di;
+        const bool ok = chol_factor_diag<CT_LD>((const double *)Lpp, nb, lane, r, di);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) if (lane < nb && c <= lane) Lpp[lane * CT_LD + c] = r[c];
+        if (lane < NB) tvec[lane] = di;
+        if (lane < nb) P.dinv[c0 + lane] = di;
+        if (!ok && lane == 0) P.flag[0] = 0;
+    };
+    auto update_pair = [&](int si, int sj, int sp) {         // tile(si, sj) -= tile(si, sp) tile(sj, sp)^T
+        const int row = lane & 15, qd = lane >> 4;
+        const MS_LDS d2_t *A = reinterpret_cast<const MS_LDS d2_t *>(tiles + (si * W + sp) * CT + row * CT_LD + 4 * qd);
+        const MS_LDS d2_t *B = reinterpret_cast<const MS_LDS d2_t *>(tiles + (sj * W + sp) * CT + row * CT_LD + 4 * qd);
+        const d2_t a0v = A[0], a1v = A[1], b0v = B[0], b1v = B[1];
+        d4_t acc = {0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v.x, b0v.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v.y, b0v.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v.x, b1v.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v.y, b1v.y, acc, 0, 0, 0);
+        MS_LDS double *C = tiles + (si * W + sj) * CT;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) C[(qd + 4 * reg) * CT_LD + row] -= acc[reg];
+    };
+    if (nblk > 0 && wave > 0) fetch_tiles(0);
+    if (nblk > 0 && wave == 0) {                              // panel 0's diagonal tile is wave 0's, like every later one
+        MS_LDS double *t = tiles + (slot[0] * W + slot[0]) * CT;
+        const int c = lane & 15;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int r = (lane >> 4) + 4 * k; t[r * CT_LD + c] = (r < n && c < n) ? Sg[(size_t)r * n + c] : 0.0; }
+    }
+    __syncthreads();
+    if (wave == 0 && nblk > 0) factor_diag(0);
+    __syncthreads();
+    for (int p = 0; p < nblk; ++p) {
+        const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
+        MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
+        // A. rows below: x L11^T = a (a thread per row), and the panel's part of the rhs
+        const int a0 = act_start[p], m = act_start[p + 1] - a0;
+        for (int idx = tid; idx < 16 * m; idx += NT) {
+            const int sb = act[a0 + (idx >> 4)] >> 16;
+            MS_LDS double *row = tiles + (sb * W + sp) * CT + (idx & 15) * CT_LD;
+            double x[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    double sacc = row[j];
+                    for (int k = 0; k < j; ++k) sacc -= x[k] * Lpp[j * CT_LD + k];
+                    x[j] = sacc * tvec[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) if (j < nb) row[j] = x[j];
+        }
+        if (tid == NT - 1) {
+            double x[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {
+                    double sacc = z[c0 + j];
+                    for (int k = 0; k < j; ++k) sacc -= x[k] * Lpp[j * CT_LD + k];
+                    x[j] = sacc * tvec[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) if (j < nb) z[c0 + j] = x[j];
+        }
+        __syncthreads();
+        // B. look-ahead: wave 0 brings the NEXT diagonal tile up to date (its update by this panel, or its first fetch) and factors it at
+        //    once -- the serial pivot chain runs beside the trailing update, the rhs update, the write-back of column p and the fetch of the
+        //    tiles that enter at the next panel, which the other seven waves share
+        const bool next_active = m > 0 && (act[a0] & 0xFFFF) == p + 1;       // block p+1 is in the window already (else it enters at p+1)
+        if (wave == 0) {
+            if (p + 1 < nblk) {
+                const int s1 = slot[p + 1];
+                if (next_active) update_pair(s1, s1, sp);
+                else {
+                    MS_LDS double *t = tiles + (s1 * W + s1) * CT;
+                    const int c = lane & 15, gc = 16 * (p + 1) + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = (lane >> 4) + 4 * k, gr = 16 * (p + 1) + r;
+                        t[r * CT_LD + c] = (gr < n && gc < n) ? Sg[(size_t)gr * n + gc] : 0.0;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                factor_diag(p + 1);
+            }
+        } else {
+            int q = 0;
+            for (int i = 0; i < m; ++i) {
+                const int si = act[a0 + i] >> 16;
+                for (int j = 0; j <= i; ++j) {
+                    if (next_active && i == 0) continue;                      // (p+1, p+1): wave 0's
+                    if ((q++ % (NW - 1)) + 1 != wave) continue;
+                    update_pair(si, act[a0 + j] >> 16, sp);
+                }
+            }
+            const int t7 = tid - 64, N7 = NT - 64;
+            for (int idx = t7; idx < 16 * m; idx += N7) {
+                const int ea = act[a0 + (idx >> 4)], gr = 16 * (ea & 0xFFFF) + (idx & 15);
+                if (gr >= n) continue;
+                const MS_LDS double *row = tiles + ((ea >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
+                double sacc = z[gr];
+                for (int k = 0; k < nb; ++k) sacc -= row[k] * z[c0 + k];
+                z[gr] = sacc;
+            }
+            for (int idx = t7; idx < 256 * (m + 1); idx += N7) {
+                const int t = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+                const int ea = t == 0 ? (p | (sp << 16)) : act[a0 + t - 1], gr = 16 * (ea & 0xFFFF) + r;
+                if (gr >= n || c >= nb || (t == 0 && c > r)) continue;
+                Sw[(size_t)gr * n + c0 + c] = tiles[((ea >> 16) * W + sp) * CT + r * CT_LD + c];
+            }
+            if (p + 1 < nblk) fetch_tiles(p + 1);             // slots released a panel ago (the host delays the reuse): nothing above reads them
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) P.y[i] = z[i];
+    __syncthreads();
+    chol_back_substitute(P, (double *)z, tid, lane, wave);
 }
 
 // The same factorisation for systems whose panel does not fit the LDS (more than kMaxFreePoses free poses: global bundle
@@ -1170,10 +1335,12 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
         schur_segments(P, lds);
     }
     { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
-    if (P.panG) {                                      // too large for an LDS panel: factor across the team, substitute back in one workgroup
+    if (P.cw_W > 0) {                                  // the active front fits the LDS: right-looking, one workgroup (banded systems of any size)
+        if (lead) cholesky_window(P, lds);
+    } else if (P.panG) {                               // too large for an LDS panel: factor across the team, substitute back in one workgroup
         cholesky_factor_team(P, lds);
         if (lead) chol_back_substitute(P, lds, threadIdx.x, threadIdx.x & 63, threadIdx.x >> 6);
-    } else if (lead) cholesky_solve(P, lds);           // the dense 6 np x 6 np factorisation stays in one workgroup (panel in LDS)
+    } else if (lead) cholesky_solve(P, lds);           // dense front: left-looking, panel in LDS, operands from L2
     team_sync(P);
     { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
     const bool ok = P.flag[0] != 0;
@@ -1206,9 +1373,11 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     long long cyc[7] = {0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
     const double chi2_init = eval_chi2(P, s_red, false, seq);
+    double chi2_carried = chi2_init;
     for (it = 0; it < P.max_iters; ++it) {
         long long tt = clock64();
-        double current = eval_chi2(P, s_red, false, seq), temp = current;
+        // g2o evaluates activeRobustChi2 again here; the state is the one the last accepted (or restored) trial left, so it is the same number
+        double current = chi2_carried, temp = current;
         { const long long t1 = clock64(); cyc[0] += t1 - tt; tt = t1; }
         build_system(P, lds);
         cyc[1] += clock64() - tt;
@@ -1253,7 +1422,7 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
-                ni = 2; current = temp;
+                ni = 2; current = temp; chi2_carried = temp;
             } else {
                 lambda *= ni; ni *= 2;
                 for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose_bk[i];      // pop()
@@ -1309,13 +1478,13 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     MS_HIP(c, hipSetDevice(c->device));
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, pobs, rowoff, yoff, wave_b; std::vector<uint16_t> pairs; std::vector<double> cost; };
-    struct Prep { std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
+    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], fs_waveb[2]; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], fs_waveb[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -1522,6 +1691,47 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 F.b_obs_start.push_back(F.b_obs_start.back());                   // the prefetch of "the next batch" may look one entry further
             }
         }
+        {   // windowed Cholesky (cholesky_window): active 16-row blocks per panel, LDS slots, tiles entering per panel
+            const int np = R.np_free, n6i = 6 * np, nblk = (n6i + 15) / 16;
+            std::vector<int> first(np);
+            for (int f = 0; f < np; ++f) first[f] = R.fs_cs.empty() ? 0 : R.fs_cs[f] / 6;
+            std::vector<int> ent(nblk, 0);
+            for (int b = 0; b < nblk; ++b) {
+                int e = n6i;
+                for (int r = 16 * b; r < std::min(16 * b + 16, n6i); ++r) e = std::min(e, 6 * first[r / 6]);
+                ent[b] = std::min(e / 16, b);
+            }
+            for (int b = nblk - 2; b >= 0; --b) ent[b] = std::min(ent[b], b);      // (a block is active at its own panel at the latest)
+            R.cw_slot.assign(nblk, 0);
+            std::vector<int> free_slots, active;
+            int W = 0;
+            std::vector<std::vector<int>> entering(nblk);
+            for (int b = 0; b < nblk; ++b) entering[ent[b]].push_back(b);
+            R.cw_act_start.push_back(0); R.cw_load_start.push_back(0);
+            for (int pnl = 0; pnl < nblk; ++pnl) {
+                if (pnl > 0) active.erase(std::find(active.begin(), active.end(), pnl - 1));      // block pnl-1 is factored ...
+                if (pnl > 1) free_slots.push_back(R.cw_slot[pnl - 2]);       // ... its slot is reused one panel later: panel pnl's tiles are fetched while pnl-1 is still updating
+                std::sort(free_slots.begin(), free_slots.end(), std::greater<int>());
+                for (int b : entering[pnl]) {
+                    int sl;
+                    if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); } else sl = W++;
+                    R.cw_slot[b] = sl;
+                    active.push_back(b);
+                }
+                std::sort(active.begin(), active.end());
+                for (int bi : active)
+                    for (int bj : active) {
+                        if (bj > bi) break;
+                        if (bi == bj && bi == pnl) continue;                       // the panel's own diagonal tile is fetched by the factoring wave
+                        if (ent[bi] == pnl || ent[bj] == pnl) { R.cw_load.push_back(bi | (R.cw_slot[bi] << 16)); R.cw_load.push_back(bj | (R.cw_slot[bj] << 16)); }
+                    }
+                R.cw_load_start.push_back((int32_t)R.cw_load.size() / 2);
+                for (int b : active) if (b != pnl) R.cw_act.push_back(b | (R.cw_slot[b] << 16));
+                R.cw_act_start.push_back((int32_t)R.cw_act.size());
+            }
+            const size_t need = ((size_t)W * W * CT + (size_t)((n6i + 15) & ~15) + 16 + 16) * sizeof(double);
+            R.cw_W = (R.fused && nblk < 65536 && W >= 1 && W < 256 && need <= kLdsBytes) ? W : 0;
+        }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
         // inputs first, contiguous: they go up in ONE host->device copy per problem
@@ -1536,6 +1746,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.env16 = bump(4 * R.env16.size());
         O.act_start = bump(4 * R.act_start.size()); O.act_blk = bump(4 * R.act_blk.size());
         O.fs_cs = bump(4 * R.fs_cs.size());
+        O.cw_slot = bump(4 * R.cw_slot.size()); O.cw_act_start = bump(4 * R.cw_act_start.size()); O.cw_act = bump(4 * R.cw_act.size());
+        O.cw_load_start = bump(4 * R.cw_load_start.size()); O.cw_load = bump(4 * R.cw_load.size());
         for (int set = 0; set < 2; ++set) {
             const FsHost &F = R.fs[set];
             O.fs_row0[set] = bump(4 * F.row0.size()); O.fs_row1[set] = bump(4 * F.row1.size()); O.fs_batch[set] = bump(4 * F.batch_start.size());
@@ -1575,6 +1787,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.env16, R.env16.data(), 4 * R.env16.size());
         up(O.act_start, R.act_start.data(), 4 * R.act_start.size()); up(O.act_blk, R.act_blk.data(), 4 * R.act_blk.size());
         up(O.fs_cs, R.fs_cs.data(), 4 * R.fs_cs.size());
+        up(O.cw_slot, R.cw_slot.data(), 4 * R.cw_slot.size()); up(O.cw_act_start, R.cw_act_start.data(), 4 * R.cw_act_start.size()); up(O.cw_act, R.cw_act.data(), 4 * R.cw_act.size());
+        up(O.cw_load_start, R.cw_load_start.data(), 4 * R.cw_load_start.size()); up(O.cw_load, R.cw_load.data(), 4 * R.cw_load.size());
         for (int set = 0; set < 2; ++set) {
             const FsHost &F = R.fs[set];
             up(O.fs_row0[set], F.row0.data(), 4 * F.row0.size()); up(O.fs_row1[set], F.row1.data(), 4 * F.row1.size()); up(O.fs_batch[set], F.batch_start.data(), 4 * F.batch_start.size());
@@ -1603,6 +1817,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.env16 = PTR(int32_t, env16);
         H.act_start = PTR(int32_t, act_start); H.act_blk = PTR(int32_t, act_blk);
         H.fs_cs = PTR(int32_t, fs_cs);
+        H.cw_W = R.cw_W; H.cw_slot = PTR(int32_t, cw_slot); H.cw_act_start = PTR(int32_t, cw_act_start); H.cw_act = PTR(int32_t, cw_act);
+        H.cw_load_start = PTR(int32_t, cw_load_start); H.cw_load = PTR(int32_t, cw_load);
         for (int set = 0; set < 2; ++set) {
             FsSet &F = H.fs[set];
             if (!R.fused) { std::memset(&F, 0, sizeof(F)); continue; }
