@@ -696,7 +696,9 @@ __device__ __forceinline__ void lds_sub(MS_LDS double *p, double v) {
     (void)__hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // ds_add_f64
 }
 
+constexpr int FS_RUN = 3;                                        // consecutive batches a wave takes at a time
 __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double *lds_, long long *cyc) {
+    __shared__ int s_fs_next;
     const BaProb &P = P_;
     BA_IDS
     const int n = P.n6;
@@ -721,6 +723,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             for (int c = lane; c < len; c += 64) trow[c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
         }
         for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = P.bp[6 * r0 + i];
+        if (tid == 0) s_fs_next = 0;
         __syncthreads();
         const long long tp1 = clock64();
         cyc[5] += tp1 - tp0;
@@ -728,14 +731,22 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
         // poses, so consecutive batches mostly repeat the same blocks and a lane keeps the sum of "its" block in registers from batch
         // to batch (LDS fp64 atomics retire ~2 lanes per cycle: one flush per block change instead of one per pair makes them affordable).
         // Index data is read one batch ahead (lane records) resp. before the Jacobians (the lane's first run), so their latency hides.
-        const int b_lo = F.wave_b[pass * (NW + 1) + wave], b_hi = F.wave_b[pass * (NW + 1) + wave + 1];
+        // batches are handed out in runs of FS_RUN consecutive ones from a counter in LDS (the cost of a batch depends on how its pairs
+        // fall onto lanes: a static split left the slowest wave 30 % behind)
+        const int pb0 = F.batch_start[pass], pb1 = F.batch_start[pass + 1];
         double acc[36];
 #pragma unroll
         for (int q = 0; q < 36; ++q) acc[q] = 0;
         int key = -1;                                              // fa << 16 | fb of the block held in acc
+        for (;;) {
+        int b_lo = 0;
+        if (lane == 0) b_lo = pb0 + FS_RUN * atomicAdd(&s_fs_next, 1);
+        b_lo = __builtin_amdgcn_readfirstlane(b_lo);
+        if (b_lo >= pb1) break;
+        const int b_hi = min(b_lo + FS_RUN, pb1);
         i4_t rec = {0, 0, 0, -1};
         int o0 = 0, nobs = 0;
-        if (b_lo < b_hi) { o0 = b_obs[b_lo]; nobs = b_obs[b_lo + 1] - o0; if (lane < nobs) rec = pobs4[o0 + lane]; }
+        { o0 = b_obs[b_lo]; nobs = b_obs[b_lo + 1] - o0; if (lane < nobs) rec = pobs4[o0 + lane]; }
         for (int b = b_lo; b < b_hi; ++b) {
             const bool act = lane < nobs;
             const int o = rec.x, pi = rec.y, l = rec.z, fa = rec.w;
@@ -818,6 +829,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             rec = rec_n; o0 = o0_n; nobs = nobs_n;
+        }
         }
         if (key >= 0) {
             const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
