@@ -48,6 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sparse-corner input and the PCIe-inclusive legs")
     ap.add_argument("--only-headline", action="store_true", help="C2+C3 leg only (profiling runs)")
+    ap.add_argument("--only-ba", action="store_true", help="local-BA leg only (profiling runs): prints its object as the line")
     ap.add_argument("--ba-batch", type=int, default=256)
     ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--c5-frames", type=int, default=40, help="frames per sequence in the C5 leg")
@@ -349,6 +350,13 @@ def run_gpu(R, args):
     import synth
     torch = R.torch
     ctx = mi355slam.Context(R.local_rank)
+    if args.only_ba:
+        args.no_cpu_baseline = True
+        res = bench_ba(R, ctx, args)
+        if R.rank == 0:
+            print(json.dumps(res), flush=True)
+        ctx.close()
+        return
     frames_np = synth.synth_sequences(BATCH, W, H, 1000 + N_SEQ * R.rank)
     hl = Headline(R, ctx, frames_np)
 

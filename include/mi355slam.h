@@ -313,8 +313,9 @@ typedef struct {
     int32_t stopped_early;       /* 1 if g2o's Terminate condition ended the run */
     double final_lambda;
     double chi2_initial, chi2_final;   /* activeRobustChi2 before / after */
-    double phase_cycles[8];            /* shader cycles: chi2 eval, linearise, Schur, Cholesky+back-subst, points+update, total,
-                                          Schur prep (Hinv, Y, S init), Schur prep + rhs (cumulative) */
+    double phase_cycles[8];            /* shader cycles of the problem's first workgroup: chi2 eval, linearise, Schur, Cholesky+back-subst,
+                                          points+update, total, then inside the fused Schur pass: tile init, wait for the slowest wave
+                                          (record-based path: Hinv / Y / S init, the same + rhs) */
 } ms_ba_result;
 
 typedef struct ms_ba ms_ba;

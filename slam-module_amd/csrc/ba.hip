@@ -396,6 +396,37 @@ __device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool 
     return team_reduce(P, acc, s_red, false, seq);
 }
 
+// ---------------------------------------------------------------- observation data one and two steps ahead
+// The thread-per-point and wave-per-pose loops walk index chains (list entry -> observation -> pose / point -> values): three dependent
+// memory round trips per observation with nothing to hide them at 2 waves per SIMD.  They keep the indices of the observation two steps
+// ahead and the values of the next one in registers instead (a two-deep software pipeline), so a step waits for arithmetic, not for memory.
+struct PtObs { int o, pi; double pose[7], uv[2], info; };
+__device__ __forceinline__ void ptobs_idx(const BaProb &P, int ii, int end, int &o, int &pi) {
+    o = -1; pi = 0;
+    if (ii < end) { o = P.pt_obs[ii]; pi = P.obs_pose[o]; }
+}
+__device__ __forceinline__ void ptobs_data(const BaProb &P, int o, int pi, PtObs &d) {
+    d.o = o; d.pi = pi;
+    if (o >= 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) d.pose[q] = P.pose[7 * (size_t)pi + q];
+        d.uv[0] = P.obs_uv[2 * (size_t)o]; d.uv[1] = P.obs_uv[2 * (size_t)o + 1]; d.info = P.obs_info[o];
+    }
+}
+struct PoseObs { int o, l; double X[3], uv[2], info; };
+__device__ __forceinline__ void poseobs_idx(const BaProb &P, int ii, int end, int &o, int &l) {
+    o = -1; l = 0;
+    if (ii < end) { o = P.fobs[ii]; l = P.obs_point[o]; }
+}
+__device__ __forceinline__ void poseobs_data(const BaProb &P, int o, int l, PoseObs &d) {
+    d.o = o; d.l = l;
+    if (o >= 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) d.X[q] = P.point[3 * (size_t)l + q];
+        d.uv[0] = P.obs_uv[2 * (size_t)o]; d.uv[1] = P.obs_uv[2 * (size_t)o + 1]; d.info = P.obs_info[o];
+    }
+}
+
 // ---------------------------------------------------------------- linearisation
 __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
@@ -409,11 +440,19 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         const bool lfree = !(P.point_fixed && P.point_fixed[l]);
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const double X[3] = {P.point[3 * (size_t)l], P.point[3 * (size_t)l + 1], P.point[3 * (size_t)l + 2]};
-        for (int ii = P.pt_start[l]; ii < P.pt_start[l + 1]; ++ii) {
-            const int o = P.pt_obs[ii], pi = P.obs_pose[o];
+        const int iend = P.pt_start[l + 1];
+        int ii = P.pt_start[l], o1, pi1;
+        PtObs cur;
+        ptobs_idx(P, ii, iend, o1, pi1); ptobs_data(P, o1, pi1, cur); ptobs_idx(P, ii + 1, iend, o1, pi1);
+        for (; ii < iend; ++ii) {
+            PtObs nxt;
+            ptobs_data(P, o1, pi1, nxt);
+            int o2, pi2;
+            ptobs_idx(P, ii + 2, iend, o2, pi2);
+            const int o = cur.o, pi = cur.pi;
             double e[2], Jp[12], Jl[6];
-            proj_edge<true>(P.pose + 7 * (size_t)pi, X, P.obs_uv + 2 * (size_t)o, e, Jp, Jl);
-            const double info = P.obs_info[o], chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+            proj_edge<true>(cur.pose, X, cur.uv, e, Jp, Jl);
+            const double info = cur.info, chi2 = info * (e[0] * e[0] + e[1] * e[1]);
             double r, w;
             huber(chi2, P.huber, r, w);
             const double wi = w * info;
@@ -431,6 +470,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
                     store18(P.Hpl + 18 * (size_t)o, W);
                 }
             }
+            cur = nxt; o1 = o2; pi1 = pi2;
         }
         store6(P.Hll + 6 * (size_t)l, H);
 #pragma unroll
@@ -447,11 +487,18 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         for (int a = 0; a < 21; ++a) A[a] = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) g[a] = 0;
-        for (int ii = P.fstart[fp] + lane; ii < P.fstart[fp + 1]; ii += 64) {
-            const int o = P.fobs[ii];
+        const int iend = P.fstart[fp + 1];
+        int ii = P.fstart[fp] + lane, o1, l1;
+        PoseObs cur;
+        poseobs_idx(P, ii, iend, o1, l1); poseobs_data(P, o1, l1, cur); poseobs_idx(P, ii + 64, iend, o1, l1);
+        for (; ii < iend; ii += 64) {
+            PoseObs nxt;
+            poseobs_data(P, o1, l1, nxt);
+            int o2, l2;
+            poseobs_idx(P, ii + 128, iend, o2, l2);
             double e[2], Jp[12], Jl[6];
-            proj_edge<true>(pose, P.point + 3 * (size_t)P.obs_point[o], P.obs_uv + 2 * (size_t)o, e, Jp, Jl);
-            const double info = P.obs_info[o], chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+            proj_edge<true>(pose, cur.X, cur.uv, e, Jp, Jl);
+            const double info = cur.info, chi2 = info * (e[0] * e[0] + e[1] * e[1]);
             double r, w;
             huber(chi2, P.huber, r, w);
             const double wi = w * info;
@@ -462,6 +509,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
 #pragma unroll
                 for (int b = a; b < 6; ++b) A[k++] += wi * (Jp[a] * Jp[b] + Jp[6 + a] * Jp[6 + b]);
             }
+            cur = nxt; o1 = o2; l1 = l2;
         }
 #pragma unroll
         for (int a = 0; a < 21; ++a) A[a] = wave_sum_d(A[a]);
@@ -476,12 +524,12 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         }
     }
     team_sync(P);
-    // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior): one WAVE per edge.  Every lane evaluates the edge
-    // (error, both 6x6 Jacobians), the wave parks them and the information matrix in its LDS slab, and lane (a, b) < 36 forms
-    // entry (a, b) of each of the up to four 6x6 blocks Js^T (W Jt) with the same operation order as a scalar loop would;
-    // contributions are added with fp64 atomics (neighbouring edges share a pose block).  One thread per edge ran ~2000
-    // dependent multiply-adds out of scratch memory: 168 k cycles per linearisation, whatever the team size.
-    {
+    // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior).  One workgroup: in rounds of 128, a LANE per edge evaluates it (error, both
+    // 6x6 Jacobians; the edges of a round run side by side instead of one after another) and parks the result in LDS, then the
+    // round's gradient entries (edge, side, a) and block entries (edge, side s, side t, a, b) of Js^T (W Jt) are spread over all threads,
+    // each formed with the operation order of a scalar loop and added with fp64 atomics (neighbouring edges share a pose block).
+    // A wave per edge (every lane computing the same edge) took 190 k cycles per linearisation at 49 edges -- as long as 20 k observations.
+    if (T_ > 1) {     // a team: one WAVE per edge, the team's waves side by side (every lane evaluates the edge; lane (a, b) < 36 forms the block entries)
         MS_LDS double *slab = (MS_LDS double *)lds_ + (size_t)wave * (CH * 36);      // [Ji 36][Jj 36][W 36][We 6]
         for (int k = gw; k < P.n_edge; k += GW) {
             const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
@@ -518,6 +566,55 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        constexpr int EB = 128, ES = 80;                                          // edges per round; doubles per edge: e 6 | Ji 36 | Jj 36 | pad
+        MS_LDS double *eb = (MS_LDS double *)lds_;
+        const int rounds = (P.n_edge + EB - 1) / EB;
+        for (int rd = rank_; rd < rounds; rd += T_) {
+            const int k0 = rd * EB, kn = min(EB, P.n_edge - k0);
+            if (tid < kn) {
+                const int k = k0 + tid, vi = P.edge_i[k], vj = P.edge_j[k];
+                if (P.pidx[vi] >= 0 || P.pidx[vj] >= 0) {
+                    double e[6], Ji[36], Jj[36];
+                    pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+                    MS_LDS double *d = eb + tid * ES;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) d[q] = e[q];
+#pragma unroll
+                    for (int q = 0; q < 36; ++q) { d[6 + q] = Ji[q]; d[42 + q] = Jj[q]; }
+                }
+            }
+            __syncthreads();
+            for (int it = tid; it < kn * 12; it += NT) {                          // bp[fs] += Js^T (-W e)
+                const int ke = it / 12, r = it - 12 * ke, side = r / 6, a2 = r - 6 * side, k = k0 + ke;
+                const int fs = P.pidx[side ? P.edge_j[k] : P.edge_i[k]];
+                if (fs < 0) continue;
+                const MS_LDS double *d = eb + ke * ES, *Js = d + 6 + 36 * side;
+                const double *W = P.edge_info + 36 * (size_t)k;
+                double v = 0;
+                for (int r2 = 0; r2 < 6; ++r2) {
+                    double we = 0;
+                    for (int b2 = 0; b2 < 6; ++b2) we += W[6 * r2 + b2] * d[b2];
+                    v += Js[6 * r2 + a2] * -we;
+                }
+                atomicAdd(&P.bp[6 * fs + a2], v);
+            }
+            for (int it = tid; it < kn * 144; it += NT) {                         // Hpp[fs][ft] += Js^T (W Jt)
+                const int ke = it / 144, r = it - 144 * ke, st = r / 36, en = r - 36 * st, a2 = en / 6, b3 = en - 6 * a2, k = k0 + ke;
+                const int fs = P.pidx[(st >> 1) ? P.edge_j[k] : P.edge_i[k]], ft = P.pidx[(st & 1) ? P.edge_j[k] : P.edge_i[k]];
+                if (fs < 0 || ft < 0) continue;
+                const MS_LDS double *d = eb + ke * ES, *Js = d + 6 + 36 * (st >> 1), *Jt = d + 6 + 36 * (st & 1);
+                const double *W = P.edge_info + 36 * (size_t)k;
+                double v = 0;
+                for (int r2 = 0; r2 < 6; ++r2) {
+                    double m = 0;                                                 // (W Jt)[r2][b3]
+                    for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * Jt[6 * c2 + b3];
+                    v += Js[6 * r2 + a2] * m;
+                }
+                atomicAdd(&P.Hpp[(size_t)(6 * fs + a2) * n6 + 6 * ft + b3], v);
+            }
+            __syncthreads();
         }
     }
     team_sync(P);
@@ -866,21 +963,31 @@ __device__ __noinline__ void point_backsub_fused(const BaProb &P_, double lambda
         if (P.point_fixed && P.point_fixed[l]) { dq[0] = dq[1] = dq[2] = 0; continue; }
         double r[3] = {P.bl[3 * (size_t)l], P.bl[3 * (size_t)l + 1], P.bl[3 * (size_t)l + 2]};
         const double X[3] = {P.point[3 * (size_t)l], P.point[3 * (size_t)l + 1], P.point[3 * (size_t)l + 2]};
-        for (int ii = P.pt_start[l]; ii < P.pt_start[l + 1]; ++ii) {
-            const int o = P.pt_obs[ii], pi = P.obs_pose[o], fa = P.pidx[pi];
-            if (fa < 0) continue;
-            double e[2], Jp[12], Jl[6], x[6];
-            proj_edge<true>(P.pose + 7 * (size_t)pi, X, P.obs_uv + 2 * (size_t)o, e, Jp, Jl);
-            const double info = P.obs_info[o], chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+        const int iend = P.pt_start[l + 1];
+        int ii = P.pt_start[l], o1, pi1;
+        PtObs cur;
+        ptobs_idx(P, ii, iend, o1, pi1); ptobs_data(P, o1, pi1, cur); ptobs_idx(P, ii + 1, iend, o1, pi1);
+        int fa = cur.o >= 0 ? P.pidx[cur.pi] : -1;
+        for (; ii < iend; ++ii) {
+            PtObs nxt;
+            ptobs_data(P, o1, pi1, nxt);
+            const int fa_n = o1 >= 0 ? P.pidx[pi1] : -1;
+            int o2, pi2;
+            ptobs_idx(P, ii + 2, iend, o2, pi2);
+            double x[6] = {0, 0, 0, 0, 0, 0};
+            if (fa >= 0) load6(P.dp + 6 * fa, x);
+            double e[2], Jp[12], Jl[6];
+            proj_edge<true>(cur.pose, X, cur.uv, e, Jp, Jl);
+            const double info = cur.info, chi2 = info * (e[0] * e[0] + e[1] * e[1]);
             double rho, w;
             huber(chi2, P.huber, rho, w);
-            const double wi = w * info;
-            load6(P.dp + 6 * fa, x);
+            const double wi = fa >= 0 ? w * info : 0.0;                  // an observation from a fixed pose moves nothing here
             double s0 = 0, s1 = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) { s0 += Jp[a] * x[a]; s1 += Jp[6 + a] * x[a]; }
 #pragma unroll
             for (int c = 0; c < 3; ++c) r[c] -= wi * (Jl[c] * s0 + Jl[3 + c] * s1);
+            cur = nxt; o1 = o2; pi1 = pi2; fa = fa_n;
         }
         double H[6];
         load6(P.Hll + 6 * (size_t)l, H);

@@ -559,7 +559,7 @@ class BundleAdjuster:
         self.ctx.check(lib().ms_ba_download(self._h, i, _vp(pose), _vp(point), _vp(chi2), C.byref(r)), "ms_ba_download")
         return dict(pose=pose, point=point, chi2=chi2,
                     stats=dict(iters=r.iterations, trials=r.trials, stop=r.stopped_early, lam=r.final_lambda, chi2_init=r.chi2_initial, chi2_final=r.chi2_final,
-                               phase_cycles=dict(zip(("eval", "linearise", "schur", "cholesky", "points_update", "total", "schur_prep", "schur_prep_rhs"), list(r.phase_cycles)))))
+                               phase_cycles=dict(zip(("eval", "linearise", "schur", "cholesky", "points_update", "total", "schur_init", "schur_wait"), list(r.phase_cycles)))))
 
     def close(self):
         if self._h and self.ctx._h:

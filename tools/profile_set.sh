@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats -d "$O/stats" -o p --output-format csv -- pytho
 echo "stats done"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=$(echo "$grp" | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp -d "$O/pmc/$name" -o p --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-ba --no-cpu-baseline > /dev/null 2>> "$O/rocprof.err"
+  rocprofv3 --kernel-trace --pmc $grp -d "$O/pmc/$name" -o p --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --only-headline > /dev/null 2>> "$O/rocprof.err"
   echo "pmc $name done"
 done
 python3 "$R/tools/pmc_summary.py" "$O/pmc" "$O/pmc_traffic.json"
