@@ -135,6 +135,19 @@ int ms_orb_download(ms_orb *orb, int frame, float *x, float *y, float *angle, in
                     uint32_t *desc, int32_t *track_id, int32_t *n);
 int ms_orb_capacity(const ms_orb *orb);
 
+/* N4, serialization half: KeyPoint::serialize (key_point.hpp:22-25) writes `ar(pt.x, pt.y, angle, octave, octave, bearing, descriptor)`
+ * for every element of KeyframeShared::keyPoints (keyframe.hpp:80-93).  ms_keypoints_pack lays the first n keypoints of frame `frame`
+ * of a device SoA view (ms_orb_device_view, or any ms_keypoints of device arrays) out in exactly that field order, 76 bytes per keypoint with no
+ * padding -- x, y, angle as f32; octave as i32 TWICE (the reference's own quirk); bearing as 3 x f64 (`bearing`: device array [n*3] =
+ * KeyPoint::bearing, which the caller computes, keyframe.cpp:55-68; NULL writes zeros); descriptor as 8 x u32 -- on the device, and
+ * copies the records to `records_host` with one transfer (synchronises).  ms_keypoints_unpack is the inverse on the host (any output may
+ * be NULL; MS_ERR_INVALID if the two octave copies of a record differ).  What is NOT known here: the archive framing around the records
+ * (cereal's size tag of the vector and the Eigen::Vector3d serializer live in the parent project's util/serialization.hpp, not in the
+ * reference tree); the record body above is what a binary archive writes for arithmetic fields and std::array<uint32_t, 8>. */
+#define MS_KEYPOINT_RECORD_BYTES 76
+int ms_keypoints_pack(ms_ctx *ctx, const ms_keypoints *view, int frame, int n, const double *bearing, uint8_t *records_host);
+int ms_keypoints_unpack(const uint8_t *records, int n, float *x, float *y, float *angle, int32_t *octave, double *bearing, uint32_t *desc);
+
 /* Per-kernel timing of ms_orb_extract with HIP events on the context stream (off by default).
  * Stage order: 0 resize (all levels), 1 blur, 2 fast, 3 select, 4 tracks, 5 describe.
  * ms_orb_stage_ms synchronises and returns the durations of the LAST ms_orb_extract call. */

@@ -1024,6 +1024,25 @@ static int dev_calloc(ms_ctx *c, T **p, size_t n) {
 }
 #define MS_TRY(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
 
+// KeyPoint::serialize (key_point.hpp:22-25): ar(pt.x, pt.y, angle, octave, octave, bearing, descriptor) -- 19 dwords per keypoint
+// (x, y, angle f32; octave i32 twice; bearing 3 x f64; descriptor 8 x u32).  Thread = one dword of one record: coalesced stores.
+__global__ __launch_bounds__(256) void k_pack_keypoints(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ angle,
+                                                       const int32_t *__restrict__ octave, const uint32_t *__restrict__ desc, const double *__restrict__ bearing,
+                                                       uint64_t base, int n, uint32_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 19) return;
+    const int k = i / 19, w = i - 19 * k;
+    const uint64_t s = base + (uint64_t)k;
+    uint32_t v;
+    if (w == 0) v = __float_as_uint(x[s]);
+    else if (w == 1) v = __float_as_uint(y[s]);
+    else if (w == 2) v = __float_as_uint(angle[s]);
+    else if (w < 5) v = (uint32_t)octave[s];
+    else if (w < 11) v = bearing ? reinterpret_cast<const uint32_t *>(bearing)[6 * (uint64_t)k + (w - 5)] : 0u;
+    else v = desc[s * 8 + (w - 11)];
+    out[i] = v;
+}
+
 extern "C" {
 
 int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
@@ -1304,6 +1323,38 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
 #undef MS_STAGE_MARK
     o->last_src = src;
     o->last_frames = n_frames;
+    return MS_OK;
+}
+
+int ms_keypoints_pack(ms_ctx *c, const ms_keypoints *view, int frame, int n, const double *bearing, uint8_t *records_host) {
+    if (!c || !view || !view->x || !view->y || !view->angle || !view->octave || !view->desc || frame < 0 || n < 0 || n > view->capacity || (n && !records_host))
+        return MS_ERR_INVALID;
+    if (n == 0) return MS_OK;
+    MS_HIP(c, hipSetDevice(c->device));
+    void *scratch = nullptr;
+    MS_TRY(ms_scratch(c, (size_t)n * MS_KEYPOINT_RECORD_BYTES, &scratch));
+    hipLaunchKernelGGL(k_pack_keypoints, dim3(ms_div_up(n * 19, 256)), dim3(256), 0, c->stream, view->x, view->y, view->angle, view->octave, view->desc, bearing,
+                       (uint64_t)frame * (uint64_t)view->capacity, n, static_cast<uint32_t *>(scratch));
+    MS_KERNEL_CHECK(c, "k_pack_keypoints");
+    MS_HIP(c, hipMemcpyAsync(records_host, scratch, (size_t)n * MS_KEYPOINT_RECORD_BYTES, hipMemcpyDeviceToHost, c->stream));
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    return MS_OK;
+}
+
+int ms_keypoints_unpack(const uint8_t *records, int n, float *x, float *y, float *angle, int32_t *octave, double *bearing, uint32_t *desc) {
+    if (n < 0 || (n && !records)) return MS_ERR_INVALID;
+    for (int k = 0; k < n; ++k) {
+        const uint8_t *r = records + (size_t)k * MS_KEYPOINT_RECORD_BYTES;
+        int32_t o1, o2;
+        std::memcpy(&o1, r + 12, 4); std::memcpy(&o2, r + 16, 4);
+        if (o1 != o2) return MS_ERR_INVALID;                    // KeyPoint::serialize writes `octave` twice; a record where they differ is corrupt
+        if (x) std::memcpy(x + k, r, 4);
+        if (y) std::memcpy(y + k, r + 4, 4);
+        if (angle) std::memcpy(angle + k, r + 8, 4);
+        if (octave) octave[k] = o1;
+        if (bearing) std::memcpy(bearing + 3 * (size_t)k, r + 20, 24);
+        if (desc) std::memcpy(desc + 8 * (size_t)k, r + 44, 32);
+    }
     return MS_OK;
 }
 

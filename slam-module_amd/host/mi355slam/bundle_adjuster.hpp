@@ -6,11 +6,63 @@
 // (:341-370), the chi2 > 5.991 outlier rule (:376-388) and the result copy (:114-137), with the optimisation on the GPU.
 #pragma once
 #include <cmath>
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <set>
 #include "common.hpp"
 
 namespace mi355slam {
 
 constexpr float CHI2_THRESHOLD = 5.991f;                                     // bundle_adjuster.cpp:28
+
+// BaStats (ba_stats.hpp:9-84): which kind of bundle adjustment ran in a frame, per frame and in total.  update() is called where
+// the reference calls it -- NEIGHBOR when localBundleAdjust stops after stage 1 (bundle_adjuster.cpp:330), LOCAL after stage 2
+// (:392), POSE / GLOBAL by the caller of poseBundleAdjust / globalBundleAdjust (mapper_helpers.cpp:1047, :1111) -- and finishFrame()
+// by the mapper (mapper.cpp:392, :431).  The reference prints through the parent project's log_info; here the table goes to `sink`.
+class BaStats {
+public:
+    enum class Ba { NONE, POSE, NEIGHBOR, LOCAL, GLOBAL, LAST };
+    explicit BaStats(bool enabled, std::function<void(const char *)> sink = {}) : enabled(enabled), sink(std::move(sink)) {
+        if (!enabled) return;
+        for (int i = 0; i < last; ++i) { bas.emplace(static_cast<Ba>(i), 0); totalBas.emplace(static_cast<Ba>(i), 0); }
+    }
+    void update(Ba ba) { if (enabled) ++bas.at(ba); }
+    void finishFrame() {
+        if (!enabled) return;
+        int count = 0;
+        for (int i = 0; i < last; ++i) { const Ba t = static_cast<Ba>(i); totalBas.at(t) += bas.at(t); count += bas.at(t); }
+        if (count == 0) { bas.at(Ba::NONE) += 1; totalBas.at(Ba::NONE) += 1; }
+        static const char *names[6] = {"none     ", "pose     ", "neighbor ", "local    ", "global   ", "TOTAL    "};
+        char line[96];
+        emit(""); emit("TYPE   \tNUM\tTOTAL");
+        int sum = 0, totalSum = 0;
+        for (int i = 0; i < last; ++i) {
+            const Ba t = static_cast<Ba>(i);
+            sum += bas.at(t); totalSum += totalBas.at(t);
+            std::snprintf(line, sizeof(line), "%s\t%d\t%d", names[i], bas.at(t), totalBas.at(t)); emit(line);
+        }
+        std::snprintf(line, sizeof(line), "%s\t%d\t%d", names[last], sum, totalSum); emit(line);
+        for (int i = 0; i < last; ++i) bas.at(static_cast<Ba>(i)) = 0;
+    }
+    int frameCount(Ba ba) const { return enabled ? bas.at(ba) : 0; }           // counters since the last finishFrame (not in the reference: for tests)
+    int totalCount(Ba ba) const { return enabled ? totalBas.at(ba) : 0; }
+private:
+    void emit(const char *l) const { if (sink) sink(l); else std::printf("%s\n", l); }
+    static constexpr int last = static_cast<int>(Ba::LAST);
+    bool enabled;
+    std::function<void(const char *)> sink;
+    std::map<Ba, int> bas, totalBas;
+};
+
+// WorkspaceBA (bundle_adjuster.hpp:16-25): the id sets localBundleAdjust refills on every call (bundle_adjuster.cpp:158-223; MpId / KfId
+// are plain ints here, id.hpp:9-24) and the statistics.  The window selection that fills the sets walks MapDB and stays with the caller.
+struct WorkspaceBA {
+    std::set<int> localMpIds;
+    std::set<int, std::greater<int>> localKfIds;
+    BaStats baStats;
+    explicit WorkspaceBA(bool enableBaStats) : baStats(enableBaStats) {}
+};
 
 struct BaWindow {
     // vertices
@@ -50,7 +102,8 @@ inline ms_ba_problem as_problem(const BaWindow &w, const std::vector<std::uint8_
 }  // namespace detail
 
 // localBundleAdjust (bundle_adjuster.cpp:141-394) on a prepared window; updates w.poses / w.points in place.
-inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize, const Parameters &parameters, bool neighbourhoodStage = true) {
+inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize, const Parameters &parameters, bool neighbourhoodStage = true,
+                                   WorkspaceBA *workspace = nullptr) {
     BaOutcome out;
     const int iterations = static_cast<int>(1 + std::sqrt(static_cast<double>(problemMaxSize)));      // :156
     std::vector<double> chi2(w.obsPose.size());
@@ -60,7 +113,10 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
     ms_ba_problem p1 = detail::as_problem(w, fixed, nullptr, iterations);
     ctx.check(ms_ba_solve_host(ctx.get(), &p1, w.poses[0].data(), w.points.empty() ? nullptr : w.points[0].data(), chi2.data(), &out.stage1), "ms_ba_solve_host");
     out.ran = true;
-    if (!neighbourhoodStage) return out;                                       // "Skip neighbordhood BA" (:326-332)
+    if (!neighbourhoodStage) {                                                 // "Skip neighbordhood BA" (:326-332)
+        if (workspace) workspace->baStats.update(BaStats::Ba::NEIGHBOR);
+        return out;
+    }
     // stage 2: unfix every keyframe (:335-337); soft orientation prior against the stage-1 pose (:341-370)
     BaWindow w2 = w;
     w2.poses.push_back(w.poses[w.currentKeyframe]);                            // conv.custom(0): fixed copy of the just-optimised pose
@@ -79,6 +135,7 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
     w.points = w2.points;
     out.outlier.resize(chi2.size());
     for (std::size_t i = 0; i < chi2.size(); ++i) out.outlier[i] = chi2[i] > CHI2_THRESHOLD;   // :378
+    if (workspace) workspace->baStats.update(BaStats::Ba::LOCAL);             // :392
     return out;
 }
 

@@ -274,6 +274,58 @@ inline std::vector<int> updateDescriptors(Context &ctx, const std::vector<std::v
     return best;
 }
 
+// ---- M5: findMatchesTranformedMps + matchMapPointsSim3 (keyframe_matcher.cpp:552-686) ------------------------------------
+// One map point of keyframe A as findMatchesTranformedMps sees it after the part that needs the map graph and the camera model
+// (:572-596): `usable` = has a map point (mpId != -1), TRIANGULATED, reprojectToImage succeeded, the viewing distance |R X + t| lies in
+// [minViewingDistance, maxViewingDistance]; (x, y) = the reprojection into keyframe B; predScaleLevel = mp.predictScaleLevel(...).
+struct Sim3Projection {
+    bool usable = false;
+    KeyPoint::Descriptor descriptor{};          // mp.descriptor
+    float x = 0, y = 0;
+    int predScaleLevel = 0;
+};
+
+// findMatchesTranformedMps (:552-631): matches[iA] = index of the best keypoint of kfB (radius margin * scaleFactors[pred], octave in
+// [pred - 1, pred], strictly smaller distance wins = first of the radius query's order, accepted at <= HAMMING_DIST_THR_HIGH) or -1.
+inline std::vector<int> findMatchesTranformedMps(Context &ctx, const std::vector<Sim3Projection> &mpsA, const std::vector<bool> &alreadyMatchedInA,
+                                                 const DeviceKeyframe &kfB, float margin, const StaticSettings &settings) {
+    std::vector<int> matchesAtoB(mpsA.size(), -1);
+    std::vector<RadiusQuery> qs;
+    std::vector<std::size_t> owner;
+    for (std::size_t indA = 0; indA < mpsA.size(); ++indA) {
+        if (alreadyMatchedInA.at(indA) || !mpsA[indA].usable) continue;                        // :566-590
+        const Sim3Projection &m = mpsA[indA];
+        RadiusQuery q;
+        q.descriptor = m.descriptor; q.x = m.x; q.y = m.y;
+        q.radius = margin * settings.scaleFactors.at((std::size_t)m.predScaleLevel);           // :596
+        q.minOctave = m.predScaleLevel - 1; q.maxOctave = m.predScaleLevel;                    // :611
+        qs.push_back(q); owner.push_back(indA);
+    }
+    const std::vector<int> best = bestCandidateCore(ctx, kfB, qs, HAMMING_DIST_THR_HIGH);     // :600-627
+    for (std::size_t i = 0; i < qs.size(); ++i) matchesAtoB[owner[i]] = best[i];
+    return matchesAtoB;
+}
+
+// matchMapPointsSim3 (:633-686) on keypoint indices: `matches` holds (index in kf1, index in kf2) pairs -- the reference keeps
+// (MpId, MpId) and looks the indices up through mapPoints.at(id).observations.at(kf.id) (:645-648); the caller does that lookup and the
+// reverse one (kf.mapPoints.at(index)) for the pairs appended here.  mps1in2 = kf1's map points projected into kf2 with
+// transform12^-1 * kf1.poseCW (:650), mps2in1 = kf2's into kf1 with transform12 * kf2.poseCW (:661).  Returns the number added.
+inline unsigned matchMapPointsSim3(Context &ctx, const DeviceKeyframe &kf1, const DeviceKeyframe &kf2, const std::vector<Sim3Projection> &mps1in2,
+                                   const std::vector<Sim3Projection> &mps2in1, std::vector<std::pair<int, int>> &matches, const StaticSettings &settings) {
+    constexpr float margin = 7.5;                                                              // :641
+    std::vector<bool> alreadyMatchedInKf1(mps1in2.size(), false), alreadyMatchedInKf2(mps2in1.size(), false);
+    for (const auto &match : matches) { alreadyMatchedInKf1.at((std::size_t)match.first) = true; alreadyMatchedInKf2.at((std::size_t)match.second) = true; }
+    const std::vector<int> matched_indices_2_in_keyfrm_1 = findMatchesTranformedMps(ctx, mps1in2, alreadyMatchedInKf1, kf2, margin, settings);
+    const std::vector<int> matched_indices_1_in_keyfrm_2 = findMatchesTranformedMps(ctx, mps2in1, alreadyMatchedInKf2, kf1, margin, settings);
+    unsigned num_matches = 0;                                                                  // only matches that agree in both directions (:672-685)
+    for (unsigned i = 0; i < matched_indices_2_in_keyfrm_1.size(); ++i) {
+        const int idx_2 = matched_indices_2_in_keyfrm_1.at(i);
+        if (idx_2 < 0) continue;
+        if (matched_indices_1_in_keyfrm_2.at((std::size_t)idx_2) == static_cast<int>(i)) { matches.emplace_back((int)i, idx_2); ++num_matches; }
+    }
+    return num_matches;
+}
+
 // create_E_21 (openvslam/essential_solver.cc:157-162), row-major 3x3
 inline void create_E_21(const double R1w[9], const double t1w[3], const double R2w[9], const double t2w[3], double E[9]) {
     double R21[9], t21[3];

@@ -262,6 +262,18 @@ class OrbExtractor:
                                              _vp(out["desc"]), _vp(out["track_id"]), C.byref(n)), "ms_orb_download")
         return {k: v[:n.value].copy() for k, v in out.items()}
 
+    def pack_keypoints(self, frame, bearing=None):
+        """KeyPoint::serialize records (76 bytes each: x, y, angle, octave, octave, bearing[3] f64, descriptor[8]) of frame `frame`."""
+        self.ctx.sync()
+        v = self.device_view()
+        cnt = np.zeros(1, np.int32)
+        self.ctx.check(lib().ms_dev_download(self.ctx._h, _vp(cnt), C.c_void_p(v.count + 4 * frame), C.c_size_t(4)), "ms_dev_download")
+        n = int(cnt[0])
+        out = np.zeros((n, 76), np.uint8)
+        db = None if bearing is None else self.ctx.upload(np.ascontiguousarray(bearing, np.float64).reshape(n, 3))
+        self.ctx.check(lib().ms_keypoints_pack(self.ctx._h, C.byref(v), frame, n, _vp(db), _vp(out)), "ms_keypoints_pack")
+        return out
+
     def set_profiling(self, enable=True):
         self.ctx.check(lib().ms_orb_set_profiling(self._h, int(enable)), "ms_orb_set_profiling")
 
@@ -298,6 +310,18 @@ class OrbExtractor:
             self.close()
         except Exception:
             pass
+
+
+def unpack_keypoints(records):
+    """Inverse of OrbExtractor.pack_keypoints (host): dict of x, y, angle, octave, bearing, desc."""
+    rec = np.ascontiguousarray(records, np.uint8).reshape(-1, 76)
+    n = len(rec)
+    out = dict(x=np.zeros(n, np.float32), y=np.zeros(n, np.float32), angle=np.zeros(n, np.float32), octave=np.zeros(n, np.int32),
+               bearing=np.zeros((n, 3), np.float64), desc=np.zeros((n, 8), np.uint32))
+    rc = lib().ms_keypoints_unpack(_vp(rec), n, _vp(out["x"]), _vp(out["y"]), _vp(out["angle"]), _vp(out["octave"]), _vp(out["bearing"]), _vp(out["desc"]))
+    if rc != 0:
+        raise MsError("ms_keypoints_unpack failed (%d): the two octave fields of a record differ" % rc)
+    return out
 
 
 # ---- matching ----

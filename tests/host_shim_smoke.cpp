@@ -137,6 +137,61 @@ int main(int argc, char **argv) {
         std::printf("searchByProjection (device radius query): %d matches of %zu queries\n", nm, rq.size());
         if (got != want || bound != bound_ref || nm < 20) { std::printf("radius searchByProjectionCore mismatch\n"); return 8; }
     }
+    // M5: matchMapPointsSim3 on two keyframes whose map points see each other (kf2 = kf1 shifted by (3, -2) px with a few bits flipped),
+    // against a sequential restatement of keyframe_matcher.cpp:552-686 (radius query in y-sorted order, octave window, <= 100, seeds, mutual check)
+    {
+        unsigned rng = 4242u;
+        auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+        auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { int d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
+        KeyPointVector kps2 = kps;
+        for (auto &k : kps2) { k.pt.x += 3.f; k.pt.y -= 2.f; for (int f = 0; f < 6; ++f) k.descriptor[rnd() % 8] ^= 1u << (rnd() % 32); if (rnd() % 7 == 0) k.octave += 1; }
+        std::rotate(kps2.begin(), kps2.begin() + 17, kps2.end());                 // indices differ between the keyframes
+        KeyframeFeatures f2; f2.keyPoints = &kps2; f2.usable.assign(kps2.size(), 1);
+        DeviceKeyframe dA(ctx, f), dB(ctx, f2);
+        auto project = [&](const KeyPointVector &from, float dx, float dy) {
+            std::vector<Sim3Projection> out(from.size());
+            for (std::size_t i = 0; i < from.size(); ++i) {
+                Sim3Projection &m = out[i];
+                m.usable = rnd() % 9 != 0;                                        // some points fail the map / camera gates
+                m.descriptor = from[i].descriptor; m.x = from[i].pt.x + dx + 0.25f * (float)(rnd() % 5); m.y = from[i].pt.y + dy - 0.25f * (float)(rnd() % 5);
+                m.predScaleLevel = std::min(7, from[i].octave + (int)(rnd() % 2));
+            }
+            return out;
+        };
+        const std::vector<Sim3Projection> p12 = project(kps, 3.f, -2.f), p21 = project(kps2, -3.f, 2.f);
+        std::vector<std::pair<int, int>> seed;
+        for (int i = 0; i < 12; ++i) { const int a = (int)((i * 37 + 5) % kps.size()); seed.emplace_back(a, (int)((a + kps.size() - 17) % kps.size())); }
+        auto reference = [&](const std::vector<Sim3Projection> &mps, const std::vector<bool> &already, const KeyPointVector &target) {
+            std::vector<std::size_t> order(target.size());
+            for (std::size_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](std::size_t a, std::size_t b) { return target[a].pt.y < target[b].pt.y; });
+            std::vector<int> out(mps.size(), -1);
+            for (std::size_t a = 0; a < mps.size(); ++a) {
+                if (already[a] || !mps[a].usable) continue;
+                const float r = 7.5f * settings.scaleFactors[(std::size_t)mps[a].predScaleLevel];
+                unsigned bestD = 256; int bestI = -1;
+                for (std::size_t o : order) {
+                    const float dx = mps[a].x - target[o].pt.x, dy = mps[a].y - target[o].pt.y;
+                    if (target[o].pt.y < mps[a].y - r || !(target[o].pt.y <= mps[a].y + r) || !(dx * dx + dy * dy < r * r)) continue;
+                    if (target[o].octave < mps[a].predScaleLevel - 1 || target[o].octave > mps[a].predScaleLevel) continue;
+                    const unsigned d = (unsigned)popc(mps[a].descriptor, target[o].descriptor);
+                    if (d < bestD) { bestD = d; bestI = (int)o; }
+                }
+                if (bestD <= 100) out[a] = bestI;
+            }
+            return out;
+        };
+        std::vector<bool> a1(kps.size(), false), a2(kps2.size(), false);
+        for (auto &m : seed) { a1[(std::size_t)m.first] = true; a2[(std::size_t)m.second] = true; }
+        const std::vector<int> w12 = reference(p12, a1, kps2), w21 = reference(p21, a2, kps);
+        std::vector<std::pair<int, int>> want = seed, got = seed;
+        for (std::size_t i = 0; i < w12.size(); ++i) if (w12[i] >= 0 && w21[(std::size_t)w12[i]] == (int)i) want.emplace_back((int)i, w12[i]);
+        const unsigned added = matchMapPointsSim3(ctx, dA, dB, p12, p21, got, settings);
+        int one_way = 0; for (int m : w12) one_way += m >= 0;
+        std::printf("matchMapPointsSim3: %u mutual matches added to %zu seeds (%d one-way candidates)\n", added, seed.size(), one_way);
+        if (got != want || added + seed.size() != got.size() || added < 30 || (int)added >= one_way) { std::printf("matchMapPointsSim3 mismatch\n"); return 12; }
+        if (findMatchesTranformedMps(ctx, p12, a1, dB, 7.5f, settings) != w12) { std::printf("findMatchesTranformedMps mismatch\n"); return 13; }
+    }
     {   auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { unsigned d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
         // updateDescriptor for a batch of map points vs the plain median-of-row rule (map_point.cpp:75-116)
         std::vector<std::vector<KeyPoint::Descriptor>> obs(40);
@@ -208,7 +263,24 @@ int main(int argc, char **argv) {
     }
     for (int i = 1; i < 3; ++i) { w.edgeI.push_back(i); w.edgeJ.push_back(i - 1); w.edgeMeas.push_back({0, 0, 0, 1, 0.2, 0, 0});
         std::array<double, 36> info{}; for (int k = 0; k < 6; ++k) info[7 * k] = 1e4; w.edgeInfo.push_back(info); }
-    BaOutcome o = localBundleAdjust(ctx, w, 50, params);
+    WorkspaceBA workspace(true);
+    std::vector<std::string> table;
+    workspace.baStats = BaStats(true, [&](const char *l) { table.emplace_back(l); });
+    BaOutcome o = localBundleAdjust(ctx, w, 50, params, true, &workspace);
+    {   // BaStats / WorkspaceBA (ba_stats.hpp:9-84): LOCAL after the two-stage run, NEIGHBOR when stage 2 is skipped, NONE for an empty frame
+        BaWindow w1 = w;
+        localBundleAdjust(ctx, w1, 50, params, false, &workspace);
+        workspace.baStats.update(BaStats::Ba::POSE);
+        bool ok = workspace.baStats.frameCount(BaStats::Ba::LOCAL) == 1 && workspace.baStats.frameCount(BaStats::Ba::NEIGHBOR) == 1 && workspace.baStats.frameCount(BaStats::Ba::POSE) == 1;
+        workspace.baStats.finishFrame();
+        ok = ok && table.size() == 8 && table[1] == "TYPE   \tNUM\tTOTAL" && table[3] == "pose     \t1\t1" && table[4] == "neighbor \t1\t1" && table[5] == "local    \t1\t1" &&
+             table[7] == "TOTAL    \t3\t3" && workspace.baStats.frameCount(BaStats::Ba::LOCAL) == 0;
+        table.clear();
+        workspace.baStats.finishFrame();                                       // a frame without any BA counts as NONE
+        ok = ok && table[2] == "none     \t1\t1" && table[7] == "TOTAL    \t1\t4" && workspace.baStats.totalCount(BaStats::Ba::NONE) == 1;
+        BaStats off(false); off.update(BaStats::Ba::LOCAL); off.finishFrame();
+        if (!ok || off.totalCount(BaStats::Ba::LOCAL) != 0) { std::printf("BaStats mismatch\n"); return 14; }
+    }
     std::printf("BA stage1 chi2 %.3f -> %.3f, stage2 -> %.3f, iterations %d/%d\n", o.stage1.chi2_initial, o.stage1.chi2_final, o.stage2.chi2_final,
                 o.stage1.iterations, o.stage2.iterations);
     if (!(o.stage2.chi2_final <= o.stage1.chi2_initial)) return 4;

@@ -97,3 +97,18 @@ def test_angle_check_host_function(oracle):
         d = np.concatenate([rng.normal(40, 10, n // 2), rng.uniform(-360, 720, n - n // 2)]).astype(np.float32)
         ids = rng.permutation(n).astype(np.int32)
         assert np.array_equal(mi355slam.angle_check(d, ids), oracle.angle_check(d, ids))
+
+
+def test_keypoint_records_unpack_in_serialize_order():
+    """KeyPoint::serialize (key_point.hpp:22-25): x, y, angle, octave, octave, bearing, descriptor = 76 packed bytes; host half of N4."""
+    import struct
+    import mi355slam
+    rec = np.zeros((3, 76), np.uint8)
+    for k in range(3):
+        rec[k] = np.frombuffer(struct.pack("<fffii3d8I", 1.5 + k, 2.5, 33.25, 4 + k, 4 + k, 0.1, 0.2, 0.3 + k, *range(k, k + 8)), np.uint8)
+    o = mi355slam.unpack_keypoints(rec)
+    assert o["x"].tolist() == [1.5, 2.5, 3.5] and o["octave"].tolist() == [4, 5, 6] and o["bearing"][2].tolist() == [0.1, 0.2, 2.3]
+    assert o["desc"][1].tolist() == list(range(1, 9)) and o["angle"][0] == 33.25
+    rec[1, 16] ^= 1                                                    # second copy of octave differs: corrupt record
+    with pytest.raises(mi355slam.MsError):
+        mi355slam.unpack_keypoints(rec)

@@ -238,3 +238,26 @@ def test_randomised_configurations(oracle, ctx):
         _, got, want = _extract_both(oracle, ctx, np.ascontiguousarray(img)[None], levels=levels, scale_factor=sf, fast_threshold=thr, max_kpts=kp)
         _assert_same_keypoints(got[0], want[0])
         done += 1
+
+
+def test_keypoint_records_round_trip(oracle, ctx):
+    """N4: the device SoA packed into KeyPoint::serialize records (key_point.hpp:22-25) and read back: every field survives, the
+    byte layout is x, y, angle (f32), octave twice (i32), bearing (3 x f64), descriptor (8 x u32) = 76 bytes."""
+    import struct
+    import mi355slam
+    imgs = np.stack([oracle.synth_frame(640, 480, 1000 + i) for i in range(2)])
+    ex, got, want = _extract_both(oracle, ctx, imgs)
+    for f in range(2):
+        n = len(want[f]["x"])
+        bearing = np.random.default_rng(f).normal(size=(n, 3))
+        rec = ex.pack_keypoints(f, bearing)
+        assert rec.shape == (n, 76)
+        back = mi355slam.unpack_keypoints(rec)
+        for k in ("x", "y", "angle"):
+            assert np.array_equal(back[k].view(np.uint32), want[f][k].view(np.uint32))
+        assert np.array_equal(back["octave"], want[f]["octave"]) and np.array_equal(back["desc"], want[f]["desc"]) and np.array_equal(back["bearing"], bearing)
+        i = n // 2                                                     # one record decoded independently of the library
+        x, y, a, o1, o2, b0, b1, b2, *d = struct.unpack("<fffii3d8I", rec[i].tobytes())
+        assert (x, y, a, o1, o2) == (want[f]["x"][i], want[f]["y"][i], want[f]["angle"][i], want[f]["octave"][i], want[f]["octave"][i])
+        assert (b0, b1, b2) == tuple(bearing[i]) and d == want[f]["desc"][i].tolist()
+    assert np.array_equal(mi355slam.unpack_keypoints(ex.pack_keypoints(0))["bearing"], np.zeros((len(want[0]["x"]), 3)))     # no bearing given: zeros

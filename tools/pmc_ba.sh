@@ -3,7 +3,7 @@
 # One counter group per run, --kernel-trace only.  Writes the per-launch averages of the 256-workgroup launches.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=${1:-$R/gpurun_out/pmc_ba.json}
+OUT=${1:-$R/gpurun_out/pmc_ba.json}; case "$OUT" in /*) ;; *) OUT="$R/$OUT";; esac
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F64 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=$(echo "$grp" | cut -d' ' -f1)
   rm -rf "$R/gpurun_out/pmc_ba/$name"
