@@ -487,15 +487,11 @@ def bench_ba(R, ctx, args):
     stats = [ba.download(i)["stats"] for i in range(0, args.ba_batch, max(args.ba_batch // 16, 1))]
     iters = sum(s["iters"] for s in stats) / len(stats)
     trials = sum(s["trials"] for s in stats) / len(stats)
-    # latency of ONE window (what a sequential SLAM pipeline sees): a team of workgroups shares the problem (automatic size);
-    # one_cu = the same solve confined to a single workgroup, as every window of the 256-window launch above runs
+    # latency of ONE window (what a sequential SLAM pipeline sees): a team of workgroups shares the problem (automatic size)
     one = mi355slam.BundleAdjuster(ctx, probs[:1], max_iters=10)
     one.solve(); ctx.sync()
     ctx.event_mark(4); one.solve(); ctx.event_mark(5)
     single_ms = ctx.event_elapsed_ms(4, 5)
-    one.set_team(1); one.solve(); ctx.sync()
-    ctx.event_mark(4); one.solve(); ctx.event_mark(5)
-    single_one_cu_ms = ctx.event_elapsed_ms(4, 5)
     # what a keyframe pays when the window is new: create (host index build + upload) + solve + download + destroy
     t1 = time.perf_counter()
     n_new = 8
@@ -508,7 +504,7 @@ def bench_ba(R, ctx, args):
     res = {"metric": "local-BA solves/sec (50 KF x 2000 pts x 20k obs, 10 LM iters)", "value": round(solves_total / dt, 1),
            "unit": "solves/s", "windows_per_launch": args.ba_batch, "distinct_windows": len(probs), "ms_per_launch": round(kernel_ms, 3),
            "lm_iterations": round(iters, 2), "lm_trials": round(trials, 2),
-           "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1), "single_window_one_cu_ms": round(single_one_cu_ms, 3),
+           "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
            "new_window_ms": round(new_window_ms, 3), "dtype": "f64",
            "roofline": {"kernel": "k_ba_lm", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -47,9 +49,9 @@ struct FsSet {
     int32_t n_pass;
     const int32_t *row0, *row1;              // [n_pass]
     const int32_t *batch_start;              // [n_pass + 1] first batch of a pass
-    const int32_t *b_obs_start, *b_run_start;    // [n_batch + 1]: lane slots / pair chunks of a batch
+    const int32_t *b_obs_start, *b_run_start;    // [n_batch + 1]: lane slots / first pair element (uint16 units, 8-aligned) of a batch
+    const int32_t *b_fmt;                    // [n_batch] 0: the batch's pairs are chunks of 8; n > 0: n single pairs, one per lane (batches with <= 64 pairs)
     const int32_t *pobs;                     // per lane slot: observation, pose vertex, point, free pose index (int4)
-    const int32_t *wave_b;                   // [n_pass][NW + 1] batch range of every wave, balanced by estimated cost
     const uint16_t *pairs;                   // chunks of 8 pairs (a_lane | b_lane << 8, 0xFFFF = none): the pairs of a chunk fall into the same block (pose a,
                                              // pose b); a batch's chunks are sorted by block
     const int32_t *rowoff;                   // [np_free] offset (doubles) of pose row fa inside its pass's tile
@@ -93,6 +95,7 @@ struct BaProb {
     // all), [1] fine (about one pose row per pass: the workgroups of a team take them round-robin); null when the problem uses the
     // record-based path (a point with more than 64 free observations, or a pose row wider than the LDS tile)
     FsSet fs[2];
+    int32_t fused;                           // 1: schur_fused / point_backsub_fused (no Hpl / Y records exist); 0: the record-based path
     // windowed Cholesky (cholesky_window): the active front of the factorisation as W x W tiles of 16 x 16 in LDS; 0 = front too wide
     int32_t cw_W;
     const int32_t *cw_slot;                  // [nblk] LDS slot (row and column index in the tile grid) of 16-row block b while it is active
@@ -461,7 +464,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
                 for (int a = 0; a < 3; ++a) b[a] += -(Jl[a] * e[0] + Jl[3 + a] * e[1]) * wi;
                 H[0] += wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); H[1] += wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); H[2] += wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
                 H[3] += wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); H[4] += wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); H[5] += wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
-                if (P.pidx[pi] >= 0 && !P.fs[0].row0) {      // the record-based Schur path keeps Hpl; the fused pass recomputes it
+                if (P.pidx[pi] >= 0 && !P.fused) {      // the record-based Schur path keeps Hpl; the fused pass recomputes it
                     double W[18];
 #pragma unroll
                     for (int a = 0; a < 6; ++a)
@@ -806,6 +809,8 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
     const MS_GLOBAL int32_t *cs = (const MS_GLOBAL int32_t *)P.fs_cs, *rowoff = (const MS_GLOBAL int32_t *)F.rowoff, *env = (const MS_GLOBAL int32_t *)P.env16;
     const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)F.pobs;
     const MS_GLOBAL u4_t *chunks = (const MS_GLOBAL u4_t *)F.pairs;
+    const MS_GLOBAL uint16_t *pairs16 = (const MS_GLOBAL uint16_t *)F.pairs;
+    const MS_GLOBAL int32_t *b_fmt = (const MS_GLOBAL int32_t *)F.b_fmt;
     const MS_GLOBAL int32_t *b_obs = (const MS_GLOBAL int32_t *)F.b_obs_start, *b_run = (const MS_GLOBAL int32_t *)F.b_run_start;
     const MS_GLOBAL double *Hpp = (const MS_GLOBAL double *)P.Hpp;
     MS_GLOBAL double *Sg = (MS_GLOBAL double *)P.S;
@@ -857,9 +862,11 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
                 uv[0] = P.obs_uv[2 * (size_t)o]; uv[1] = P.obs_uv[2 * (size_t)o + 1]; info = P.obs_info[o];
             }
             // behind the gathers: this batch's run table entry and first pair chunk, the next batch's lane records
-            const int run_lo = b_run[b], run_hi = b_run[b + 1];
+            const int fmt = b_fmt[b], run_lo = b_run[b] >> 3, run_hi = fmt ? run_lo : (b_run[b + 1] >> 3);
             u4_t pk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (run_lo + lane < run_hi) pk = chunks[run_lo + lane];
+            unsigned single = 0xFFFFu;
+            if (lane < fmt) single = pairs16[b_run[b] + lane];
             i4_t rec_n = {0, 0, 0, -1};
             int o0_n = 0, nobs_n = 0;
             if (b + 1 < b_hi) { o0_n = b_obs[b + 1]; nobs_n = b_obs[b + 2] - o0_n; if (lane < nobs_n) rec_n = pobs4[o0_n + lane]; }
@@ -889,37 +896,41 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            auto take_block = [&](unsigned ab) {                      // the block of pair ab becomes the lane's current one: the old sum goes out first
+                const int k2 = (meta[ab & 255u] << 16) | meta[ab >> 8];
+                if (k2 != key) {
+                    if (key >= 0) {
+                        const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
+                        MS_LDS double *blk = tile + rowoff[fa2] + 6 * fb2 - c0;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i)
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) { lds_sub(blk + i * len + j, acc[6 * i + j]); acc[6 * i + j] = 0; }
+                    }
+                    key = k2;
+                }
+            };
+            auto add_pair = [&](unsigned ab) {
+                const MS_LDS double *za = stage + (ab & 255u) * 18, *zb = stage + (ab >> 8) * 18;
+                double A[18], B[18];
+#pragma unroll
+                for (int q = 0; q < 18; ++q) { A[q] = za[q]; B[q] = zb[q]; }
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[6 * i + j] += A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+            };
+            if (single != 0xFFFFu) { take_block(single); add_pair(single); }
             for (int run = run_lo + lane; run < run_hi; run += 64) {
                 u4_t nx = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 if (run + 64 < run_hi) nx = chunks[run + 64];
-                {
-                    const unsigned ab = pk.x & 0xFFFFu;
-                    const int k2 = (meta[ab & 255u] << 16) | meta[ab >> 8];
-                    if (k2 != key) {
-                        if (key >= 0) {
-                            const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
-                            MS_LDS double *blk = tile + rowoff[fa2] + 6 * fb2 - c0;
-#pragma unroll
-                            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                                for (int j = 0; j < 6; ++j) { lds_sub(blk + i * len + j, acc[6 * i + j]); acc[6 * i + j] = 0; }
-                        }
-                        key = k2;
-                    }
-                }
+                take_block(pk.x & 0xFFFFu);
 #pragma unroll 1
                 for (int k = 0; k < 8; ++k) {
                     const unsigned wd = k < 2 ? pk.x : (k < 4 ? pk.y : (k < 6 ? pk.z : pk.w));
                     const unsigned ab = (k & 1) ? wd >> 16 : wd & 0xFFFFu;
                     if (ab == 0xFFFFu) break;
-                    const MS_LDS double *za = stage + (ab & 255u) * 18, *zb = stage + (ab >> 8) * 18;
-                    double A[18], B[18];
-#pragma unroll
-                    for (int q = 0; q < 18; ++q) { A[q] = za[q]; B[q] = zb[q]; }
-#pragma unroll
-                    for (int i = 0; i < 6; ++i)
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) acc[6 * i + j] += A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+                    add_pair(ab);
                 }
                 pk = nx;
             }
@@ -1446,7 +1457,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     const bool lead = P.team == 1 || blockIdx.x % (unsigned)P.team == 0;
     if (lead && threadIdx.x == 0) P.flag[0] = 1;
     team_sync(P);
-    const bool fused = P.fs[0].row0 != nullptr;
+    const bool fused = P.fused != 0;
     if (fused) schur_fused(P, lambda, lds, cyc);
     else {
         schur_prepare(P, lambda);
@@ -1595,15 +1606,18 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     if (!c || !problems || !out || n < 1) return MS_ERR_INVALID;
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
+    const bool tm_on = std::getenv("MS_BA_TIMING") != nullptr;           // prints the host index build and the allocation + upload time of every create to stderr
+    auto tm_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tm0 = tm_now();
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, pobs, rowoff, yoff, wave_b; std::vector<uint16_t> pairs; std::vector<double> cost; };
+    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; };
     struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
-                  bool fused = false; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
+                  bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], fs_waveb[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -1631,7 +1645,38 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int f = 0; f < R.np_free; ++f) R.fstart[f + 1] += R.fstart[f];
         R.fobs.resize(R.fstart[R.np_free]);
         { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
-        {   // Schur work list: for every free point, every ordered pair (a, b) of its observations with free poses fb <= fa,
+        // envelope of the reduced camera matrix at pose level: the first free pose each free pose is coupled with (a shared point or a
+        // pose-pose edge), and the free observations of every free point, sorted by free pose (flat arrays: the fused Schur pass is built from them)
+        std::vector<int> first(R.np_free);
+        std::vector<int32_t> fp_start(Q.n_point + 1, 0), fp_f, fp_o;
+        {
+            for (int f = 0; f < R.np_free; ++f) first[f] = f;
+            int max_k = 0;
+            for (int l = 0; l < Q.n_point; ++l) {
+                fp_start[l] = (int32_t)fp_f.size();
+                if (Q.point_fixed && Q.point_fixed[l]) continue;
+                const size_t b0 = fp_f.size();
+                for (int ii = R.pt_start[l]; ii < R.pt_start[l + 1]; ++ii) {
+                    const int o = R.pt_obs[ii], f = R.pidx[Q.obs_pose[o]];
+                    if (f < 0) continue;
+                    size_t at = fp_f.size();
+                    fp_f.push_back(f); fp_o.push_back(o);
+                    while (at > b0 && fp_f[at - 1] > f) { std::swap(fp_f[at - 1], fp_f[at]); std::swap(fp_o[at - 1], fp_o[at]); --at; }     // insertion: lists are short and mostly sorted
+                }
+                const int kk = (int)(fp_f.size() - b0);
+                max_k = std::max(max_k, kk);
+                if (kk) { const int fmin = fp_f[b0]; for (size_t a = b0; a < fp_f.size(); ++a) first[fp_f[a]] = std::min(first[fp_f[a]], fmin); }
+            }
+            fp_start[Q.n_point] = (int32_t)fp_f.size();
+            for (int k = 0; k < Q.n_pose_edge; ++k) {
+                const int fi = R.pidx[Q.edge_i[k]], fj = R.pidx[Q.edge_j[k]];
+                if (fi >= 0 && fj >= 0) first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj));
+            }
+            bool ok = R.np_free > 0 && max_k <= FS_OB;
+            for (int f = 0; f < R.np_free && ok; ++f) if (36 * (f - first[f] + 1) + 6 > kFsTileDoubles) ok = false;
+            R.fused = ok;
+        }
+        if (!R.fused) {   // record-based Schur work list: for every free point, every ordered pair (a, b) of its observations with free poses fb <= fa,
             // counting-sorted by (fa, fb), then cut into chunks of CH items of one pose pair
             const int np = R.np_free;
             std::vector<int32_t> count((size_t)np * np + 1, 0);
@@ -1674,13 +1719,6 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         {   // envelope of the reduced camera matrix: the first free pose each free pose is coupled with (a shared point or a
             // pose-pose edge).  Cholesky creates no fill left of it, so the factorisation skips everything outside.
             const int np = R.np_free, n6i = 6 * np;
-            std::vector<int> first(np);
-            for (int f = 0; f < np; ++f) first[f] = f;
-            for (int32_t pr : R.seg_pair) { const int fa = pr >> 16, fb = pr & 0xFFFF; first[fa] = std::min(first[fa], fb); }
-            for (int k = 0; k < Q.n_pose_edge; ++k) {
-                const int fi = R.pidx[Q.edge_i[k]], fj = R.pidx[Q.edge_j[k]];
-                if (fi >= 0 && fj >= 0) { first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj)); }
-            }
             R.env16.assign(n6i / 16 + 2, 0);
             for (int b = 0; b < (int)R.env16.size(); ++b) {
                 int e = n6i;
@@ -1703,25 +1741,19 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
         {   // fused Schur pass (schur_fused): pose rows -> passes whose envelope part fits the LDS tile, points -> batches of <= 64 observations
             const int np = R.np_free;
-            std::vector<int> first(np);
-            for (int f = 0; f < np; ++f) first[f] = f;
-            for (int32_t pr : R.seg_pair) { const int fa = pr >> 16, fb = pr & 0xFFFF; first[fa] = std::min(first[fa], fb); }
-            for (int k = 0; k < Q.n_pose_edge; ++k) {
-                const int fi = R.pidx[Q.edge_i[k]], fj = R.pidx[Q.edge_j[k]];
-                if (fi >= 0 && fj >= 0) first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj));
-            }
             R.fs_cs.resize(np);
-            bool ok = np > 0;
-            for (int f = 0; f < np; ++f) { R.fs_cs[f] = 6 * first[f]; if (36 * (f - first[f] + 1) + 6 > kFsTileDoubles) ok = false; }
-            // free observations of every free point, in pose order (the order of pt_obs is observation order; pairs need fb <= fa only by value)
-            for (int l = 0; l < Q.n_point && ok; ++l) {
-                if (Q.point_fixed && Q.point_fixed[l]) continue;
-                int kk = 0;
-                for (int ii = R.pt_start[l]; ii < R.pt_start[l + 1]; ++ii) kk += R.pidx[Q.obs_pose[R.pt_obs[ii]]] >= 0;
-                if (kk > FS_OB) ok = false;
-            }
-            R.fused = ok;
+            for (int f = 0; f < np; ++f) R.fs_cs[f] = 6 * first[f];
+            const bool ok = R.fused;
+            std::vector<int32_t> stamp(Q.n_point, -1);
+            std::vector<std::pair<uint64_t, int32_t>> pts;               // (signature of the point's pose set, point)
+            std::vector<std::pair<int32_t, uint16_t>> bp2;                // (block key, pair) of the open batch
+            // Only the set the launches will use is built (the other one aliases it: still correct, only slower, should ms_ba_set_team
+            // ask for the other regime later): a batch that fills the chip always runs one workgroup per problem, a handful of windows
+            // gets teams -- the same rule ms_ba_solve applies.
+            const int max_team = std::max(1, std::min(kMaxTeam, c->n_cu / std::max(n, 1)));
+            R.fs_only = (max_team == 1 || std::min(32, std::max(1, Q.n_obs / 512)) == 1) ? 0 : 1;
             for (int set = 0; set < 2 && ok; ++set) {
+                if (set != R.fs_only) continue;
                 FsHost &F = R.fs[set];
                 const int max_rows = set == 0 ? np : (np + 63) / 64;      // fine set: about one pose row per pass, at most 64 passes' worth per row group
                 F.rowoff.assign(np, 0);
@@ -1740,10 +1772,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                     r = r1;
                 }
                 F.batch_start.push_back(0); F.b_obs_start.push_back(0); F.b_run_start.push_back(0);
-                std::vector<int32_t> stamp(Q.n_point, -1);
-                struct Pt { int32_t l; std::vector<int32_t> f, o; };
-                std::vector<Pt> pts;
-                std::vector<std::pair<int32_t, uint16_t>> bp2;           // (block key, pair) of the open batch
+                F.pobs.reserve(4 * fp_f.size() * (set ? 6 : 2)); F.pairs.reserve(8 * fp_f.size());
+                std::fill(stamp.begin(), stamp.end(), -1);
                 for (size_t ps = 0; ps < F.row0.size(); ++ps) {
                     const int r0 = F.row0[ps], r1 = F.row1[ps];
                     pts.clear();
@@ -1752,68 +1782,95 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                             const int l = Q.obs_point[R.fobs[ii]];
                             if (stamp[l] == (int32_t)ps || (Q.point_fixed && Q.point_fixed[l])) continue;
                             stamp[l] = (int32_t)ps;
-                            Pt q; q.l = l;      // the point's free observations on poses < r1 (later poses have no pair with a row of this pass)
-                            for (int jj = R.pt_start[l]; jj < R.pt_start[l + 1]; ++jj) {
-                                const int o = R.pt_obs[jj], f = R.pidx[Q.obs_pose[o]];
-                                if (f >= 0 && f < r1) { q.f.push_back(f); q.o.push_back(o); }
-                            }
-                            pts.push_back(std::move(q));
+                            // signature of the point's free poses below r1 (later poses have no pair with a row of this pass): points with the same
+                            // set get the same key, and keys order roughly by position in the window
+                            uint64_t h = 1469598103934665603ull; int fmin = 0x7fff, fmax = 0, kk = 0;
+                            for (int jj = fp_start[l]; jj < fp_start[l + 1] && fp_f[jj] < r1; ++jj) { h = (h ^ (uint64_t)fp_f[jj]) * 1099511628211ull; fmin = std::min(fmin, (int)fp_f[jj]); fmax = fp_f[jj]; ++kk; }
+                            pts.emplace_back(((uint64_t)fmin << 48) | ((uint64_t)fmax << 32) | ((uint64_t)(kk & 0xFF) << 24) | (h & 0xFFFFFFull), l);
                         }
-                    // points with the same set of poses next to each other: their pairs fall into the same blocks
-                    std::stable_sort(pts.begin(), pts.end(), [](const Pt &x, const Pt &y) { return x.f < y.f; });
+                    std::sort(pts.begin(), pts.end());                    // points with the same set of poses next to each other: their pairs fall into the same blocks
                     int in_batch = 0;
-                    auto close_batch = [&]() {
-                        if (in_batch == 0) return;
-                        std::stable_sort(bp2.begin(), bp2.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                    bool uniform = true;                                  // every point of the open batch has the same pose set
+                    uint64_t batch_key = 0;
+                    int batch_k = 0, batch_first = -1;                    // poses per point / first point (index into pts) of the open batch
+                    auto emit_chunks = [&](size_t n_pairs, auto &&pair_at, auto &&key_at) {
                         // chunks of <= 8 pairs of one block; when the batch has few pairs the chunks get shorter so that more lanes share them
-                        const size_t cap = std::min<size_t>(8, std::max<size_t>(1, (bp2.size() + 63) / 64));
-                        auto pad = [&]() { while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF); };
+                        const size_t cap = std::min<size_t>(8, std::max<size_t>(1, (n_pairs + 63) / 64));
                         size_t in_chunk = 0;
-                        for (size_t i = 0; i < bp2.size(); ++i) {
-                            if (i && (bp2[i].first != bp2[i - 1].first || in_chunk == cap)) { pad(); in_chunk = 0; }
-                            F.pairs.push_back(bp2[i].second); ++in_chunk;
+                        for (size_t i = 0; i < n_pairs; ++i) {
+                            if (i && (key_at(i) != key_at(i - 1) || in_chunk == cap)) { while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF); in_chunk = 0; }
+                            F.pairs.push_back(pair_at(i)); ++in_chunk;
                         }
-                        pad();
-                        F.cost.push_back(2000.0 + 20.0 * in_batch + 30.0 * (double)bp2.size());      // rough cycles: Jacobians + pair products (64 lanes share them)
-                        bp2.clear();
-                        F.b_obs_start.push_back((int32_t)(F.pobs.size() / 4)); F.b_run_start.push_back((int32_t)(F.pairs.size() / 8));
+                        while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF);
+                    };
+                    auto close_batch = [&](int pt_end) {
+                        if (in_batch == 0) return;
+                        int single_fmt = 0;
+                        if (uniform) {
+                            // the usual case: G points with the same k poses -> pairs in (a, b) position order are already grouped by block, blocks ascending
+                            const int G = pt_end - batch_first, k = batch_k, j0 = fp_start[pts[batch_first].second];
+                            int a0 = 0;
+                            while (a0 < k && fp_f[j0 + a0] < r0) ++a0;
+                            const size_t n_pairs = (size_t)G * ((size_t)k * (k + 1) / 2 - (size_t)a0 * (a0 + 1) / 2);
+                            const size_t cap = std::min<size_t>(8, std::max<size_t>(1, (n_pairs + 63) / 64));
+                            single_fmt = n_pairs <= 64 ? (int)n_pairs : 0;
+                            for (int a = a0; a < k; ++a)
+                                for (int b2 = 0; b2 <= a; ++b2) {
+                                    if (single_fmt) { for (int gp = 0; gp < G; ++gp) F.pairs.push_back((uint16_t)((gp * k + a) | ((gp * k + b2) << 8))); continue; }
+                                    size_t in_chunk = 0;
+                                    for (int gp = 0; gp < G; ++gp) {
+                                        if (in_chunk == cap) { while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF); in_chunk = 0; }
+                                        F.pairs.push_back((uint16_t)((gp * k + a) | ((gp * k + b2) << 8))); ++in_chunk;
+                                    }
+                                    while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF);
+                                }
+                        } else {
+                            bp2.clear();
+                            int base = 0;
+                            for (int q = batch_first; q < pt_end; ++q) {
+                                const int l = pts[q].second, j0 = fp_start[l];
+                                int kk = 0;
+                                while (j0 + kk < fp_start[l + 1] && fp_f[j0 + kk] < r1) ++kk;
+                                for (int a = 0; a < kk; ++a) {
+                                    const int fa = fp_f[j0 + a];
+                                    if (fa < r0) continue;
+                                    for (int b2 = 0; b2 < kk; ++b2)
+                                        if (fp_f[j0 + b2] <= fa) bp2.emplace_back((fa << 16) | fp_f[j0 + b2], (uint16_t)((base + a) | ((base + b2) << 8)));
+                                }
+                                base += kk;
+                            }
+                            std::stable_sort(bp2.begin(), bp2.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                            single_fmt = bp2.size() <= 64 ? (int)bp2.size() : 0;
+                            if (single_fmt) for (const auto &e : bp2) F.pairs.push_back(e.second);
+                            else emit_chunks(bp2.size(), [&](size_t i) { return bp2[i].second; }, [&](size_t i) { return bp2[i].first; });
+                        }
+                        while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF);
+                        F.b_fmt.push_back(single_fmt);
+                        F.b_obs_start.push_back((int32_t)(F.pobs.size() / 4)); F.b_run_start.push_back((int32_t)F.pairs.size());
                         in_batch = 0;
                     };
-                    for (const Pt &q : pts) {
-                        const int kk = (int)q.o.size();
-                        if (in_batch + kk > FS_OB) close_batch();
-                        const int base = in_batch;
-                        for (int a = 0; a < kk; ++a) { F.pobs.push_back(q.o[a]); F.pobs.push_back(Q.obs_pose[q.o[a]]); F.pobs.push_back(q.l); F.pobs.push_back(q.f[a]); }
-                        for (int a = 0; a < kk; ++a) {
-                            if (q.f[a] < r0) continue;
-                            for (int b2 = 0; b2 < kk; ++b2)
-                                if (q.f[b2] <= q.f[a]) bp2.emplace_back((q.f[a] << 16) | q.f[b2], (uint16_t)((base + a) | ((base + b2) << 8)));
+                    for (int q = 0; q < (int)pts.size(); ++q) {
+                        const int l = pts[q].second, j0 = fp_start[l];
+                        int kk = 0;
+                        while (j0 + kk < fp_start[l + 1] && fp_f[j0 + kk] < r1) ++kk;
+                        if (in_batch + kk > FS_OB) close_batch(q);
+                        if (in_batch == 0) { uniform = true; batch_key = pts[q].first; batch_k = kk; batch_first = q; }
+                        else if (pts[q].first != batch_key || kk != batch_k) uniform = false;
+                        if (uniform && q > batch_first) {                 // equal signatures: make sure the sets really are equal (the key holds a 24-bit hash)
+                            const int jb = fp_start[pts[batch_first].second];
+                            for (int a = 0; a < kk; ++a) if (fp_f[j0 + a] != fp_f[jb + a]) { uniform = false; break; }
                         }
+                        for (int a = 0; a < kk; ++a) { const int o = fp_o[j0 + a]; F.pobs.push_back(o); F.pobs.push_back(Q.obs_pose[o]); F.pobs.push_back(l); F.pobs.push_back(fp_f[j0 + a]); }
                         in_batch += kk;
                     }
-                    close_batch();
+                    close_batch((int)pts.size());
                     F.batch_start.push_back((int32_t)F.b_obs_start.size() - 1);
-                    {   // the pass's batches in NW contiguous ranges of about equal cost
-                        const int b0 = F.batch_start[ps], b1 = F.batch_start[ps + 1];
-                        double tot = 0;
-                        for (int b2 = b0; b2 < b1; ++b2) tot += F.cost[b2];
-                        double run_c = 0; int w = 1;
-                        F.wave_b.push_back(b0);
-                        for (int b2 = b0; b2 < b1 && w < NW; ++b2) {
-                            run_c += F.cost[b2];
-                            while (w < NW && run_c >= tot * w / NW) { F.wave_b.push_back(b2 + 1); ++w; }
-                        }
-                        while (w++ < NW) F.wave_b.push_back(b1);
-                        F.wave_b.push_back(b1);
-                    }
                 }
-                F.b_obs_start.push_back(F.b_obs_start.back());                   // the prefetch of "the next batch" may look one entry further
+                F.b_obs_start.push_back(F.b_obs_start.back());
             }
         }
         {   // windowed Cholesky (cholesky_window): active 16-row blocks per panel, LDS slots, tiles entering per panel
             const int np = R.np_free, n6i = 6 * np, nblk = (n6i + 15) / 16;
-            std::vector<int> first(np);
-            for (int f = 0; f < np; ++f) first[f] = R.fs_cs.empty() ? 0 : R.fs_cs[f] / 6;
             std::vector<int> ent(nblk, 0);
             for (int b = 0; b < nblk; ++b) {
                 int e = n6i;
@@ -1870,8 +1927,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int set = 0; set < 2; ++set) {
             const FsHost &F = R.fs[set];
             O.fs_row0[set] = bump(4 * F.row0.size()); O.fs_row1[set] = bump(4 * F.row1.size()); O.fs_batch[set] = bump(4 * F.batch_start.size());
-            O.fs_bobs[set] = bump(4 * F.b_obs_start.size()); O.fs_brun[set] = bump(4 * F.b_run_start.size()); O.fs_pobs[set] = bump(4 * F.pobs.size());
-            O.fs_pairs[set] = bump(2 * F.pairs.size() + 16); O.fs_rowoff[set] = bump(4 * F.rowoff.size()); O.fs_yoff[set] = bump(4 * F.yoff.size()); O.fs_waveb[set] = bump(4 * F.wave_b.size());
+            O.fs_bobs[set] = bump(4 * F.b_obs_start.size()); O.fs_brun[set] = bump(4 * F.b_run_start.size()); O.fs_bfmt[set] = bump(4 * F.b_fmt.size()); O.fs_pobs[set] = bump(4 * F.pobs.size());
+            O.fs_pairs[set] = bump(2 * F.pairs.size() + 16); O.fs_rowoff[set] = bump(4 * F.rowoff.size()); O.fs_yoff[set] = bump(4 * F.yoff.size());
         }
         in_hi[p] = total;
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
@@ -1883,6 +1940,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
         O.bar = bump(256); O.red = bump(2 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
     }
+    const double tm1 = tm_now();
     ms_ba *B = new ms_ba();
     B->ctx = c; B->n = n; B->arena_bytes = total;
     if (hipMalloc(reinterpret_cast<void **>(&B->d_arena), total) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&B->d_probs), sizeof(BaProb) * n) != hipSuccess) {
@@ -1911,9 +1969,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int set = 0; set < 2; ++set) {
             const FsHost &F = R.fs[set];
             up(O.fs_row0[set], F.row0.data(), 4 * F.row0.size()); up(O.fs_row1[set], F.row1.data(), 4 * F.row1.size()); up(O.fs_batch[set], F.batch_start.data(), 4 * F.batch_start.size());
-            up(O.fs_bobs[set], F.b_obs_start.data(), 4 * F.b_obs_start.size()); up(O.fs_brun[set], F.b_run_start.data(), 4 * F.b_run_start.size());
+            up(O.fs_bobs[set], F.b_obs_start.data(), 4 * F.b_obs_start.size()); up(O.fs_brun[set], F.b_run_start.data(), 4 * F.b_run_start.size()); up(O.fs_bfmt[set], F.b_fmt.data(), 4 * F.b_fmt.size());
             up(O.fs_pobs[set], F.pobs.data(), 4 * F.pobs.size()); up(O.fs_pairs[set], F.pairs.data(), 2 * F.pairs.size());
-            up(O.fs_rowoff[set], F.rowoff.data(), 4 * F.rowoff.size()); up(O.fs_yoff[set], F.yoff.data(), 4 * F.yoff.size()); up(O.fs_waveb[set], F.wave_b.data(), 4 * F.wave_b.size());
+            up(O.fs_rowoff[set], F.rowoff.data(), 4 * F.rowoff.size()); up(O.fs_yoff[set], F.yoff.data(), 4 * F.yoff.size());
         }
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
         if (hipMemcpyAsync(B->d_arena + in_lo[p], stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -1941,11 +1999,14 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int set = 0; set < 2; ++set) {
             FsSet &F = H.fs[set];
             if (!R.fused) { std::memset(&F, 0, sizeof(F)); continue; }
+            if (set != R.fs_only) continue;
             F.n_pass = (int32_t)R.fs[set].row0.size();
             F.row0 = PTR(int32_t, fs_row0[set]); F.row1 = PTR(int32_t, fs_row1[set]); F.batch_start = PTR(int32_t, fs_batch[set]);
-            F.b_obs_start = PTR(int32_t, fs_bobs[set]); F.b_run_start = PTR(int32_t, fs_brun[set]); F.pobs = PTR(int32_t, fs_pobs[set]);
-            F.pairs = PTR(uint16_t, fs_pairs[set]); F.rowoff = PTR(int32_t, fs_rowoff[set]); F.yoff = PTR(int32_t, fs_yoff[set]); F.wave_b = PTR(int32_t, fs_waveb[set]);
+            F.b_obs_start = PTR(int32_t, fs_bobs[set]); F.b_run_start = PTR(int32_t, fs_brun[set]); F.b_fmt = PTR(int32_t, fs_bfmt[set]); F.pobs = PTR(int32_t, fs_pobs[set]);
+            F.pairs = PTR(uint16_t, fs_pairs[set]); F.rowoff = PTR(int32_t, fs_rowoff[set]); F.yoff = PTR(int32_t, fs_yoff[set]);
         }
+        if (R.fused) H.fs[1 - R.fs_only] = H.fs[R.fs_only];          // the set that was not built aliases the one that was
+        H.fused = R.fused ? 1 : 0;
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
         H.dinv = PTR(double, dinv);
         H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
@@ -1958,6 +2019,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         ms_ba_destroy(B);
         return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
     }
+    if (tm_on) std::fprintf(stderr, "ms_ba_create: prep %.3f ms, alloc+upload %.3f ms, arena %.1f MB\n", tm1 - tm0, tm_now() - tm1, total / 1e6);
     *out = B;
     return MS_OK;
 }
