@@ -1364,9 +1364,61 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += NT) P.y[i] = z[i];
+    // back substitution L^T x = z, panels in reverse, again in LDS: column p of L (the tiles this loop wrote out above) comes back one panel
+    // ahead of its use (double buffer in the tile area), a thread per (active block, column) forms L[b,p]^T x_b, wave 0 solves the 16 x 16
+    // triangle as a lane recurrence.  Two barriers per panel; the version that reads rows of S from L2 spent a third of the factorisation's time here.
+    MS_LDS double *part = tvec + 16;                          // [16 * W] partial dot products, then [2][16] reciprocal pivots
+    MS_LDS double *dv = part + 16 * W;
+    auto fetch_col = [&](int pnl, int buf) {
+        const int fa0 = act_start[pnl], fm = act_start[pnl + 1] - fa0;
+        for (int t = wave; t <= fm; t += NW) {
+            const int b = t == 0 ? pnl : (act[fa0 + t - 1] & 0xFFFF);
+            MS_LDS double *dst = tiles + (buf * W + t) * CT;
+            const int c = lane & 15, gc = 16 * pnl + c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = (lane >> 4) + 4 * k, gr = 16 * b + r;
+                dst[r * CT_LD + c] = (gr < n && gc < n && (t > 0 || c <= r)) ? Sg[(size_t)gr * n + gc] : 0.0;
+            }
+        }
+        if (wave == NW - 1 && lane < 16) dv[16 * buf + lane] = 16 * pnl + lane < n ? P.dinv[16 * pnl + lane] : 0.0;
+    };
+    __syncthreads();                                          // the last panel's stores to S are done (same workgroup: visible through L1 after the barrier's waitcnt)
+    if (nblk > 0) fetch_col(nblk - 1, 0);
     __syncthreads();
-    chol_back_substitute(P, (double *)z, tid, lane, wave);
+    for (int p = nblk - 1; p >= 0; --p) {
+        const int c0 = 16 * p, nb = min(16, n - c0), buf = (nblk - 1 - p) & 1;
+        const int a0 = act_start[p], m = act_start[p + 1] - a0;
+        if (p > 0) fetch_col(p - 1, buf ^ 1);
+        if (tid < 16 * m) {
+            const int t = 1 + (tid >> 4), c = tid & 15, b = act[a0 + t - 1] & 0xFFFF;
+            const MS_LDS double *T = tiles + (buf * W + t) * CT;
+            double sum = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int gr = 16 * b + r; if (gr < n) sum += T[r * CT_LD + c] * z[gr]; }
+            part[tid] = sum;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const MS_LDS double *T0 = tiles + (buf * W) * CT;
+            double rr = 0, di = 0, xk = 0, col[NB];
+            if (lane < nb) { rr = z[c0 + lane]; for (int t = 0; t < m; ++t) rr -= part[16 * t + lane]; di = dv[16 * buf + lane]; }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? T0[j * CT_LD + lane] : 0.0;       // L[c0 + j][c0 + lane], j > lane
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                if (j < nb) {                                  // uniform
+                    const double xj = readlane_d(rr, j) * readlane_d(di, j);
+                    if (lane == j) xk = xj;
+                    rr -= col[j] * xj;                         // col[j] is zero for lanes >= j
+                }
+            }
+            if (lane < nb) z[c0 + lane] = xk;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) P.dp[i] = z[i];
+    __syncthreads();
 }
 
 // The same factorisation for systems whose panel does not fit the LDS (more than kMaxFreePoses free poses: global bundle
@@ -1905,8 +1957,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 for (int b : active) if (b != pnl) R.cw_act.push_back(b | (R.cw_slot[b] << 16));
                 R.cw_act_start.push_back((int32_t)R.cw_act.size());
             }
-            const size_t need = ((size_t)W * W * CT + (size_t)((n6i + 15) & ~15) + 16 + 16) * sizeof(double);
-            R.cw_W = (R.fused && nblk < 65536 && W >= 1 && W < 256 && need <= kLdsBytes) ? W : 0;
+            if (W == 1) W = 2;                                               // the back substitution double-buffers a column (<= W tiles) in the W x W tile area
+            R.cw_W = (R.fused && nblk < 65536 && W >= 1 && W < 256 && ((size_t)W * W * CT + (size_t)((n6i + 15) & ~15) + 16 + 16 * (size_t)W + 32 + 16) * sizeof(double) <= kLdsBytes) ? W : 0;
         }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
