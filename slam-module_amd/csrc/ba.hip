@@ -479,8 +479,14 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) P.bl[3 * (size_t)l + a] = b[a];
     }
-    // per free pose: Hpp diagonal block + bp (one wave per pose, lanes over its observations)
-    for (int fp = gw; fp < P.np_free; fp += GW) {
+    // per free pose: Hpp diagonal block + bp (a wave per pose, lanes over its observations).  A team cuts every pose's observations into
+    // slices so that all its waves have work, adds the slices' sums with fp64 atomics, and lets the first waves take the SE3 edges at the
+    // same time (one wave per edge, ~27 k cycles each): both only ADD into Hpp / bp, so no barrier is needed between them.
+    const int edge_waves = T_ > 1 ? min(P.n_edge, GW / 2) : 0;
+    const int PW = GW - edge_waves, pw = gw - edge_waves;
+    const int n_slice = T_ > 1 ? max(1, min(8, PW / max(P.np_free, 1))) : 1;
+    for (int u = pw; pw >= 0 && u < P.np_free * n_slice; u += PW) {
+        const int fp = u / n_slice, sl = u - fp * n_slice;
         const int pi = P.free2pose[fp];
         double pose[7];
 #pragma unroll
@@ -490,8 +496,9 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         for (int a = 0; a < 21; ++a) A[a] = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) g[a] = 0;
-        const int iend = P.fstart[fp + 1];
-        int ii = P.fstart[fp] + lane, o1, l1;
+        const int f_lo = P.fstart[fp], f_len = P.fstart[fp + 1] - f_lo;
+        const int iend = f_lo + (int)((long long)f_len * (sl + 1) / n_slice);
+        int ii = f_lo + (int)((long long)f_len * sl / n_slice) + lane, o1, l1;
         PoseObs cur;
         poseobs_idx(P, ii, iend, o1, l1); poseobs_data(P, o1, l1, cur); poseobs_idx(P, ii + 64, iend, o1, l1);
         for (; ii < iend; ii += 64) {
@@ -521,12 +528,16 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         if (lane == 0) {
             int k = 0;
             for (int a = 0; a < 6; ++a) {
-                P.bp[6 * fp + a] = g[a];
-                for (int b = a; b < 6; ++b) { P.Hpp[(size_t)(6 * fp + a) * n6 + 6 * fp + b] = A[k]; P.Hpp[(size_t)(6 * fp + b) * n6 + 6 * fp + a] = A[k]; ++k; }
+                if (T_ > 1) atomicAdd(&P.bp[6 * fp + a], g[a]); else P.bp[6 * fp + a] = g[a];
+                for (int b = a; b < 6; ++b) {
+                    if (T_ > 1) { atomicAdd(&P.Hpp[(size_t)(6 * fp + a) * n6 + 6 * fp + b], A[k]); if (b != a) atomicAdd(&P.Hpp[(size_t)(6 * fp + b) * n6 + 6 * fp + a], A[k]); }
+                    else { P.Hpp[(size_t)(6 * fp + a) * n6 + 6 * fp + b] = A[k]; P.Hpp[(size_t)(6 * fp + b) * n6 + 6 * fp + a] = A[k]; }
+                    ++k;
+                }
             }
         }
     }
-    team_sync(P);
+    if (T_ == 1) team_sync(P);
     // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior).  One workgroup: in rounds of 128, a LANE per edge evaluates it (error, both
     // 6x6 Jacobians; the edges of a round run side by side instead of one after another) and parks the result in LDS, then the
     // round's gradient entries (edge, side, a) and block entries (edge, side s, side t, a, b) of Js^T (W Jt) are spread over all threads,
@@ -534,7 +545,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     // A wave per edge (every lane computing the same edge) took 190 k cycles per linearisation at 49 edges -- as long as 20 k observations.
     if (T_ > 1) {     // a team: one WAVE per edge, the team's waves side by side (every lane evaluates the edge; lane (a, b) < 36 forms the block entries)
         MS_LDS double *slab = (MS_LDS double *)lds_ + (size_t)wave * (CH * 36);      // [Ji 36][Jj 36][W 36][We 6]
-        for (int k = gw; k < P.n_edge; k += GW) {
+        for (int k = gw; gw < edge_waves && k < P.n_edge; k += edge_waves) {
             const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
             if (fi < 0 && fj < 0) continue;                                       // wave-uniform
             double e[6], Ji[36], Jj[36];
@@ -1803,18 +1814,29 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             // ask for the other regime later): a batch that fills the chip always runs one workgroup per problem, a handful of windows
             // gets teams -- the same rule ms_ba_solve applies.
             const int max_team = std::max(1, std::min(kMaxTeam, c->n_cu / std::max(n, 1)));
-            R.fs_only = (max_team == 1 || std::min(32, std::max(1, Q.n_obs / 512)) == 1) ? 0 : 1;
+            const int pred_team = std::min(max_team, std::min(32, std::max(1, Q.n_obs / 512)));      // what ms_ba_solve picks on its own
+            R.fs_only = pred_team == 1 ? 0 : 1;
             for (int set = 0; set < 2 && ok; ++set) {
                 if (set != R.fs_only) continue;
                 FsHost &F = R.fs[set];
-                const int max_rows = set == 0 ? np : (np + 63) / 64;      // fine set: about one pose row per pass, at most 64 passes' worth per row group
+                // coarse set: as many rows per pass as the tile takes.  Fine set: one pass per workgroup of the team the launch will get, cut so that
+                // the passes carry about the same number of block products (a row's cost = its observations' partners on earlier poses: rows at the
+                // start of the window are cheap, and an even row count per pass left a third of the team waiting for the rest)
+                std::vector<double> rowcost(np, 1.0), cum(np + 1, 0.0);
+                if (set == 1)
+                    for (int l = 0; l < Q.n_point; ++l)
+                        for (int jj = fp_start[l]; jj < fp_start[l + 1]; ++jj) rowcost[fp_f[jj]] += 2.0 * (jj - fp_start[l] + 1);
+                for (int f = 0; f < np; ++f) cum[f + 1] = cum[f] + rowcost[f];
+                const int want_passes = set == 0 ? 1 : std::max(1, std::min(pred_team, np));
                 F.rowoff.assign(np, 0);
                 int r = 0;
                 while (r < np) {                                          // greedy row ranges under the tile budget
                     int r1 = r, used = 0;
-                    while (r1 < np && r1 - r < max_rows) {
+                    const double stop = set == 0 ? 1e300 : cum[np] * (double)(F.row0.size() + 1) / want_passes;
+                    while (r1 < np) {
                         const int need = 36 * (r1 - first[r1] + 1) + 6;
                         if (used + need > kFsTileDoubles) break;
+                        if (r1 > r && cum[r1 + 1] - 0.5 * rowcost[r1] > stop) break;
                         used += need; ++r1;
                     }
                     F.row0.push_back(r); F.row1.push_back(r1);

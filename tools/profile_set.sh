@@ -18,3 +18,12 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   echo "pmc $name done"
 done
 python3 "$R/tools/pmc_summary.py" "$O/pmc" "$O/pmc_traffic.json"
+# the local-BA launch (k_ba_lm) has passes of its own; its per-launch averages join the same file under kernels.k_ba_lm
+bash "$R/tools/pmc_ba.sh" "$O/pmc_ba.json" > "$O/pmc_ba.log" 2>&1 || true
+python3 - "$O/pmc_traffic.json" "$O/pmc_ba.json" <<'PY'
+import json, sys
+t = json.load(open(sys.argv[1])); b = json.load(open(sys.argv[2]))
+t["kernels"]["k_ba_lm"] = b
+json.dump(t, open(sys.argv[1], "w"), indent=1)
+print("merged k_ba_lm into", sys.argv[1])
+PY
