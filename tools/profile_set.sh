@@ -12,6 +12,10 @@ python3 "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err"
 echo "bench done"
 rocprofv3 --kernel-trace --stats -d "$O/stats" -o p --output-format csv -- python3 "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/rocprof.err"
 echo "stats done"
+# the same headline region alone (23 launches of every front-end kernel, all of them 256-frame batches): per-kernel averages that can be held
+# against the bench line's HIP-event times (the full command above also launches the kernels once per frame in its C5 leg)
+rocprofv3 --kernel-trace --stats -d "$O/stats_headline" -o p --output-format csv -- python3 "$R/bench.py" --only-headline > "$O/bench_headline_under_rocprof.json" 2>> "$O/rocprof.err"
+echo "headline stats done"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=$(echo "$grp" | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d "$O/pmc/$name" -o p --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --only-headline > /dev/null 2>> "$O/rocprof.err"

@@ -3,11 +3,12 @@ previous frame -> ratio test, and every 5th frame (a keyframe) one local bundle 
 batched across frames; the numbers are what a single backend thread driving the library would get."""
 import os, sys, time
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-for p in ("slam-module_amd", "oracle", "tests"): sys.path.insert(0, os.path.join(R, p))
-import numpy as np, mi355slam, mso, ba_synth
+for p in ("slam-module_amd", "tools", "tests"): sys.path.insert(0, os.path.join(R, p))
+import numpy as np, mi355slam, synth, ba_synth
 ctx = mi355slam.Context(0)
 W, H, N = 1280, 720, 64
-frames = np.stack([mso.synth_frame(W, H, 1000, 2 * i, i) for i in range(N)])
+g = synth.SequenceSynth(W, H, 1000, 2 * (N - 1), N - 1)
+frames = np.stack([g.frame(2 * i, i) for i in range(N)])
 buf = ctx.upload(frames)
 ex = [mi355slam.OrbExtractor(ctx, W, H, max_batch=1) for _ in range(2)]           # ping-pong: the previous frame's keypoints stay on the device
 views = [None, None]
