@@ -161,6 +161,33 @@ def test_unaligned_device_input_is_copied(oracle, ctx):
     _assert_same_keypoints(got, want)
 
 
+def test_keypoints_on_the_minimum_margin(oracle, ctx):
+    """Regression for the round-1 fault: a keypoint whose patch starts at the first byte of a plane.  Isolated bright pixels
+    at (19, 19), (w-20, 19), (19, h-20), (w-20, h-20) are FAST corners exactly on the 19-pixel margin (feature_detector.cpp:106-123): the
+    orientation / descriptor patches then begin at column / row 0 (negative offsets from the centre would address ~4 GiB past the slab).
+    Level 0 in the slab (host frames), used in place (aligned device frames) and through the device-side copy (odd stride)."""
+    import mi355slam
+    w, h = 320, 256
+    img = np.full((h, w), 30, np.uint8)
+    corners = [(19, 19), (w - 20, 19), (19, h - 20), (w - 20, h - 20), (100, 100), (160, 19)]
+    for x, y in corners:
+        img[y, x] = 250
+    cfg = oracle.cfg(levels=3, max_kpts=200)
+    want = oracle.orb_extract(cfg, img)
+    lvl0 = {(int(x), int(y)) for x, y, o in zip(want["x"], want["y"], want["octave"]) if o == 0}
+    assert set(corners) <= lvl0
+    ex = mi355slam.OrbExtractor(ctx, w, h, levels=3, max_kpts=200, max_batch=2)
+    ex.extract(np.stack([img, img]))                                  # host frames: level 0 copied into the slab
+    _assert_same_keypoints(ex.download(0), want); _assert_same_keypoints(ex.download(1), want)
+    buf = ctx.upload(np.stack([img, img]))
+    ex.extract(buf, n_frames=2, frame_stride=w * h, row_stride=w)     # aligned device frames: used in place as level 0
+    _assert_same_keypoints(ex.download(0), want); _assert_same_keypoints(ex.download(1), want)
+    padded = np.zeros((h, w + 5), np.uint8); padded[:, :w] = img
+    pb = ctx.upload(padded)
+    ex.extract(pb, n_frames=1, frame_stride=padded.size, row_stride=w + 5)     # odd stride: device-side copy
+    _assert_same_keypoints(ex.download(0), want)
+
+
 def test_extract_is_deterministic_across_runs(oracle, ctx):
     import mi355slam
     imgs = np.stack([oracle.synth_frame(640, 480, 2000 + i) for i in range(4)])
