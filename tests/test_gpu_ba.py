@@ -184,6 +184,35 @@ def test_team_barriers_hold_beside_a_saturating_front_end_batch(oracle):
     ba.close(); ca.close(); cb.close()
 
 
+def test_points_seen_by_more_than_64_keyframes_take_the_record_path(oracle, ctx):
+    """The fused Schur pass packs a point's observations into the 64 lanes of a wave; a window in which a point has more free observations
+    than that keeps the record-based path (Hpl / Y records, pose-pair segments, left-looking Cholesky).  Both paths must give the oracle's
+    result -- here in one batch: a 72-keyframe window whose points are seen by 70 consecutive keyframes next to an ordinary one -- and ragged
+    visibility (2 .. 40 observations per point, scattered over the window) must go through the fused path's sort-based batching."""
+    import mi355slam
+    wide = ba_synth.make_problem(72, 150, 70, seed=31)
+    assert np.bincount(wide["obs_point"]).max() == 70
+    rng = np.random.default_rng(5)
+    rag = ba_synth.make_problem(40, 500, 6, seed=32)
+    op, ol, uv, info = list(rag["obs_pose"]), list(rag["obs_point"]), list(rag["obs_uv"]), list(rag["obs_info"])
+    seen = set(zip(op, ol))
+    for l in range(0, 500, 3):                                        # every third point gets up to 34 more observations anywhere in the window
+        for i in rng.choice(40, size=int(rng.integers(1, 35)), replace=False):
+            q = ba_synth._R_from_quat(rag["gt_pose"][i, :4]) @ rag["gt_point"][l] + rag["gt_pose"][i, 4:]
+            if q[2] < 0.5 or (int(i), l) in seen: continue
+            seen.add((int(i), l)); op.append(int(i)); ol.append(l); uv.append(q[:2] / q[2] + rng.normal(0, 1 / 500, 2)); info.append(500.0 ** 2)
+    rag["obs_pose"], rag["obs_point"] = np.array(op, np.int32), np.array(ol, np.int32)
+    rag["obs_uv"], rag["obs_info"] = np.array(uv), np.array(info)
+    assert 30 < np.bincount(rag["obs_point"]).max() <= 40
+    probs = [wide, rag, ba_synth.make_problem(20, 300, 7, seed=33)]
+    want = [oracle.ba_solve(p, 8, False) for p in probs]
+    for team in (1, 4):
+        ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=8); ba.set_team(team); ba.solve()
+        for i, p in enumerate(probs):
+            _check(p, ba.download(i), want[i])
+        ba.close()
+
+
 def test_two_contexts_solve_with_teams_at_the_same_time(oracle):
     """SURVEY 8(b) threading: poseBundleAdjust on the front-end thread beside localBundleAdjust on the back-end thread
     (mapper.cpp:379-390 vs :268-269) = two handles on two contexts, both with teams whose grids together exceed the chip
