@@ -349,8 +349,9 @@ int ms_ba_set_team(ms_ba *ba, int workgroups_per_problem);
 int ms_ba_set_factor_team(ms_ba *ba, int workgroups);
 int ms_ba_solve(ms_ba *ba);
 /* Team launches (more than one workgroup per problem) synchronise their workgroups with spin barriers, which need every workgroup
- * of the launch resident: problems x team <= CUs is enforced, and the team launches of one process are chained per device (each
- * waits for the previous one, whichever context issued it), so two contexts -- the front end's poseBundleAdjust beside the back
+ * of the launch resident: problems x team <= CUs is enforced per launch, and the team launches of one process are admitted per device
+ * so that their workgroups together fit the CUs (a launch waits, on the device, for as many older ones of other contexts as it takes),
+ * so two contexts -- the front end's poseBundleAdjust beside the back
  * end's localBundleAdjust, mapper.cpp:379-390 vs :268-269 -- may solve at the same time.  If a barrier still gives up (no progress
  * for ~1 s: CUs held by another PROCESS), ms_ba_download repeats the solve with one workgroup per problem before it returns;
  * ms_ba_team_fallbacks counts those repeats.  ms_ba_debug_fail_team_barriers(ba, 1) makes every team barrier of the following

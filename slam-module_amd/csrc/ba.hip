@@ -1659,8 +1659,11 @@ struct ms_ba {
     int team_fallbacks = 0;            // launches repeated with one workgroup per problem after a team barrier gave up
 };
 
-static std::mutex g_team_mu;           // team launches of this process are chained per device (see ms_ba_solve)
-static hipEvent_t g_team_ev[64] = {nullptr};
+// Team launches of this process, per device: what is (or may still be) running, so that the workgroups of all concurrent team launches
+// together never exceed the CUs (see ms_ba_solve)
+struct TeamLaunch { hipEvent_t ev; hipStream_t stream; int wgs; bool live; };
+static std::mutex g_team_mu;
+static std::vector<TeamLaunch> g_team_live[64];
 #define MS_TRY_BA(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
 
 extern "C" {
@@ -2144,20 +2147,46 @@ int ms_ba_solve(ms_ba *B) {
     }
     // A plain launch: every workgroup needs more than half a CU's LDS and problems x team <= CUs, so all of a team's workgroups
     // become resident as soon as CUs are free.  What the spin barriers additionally need is that no OTHER team launch holds CUs
-    // while waiting for its own missing workgroups (two half-resident teams would wait for each other until the give-up): team
-    // launches of one process are therefore chained on one event per device -- each waits for the previous one, whatever stream
-    // (context) it came from.  Launches without a team (one workgroup per problem: every batch) are not chained.  A kernel of
-    // another stream that keeps CUs busy only delays the team; should a barrier still give up (~1 s without progress),
-    // ms_ba_download solves the batch again with one workgroup per problem.
+    // while waiting for its own missing workgroups (two half-resident teams would wait for each other until the give-up): the
+    // team launches of one process are therefore admitted per device so that the workgroups of all of them together fit the CUs --
+    // a new launch waits (on the device, through events) for as many of the oldest running ones of OTHER streams as it takes; eight
+    // 32-workgroup solves of eight contexts run side by side, two 160-workgroup ones run one after the other.  Launches without a
+    // team (one workgroup per problem: every batch) never wait for anything and are not counted.  A kernel of another stream that
+    // keeps CUs busy only delays a team; should a barrier still give up (~1 s without progress), ms_ba_download solves the batch
+    // again with one workgroup per problem.
     if (team > 1) {
         std::lock_guard<std::mutex> lk(g_team_mu);
-        hipEvent_t &ev = g_team_ev[c->device & 63];
-        if (!ev) MS_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        else MS_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+        std::vector<TeamLaunch> &live = g_team_live[c->device & 63];
+        const int need = B->n * team;
+        int in_use = 0;
+        for (TeamLaunch &t : live) {                                   // retire what has finished; launches of this stream precede the new one anyway
+            if (t.live && hipEventQuery(t.ev) == hipSuccess) t.live = false;
+            if (t.live && t.stream != c->stream) in_use += t.wgs;
+        }
+        for (TeamLaunch &t : live) {                                   // oldest first: wait (on the device) for as many as it takes to make room
+            if (in_use + need <= B->cus) break;
+            if (!t.live || t.stream == c->stream) continue;
+            MS_HIP(c, hipStreamWaitEvent(c->stream, t.ev, 0));
+            in_use -= t.wgs;
+        }
         hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, c->stream, B->d_probs, B->n, B->debug_fail_barriers);
         hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
         MS_KERNEL_CHECK(c, "k_ba_lm");
-        MS_HIP(c, hipEventRecord(ev, c->stream));
+        TeamLaunch *slot = nullptr;
+        for (TeamLaunch &t : live) if (!t.live) { slot = &t; break; }
+        if (!slot) {
+            if (live.size() >= 64) {                                   // (never in practice: 64 unfinished team launches) -- fall back to waiting for the oldest
+                MS_HIP(c, hipEventSynchronize(live.front().ev));
+                slot = &live.front();
+            } else {
+                live.push_back(TeamLaunch{nullptr, nullptr, 0, false});
+                slot = &live.back();
+                MS_HIP(c, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+            }
+        }
+        MS_HIP(c, hipEventRecord(slot->ev, c->stream));
+        slot->stream = c->stream; slot->wgs = need; slot->live = true;
+        if (slot != &live.back()) std::rotate(slot, slot + 1, &live.back() + 1);      // keep the list in launch order (oldest first)
     } else {
         hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
         MS_KERNEL_CHECK(c, "k_ba_lm");
