@@ -896,32 +896,71 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
             K[k].oy = __fmul_rn((float)K[k].y, g->L[level].scale);
         }
     }
-    // Both patches of the keypoint are first copied into the wave's LDS slab with coalesced row loads (31 rows x 32 B of the level,
-    // 39 rows x 40 B of its blurred twin: 11 wave-wide dword loads that touch ~120 cache lines), and the 16 moment samples and 8
-    // BRIEF samples of every lane are byte reads from LDS.  Gathered straight from memory the same samples were 24 byte loads that
-    // touch ~400 lines per keypoint, and the texture addresser's line rate, not HBM or latency, set the kernel's pace.
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescPerWave][32 * 32 + 39 * 40];
+    // ONE window of the (unblurred) level is copied into the wave's LDS slab with coalesced row loads: 45 rows x 48 B around the keypoint
+    // (x-23 .. x+24, y-22 .. y+22; 9 wave-wide dword loads).  It holds the 31 x 31 orientation patch (copied out once more with everything
+    // outside the radius-15 disc zeroed) AND everything the 39 x 39 BLURRED patch of the BRIEF tests depends on (19 + 3 pixels each way),
+    // so the blur (image_pyramid.cpp:84: 7 x 7, sigma 2, REFLECT_101) is computed here, for the patch only, with k_blur's own arithmetic --
+    // vertical pass on packed 16-bit lanes, horizontal pass with v_dot2 and one rounding -- and the blurred pyramid is no longer
+    // written and read back for every frame (2 P bytes and a 0.49 ms kernel per 256-frame step; round 1 fetched 31 x 32 B of the level plus
+    // 39 x 40 B of its blurred twin = 70 row pieces per keypoint, now 45).  k_blur still exists: ImagePyramid::getBlurredLevel runs it on demand.
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kDescPerWave][45 * 12 + 32 * 8 + 39 * 10];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
         int pitch;
         const uint8_t *img = level_ptr(src, g, f, K[k].oct, pitch);
-        const uint8_t *corner = img + (int64_t)(K[k].y - kHalfPatch) * pitch + (K[k].x - kHalfPatch);
-        uint32_t *pu = reinterpret_cast<uint32_t *>(&s_patch[wv][k][0]);
+        const int w = g->L[K[k].oct].w, h = g->L[K[k].oct].h, kx = K[k].x, ky = K[k].y;
+        uint32_t *win = &s_patch[wv][k][0], *pu = win + 45 * 12, *pb = pu + 32 * 8;
+        if (kx >= 23 && kx + 24 < w && ky >= 22 && ky + 22 < h) {          // wave-uniform: the whole window lies inside the level
+            const uint8_t *corner = img + (int64_t)(ky - 22) * pitch + (kx - 23);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                                   // 31 rows x 8 dwords, everything outside the radius-15 disc zeroed on the way
-            const int i = lane + 64 * t, r = i >> 3, c4 = i & 7;        // (the mask of the 32nd row is zero: it only pads the second half's 16 rows)
-            uint32_t v = 0;
-            if (i < 31 * 8) v = reinterpret_cast<const U32u *>(corner + (uint32_t)r * (uint32_t)pitch + 4u * c4)->v;
+            for (int t = 0; t < 9; ++t) {
+                const int i = lane + 64 * t, r = i / 12, c = i - 12 * r;
+                if (i < 45 * 12) win[i] = reinterpret_cast<const U32u *>(corner + (uint32_t)r * (uint32_t)pitch + 4u * c)->v;
+            }
+        } else {                                                          // a keypoint within 24 pixels of the border (a few per cent): BORDER_REFLECT_101 byte by byte
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                const int i = lane + 64 * t, r = i / 12, c = i - 12 * r;
+                if (i >= 45 * 12) break;
+                const uint8_t *row = img + (int64_t)reflect101(ky - 22 + r, h) * pitch;
+                uint32_t v = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) v |= (uint32_t)row[reflect101(kx - 23 + 4 * c + bb, w)] << (8 * bb);
+                win[i] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                                   // orientation patch: rows y-15 .. y+15 = window rows 7 .., columns x-15 .. = window dword 2 ..;
+            const int i = lane + 64 * t, r = i >> 3, c4 = i & 7;        // everything outside the radius-15 disc zeroed (the mask of the 32nd row is zero)
+            const uint32_t v = i < 31 * 8 ? win[(r + 7) * 12 + c4 + 2] : 0u;
             pu[i] = v & dmask[t];
         }
-        const int bp = g->L[K[k].oct].pitch;
-        const uint8_t *bcorner = blur_ptr(src, g, f, K[k].oct) + (int64_t)(K[k].y - kPatchRadius) * bp + (K[k].x - kPatchRadius);
-        uint32_t *pb = reinterpret_cast<uint32_t *>(&s_patch[wv][k][32 * 32]);
+        {   // blurred patch rows y-19 .. y+19 (output row ro <- window rows ro .. ro+6), columns x-19 .. x+19 = window bytes 4 .. 42.
+            // lane = 12 * rg + dc: dword column dc of the window, output rows 8 rg .. 8 rg + 7; neighbours dc +- 1 are lanes +- 1 (DPP)
+            const int rg = lane / 12, dc = lane - 12 * rg;
+            uint32_t e[14], o[14];
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {                                   // 39 rows x 10 dwords
-            const int i = lane + 64 * t, r = i / 10, c4 = i - 10 * r;
-            if (i < 39 * 10) pb[i] = reinterpret_cast<const U32u *>(bcorner + (uint32_t)r * (uint32_t)bp + 4u * c4)->v;   // the 40th byte (x + 20) is never sampled; it may be the next row's first
+            for (int r = 0; r < 14; ++r) {
+                const uint32_t d = win[min(8 * rg + r, 44) * 12 + dc];
+                e[r] = d & 0x00FF00FFu;
+                o[r] = (d >> 8) & 0x00FF00FFu;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t Ce = vsum7(e + j), Co = vsum7(o + j);            // columns (x, x+2) and (x+1, x+3) of the dword
+                const uint32_t Le = wave_from_prev(Ce), Lo = wave_from_prev(Co);
+                const uint32_t Re = wave_from_next(Ce), Ro = wave_from_next(Co);
+                uint32_t o0 = dot2(Lo, 18, 48, 32768u); o0 = dot2(Le, 0, 34, o0); o0 = dot2(Ce, 56, 34, o0); o0 = dot2(Co, 48, 18, o0);
+                uint32_t o1 = dot2(Le, 0, 18, 32768u); o1 = dot2(Lo, 0, 34, o1); o1 = dot2(Ce, 48, 48, o1); o1 = dot2(Co, 56, 34, o1); o1 = dot2(Re, 18, 0, o1);
+                uint32_t o2 = dot2(Lo, 0, 18, 32768u); o2 = dot2(Ce, 34, 56, o2); o2 = dot2(Co, 48, 48, o2); o2 = dot2(Re, 34, 0, o2); o2 = dot2(Ro, 18, 0, o2);
+                uint32_t o3 = dot2(Ce, 18, 48, 32768u); o3 = dot2(Co, 34, 56, o3); o3 = dot2(Re, 48, 18, o3); o3 = dot2(Ro, 34, 0, o3);
+                const int ro = 8 * rg + j;
+                if (lane < 60 && dc >= 1 && dc <= 10 && ro < 39)
+                    pb[ro * 10 + (dc - 1)] = (o0 >> 16) | ((o1 >> 16) << 8) | ((o2 >> 16) << 16) | ((o3 >> 16) << 24);
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -933,7 +972,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     float angle_deg[kDescPerWave], ca[kDescPerWave], sa[kDescPerWave];
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
-        const uint8_t *colp = &s_patch[wv][k][0] + half * (16 * 32) + col;
+        const uint8_t *colp = reinterpret_cast<const uint8_t *>(&s_patch[wv][k][45 * 12]) + half * (16 * 32) + col;
         int S = 0, J = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -959,7 +998,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
         const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
 #pragma unroll
         for (int k = 0; k < kDescPerWave; ++k) {
-            const uint8_t *pb = &s_patch[wv][k][32 * 32];
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(&s_patch[wv][k][45 * 12 + 32 * 8]);
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa[k]), __fmul_rn(y1, ca[k])));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca[k]), __fmul_rn(y1, sa[k])));
             const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa[k]), __fmul_rn(y2, ca[k])));
@@ -1007,6 +1046,7 @@ struct ms_orb {
     float4 *d_pattern_f = nullptr;            // k_describe: the 256 BRIEF point pairs as floats
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
+    bool blur_valid = false;           // the blurred planes of the slab hold the last batch (k_blur runs on demand only)
     hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
     // state of the last call
     FrameSrc last_src{};
@@ -1294,10 +1334,9 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         MS_KERNEL_CHECK(c, "k_resize");
     }
     MS_STAGE_MARK();
-    // (k_blur was tried on a second stream beside k_fast: no gain -- the detection kernel already fills the chip -- and
-    // overlapped launches have no well-defined per-kernel duration, so everything stays on the context stream.)
-    hipLaunchKernelGGL(k_blur, dim3(G.btiles_total, n_frames), dim3(256), 0, st, src, o->tile_levels, o->blur_tiles);
-    MS_KERNEL_CHECK(c, "k_blur");
+    // The blurred pyramid (image_pyramid.cpp:82-85) is not materialised per frame any more: its only consumer on the path, the BRIEF tests,
+    // blurs its own 39 x 39 patches inside k_describe.  ImagePyramid::getBlurredLevel (ms_orb_download_level) runs k_blur on demand.
+    o->blur_valid = false;
     MS_STAGE_MARK();
     hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_ftile_tab, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
@@ -1396,7 +1435,15 @@ int ms_orb_download_level(ms_orb *o, int frame, int level, int blurred, uint8_t 
     MS_HIP(c, hipStreamSynchronize(c->stream));
     const LevelGeom &L = o->geom.L[level];
     const uint8_t *p; size_t pitch;
-    if (blurred) { p = o->d_slab + (size_t)frame * o->geom.slab_stride + L.blur_off; pitch = L.pitch; }
+    if (blurred) {
+        if (!o->blur_valid) {                                  // the blurred levels of the last batch, computed when somebody asks for them
+            hipLaunchKernelGGL(k_blur, dim3(o->geom.btiles_total, o->last_frames), dim3(256), 0, c->stream, o->last_src, o->tile_levels, o->blur_tiles);
+            MS_KERNEL_CHECK(c, "k_blur");
+            MS_HIP(c, hipStreamSynchronize(c->stream));
+            o->blur_valid = true;
+        }
+        p = o->d_slab + (size_t)frame * o->geom.slab_stride + L.blur_off; pitch = L.pitch;
+    }
     else if (level == 0) { p = o->last_src.lvl0 + (size_t)frame * o->last_src.lvl0_frame_stride; pitch = o->last_src.lvl0_pitch; }
     else { p = o->d_slab + (size_t)frame * o->geom.slab_stride + L.img_off; pitch = L.pitch; }
     MS_HIP(c, hipMemcpy2D(dst, L.w, p, pitch, L.w, L.h, hipMemcpyDeviceToHost));
