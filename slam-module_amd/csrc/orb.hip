@@ -945,8 +945,8 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
 #pragma unroll
             for (int r = 0; r < 14; ++r) {
                 const uint32_t d = win[min(8 * rg + r, 44) * 12 + dc];
-                e[r] = d & 0x00FF00FFu;
-                o[r] = (d >> 8) & 0x00FF00FFu;
+                e[r] = __builtin_amdgcn_perm(0u, d, 0x0C020C00u);       // bytes 0, 2 as two 16-bit lanes (one op instead of and / shift + and)
+                o[r] = __builtin_amdgcn_perm(0u, d, 0x0C030C01u);       // bytes 1, 3
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
                 uint32_t o3 = dot2(Ce, 18, 48, 32768u); o3 = dot2(Co, 34, 56, o3); o3 = dot2(Re, 48, 18, o3); o3 = dot2(Ro, 34, 0, o3);
                 const int ro = 8 * rg + j;
                 if (lane < 60 && dc >= 1 && dc <= 10 && ro < 39)
-                    pb[ro * 10 + (dc - 1)] = (o0 >> 16) | ((o1 >> 16) << 8) | ((o2 >> 16) << 16) | ((o3 >> 16) << 24);
+                    pb[ro * 10 + (dc - 1)] = __builtin_amdgcn_perm(o1, o0, 0x0C0C0602u) | __builtin_amdgcn_perm(o3, o2, 0x06020C0Cu);   // byte 2 of each sum (the sums stay below 2^24)
             }
         }
     }
