@@ -1303,9 +1303,13 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
                                G.slab_stride, o->lvl0_off, G.width, G.height, o->lvl0_pitch);
             MS_KERNEL_CHECK(c, "k_copy_level0");
         } else {
-            for (int f = 0; f < n_frames; ++f)
-                MS_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * G.slab_stride, o->lvl0_pitch, images + (size_t)f * frame_stride, row_stride,
-                                           G.width, G.height, hipMemcpyHostToDevice, st));
+            for (int f = 0; f < n_frames; ++f) {
+                if (row_stride == (size_t)o->lvl0_pitch)            // rows as far apart on the host as in the slab: one linear copy per frame (the copy engines move these faster than pitched 2-D copies)
+                    MS_HIP(c, hipMemcpyAsync(dst + (size_t)f * G.slab_stride, images + (size_t)f * frame_stride, row_stride * (size_t)(G.height - 1) + G.width, hipMemcpyHostToDevice, st));
+                else
+                    MS_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * G.slab_stride, o->lvl0_pitch, images + (size_t)f * frame_stride, row_stride,
+                                               G.width, G.height, hipMemcpyHostToDevice, st));
+            }
         }
         src.lvl0 = dst; src.lvl0_frame_stride = G.slab_stride; src.lvl0_pitch = o->lvl0_pitch;
         o->lvl0_in_slab = true;
