@@ -41,8 +41,8 @@ N_SEQ = 8                      # C5: independent sequences of the whole job
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
@@ -435,7 +435,7 @@ def run_gpu(R, args):
         def pcie_leg():
             # PCIe-inclusive: frames start in pinned HOST memory, keypoints + descriptors end in host memory
             hl.set_frames(frames_np)
-            return pcie_inclusive(R, hl, frames_np, max(args.steps // 4, 2))
+            return pcie_inclusive(R, hl, frames_np, max(min(args.steps // 4, 12), 2))
         leg("sparse_input", sparse_leg)
         leg("value_pcie_inclusive", pcie_leg)
     # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 distinct windows per launch, device-resident ----
