@@ -88,3 +88,28 @@ def test_ba_degenerate_problems(ctx, oracle):
     z = mi355slam.BundleAdjuster(ctx, [p], max_iters=0); z.solve()
     out = z.download(0)
     assert out["stats"]["iters"] == 0 and np.allclose(out["pose"], p["pose"]) and out["stats"]["chi2_final"] == pytest.approx(out["stats"]["chi2_init"])
+
+
+def test_round2_entry_points_check_their_arguments(ctx, oracle):
+    """ms_keypoints_pack, ms_hamming_set_path (per context since round 2), the team test hooks: bad arguments give a status, nothing is written."""
+    import mi355slam
+    L = mi355slam.lib()
+    assert L.ms_hamming_set_path(ctx._h, 2) == -1 and L.ms_hamming_set_path(None, 0) == -1 and L.ms_hamming_set_path(ctx._h, 0) == 0
+    other = mi355slam.Context(0)
+    other.set_hamming_path(1)                                                # one context's choice does not leak into another
+    q = np.random.default_rng(1).integers(0, 2**32, (300, 8), dtype=np.uint64).astype(np.uint32)
+    a, b = mi355slam.hamming_best2(ctx, q, q[::-1].copy()), mi355slam.hamming_best2(other, q, q[::-1].copy())
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    other.close()
+    ex = mi355slam.OrbExtractor(ctx, 640, 480, max_batch=1)
+    ex.extract(oracle.synth_frame(640, 480, 9)[None])
+    v = ex.device_view()
+    out = np.full((4, 76), 0xAB, np.uint8)
+    assert L.ms_keypoints_pack(ctx._h, C.byref(v), 0, ex.capacity + 1, None, out.ctypes.data_as(C.c_void_p)) == -1      # more than the view holds
+    assert L.ms_keypoints_pack(ctx._h, C.byref(v), -1, 4, None, out.ctypes.data_as(C.c_void_p)) == -1
+    assert L.ms_keypoints_pack(ctx._h, C.byref(v), 0, 4, None, None) == -1
+    assert (out == 0xAB).all()
+    assert L.ms_keypoints_pack(ctx._h, C.byref(v), 0, 0, None, None) == 0                                                  # nothing to pack is fine
+    assert L.ms_keypoints_unpack(None, 3, None, None, None, None, None, None) == -1
+    assert L.ms_ba_team_fallbacks(None) == -1 and L.ms_ba_debug_fail_team_barriers(None, 1) == -1
