@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -97,7 +98,7 @@ struct BaProb {
     FsSet fs[2];
     int32_t fused;                           // 1: schur_fused / point_backsub_fused (no Hpl / Y records exist); 0: the record-based path
     // windowed Cholesky (cholesky_window): the active front of the factorisation as W x W tiles of 16 x 16 in LDS; 0 = front too wide
-    int32_t cw_W;
+    int32_t cw_W, cw_zglobal;                // tiles per side of the window; 1: the rhs vector stays in global memory (it does not fit the LDS beside the tiles)
     const int32_t *cw_slot;                  // [nblk] LDS slot (row and column index in the tile grid) of 16-row block b while it is active
     const int32_t *cw_act_start, *cw_act;    // per panel p: the other active blocks (block | slot << 16), ascending
     const int32_t *cw_load_start, *cw_load;  // per panel p: tiles that enter the window (bi | si << 16, bj | sj << 16)
@@ -1232,17 +1233,21 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
 // (v_mfma_f64_16x16x4_f64, operands from LDS), and written once when its column is factored.  The rhs is forward-substituted along.
 constexpr int CT_LD = 18;                 // doubles per tile row (16 + 2: the 32-byte operand reads of 16 rows fall into different banks)
 constexpr int CT = 16 * CT_LD;            // doubles per tile
+template <bool ZG>   // ZG: the rhs / solution vector stays in global memory (P.y): systems whose n doubles do not fit the LDS beside the tiles (global BA of a long trajectory)
 __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6, W = P.cw_W, nblk = (n + 15) / 16;
     MS_LDS double *tiles = (MS_LDS double *)lds_;
-    MS_LDS double *z = tiles + W * W * CT;                    // [n] rhs, becomes L^-1 y
-    MS_LDS double *tvec = z + ((n + 15) & ~15);               // [16] reciprocal pivots of the current panel
+    typedef typename std::conditional<ZG, MS_GLOBAL double *, MS_LDS double *>::type zptr_t;
+    zptr_t z;                                                 // [n] rhs, becomes L^-1 y, then the solution
+    MS_LDS double *tvec;                                      // [16] reciprocal pivots of the current panel
+    if constexpr (ZG) { z = (MS_GLOBAL double *)P.y; tvec = tiles + W * W * CT; }
+    else { z = tiles + W * W * CT; tvec = z + ((n + 15) & ~15); }
     const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S;
     MS_GLOBAL double *Sw = (MS_GLOBAL double *)P.S;
     const MS_GLOBAL int32_t *slot = (const MS_GLOBAL int32_t *)P.cw_slot, *act_start = (const MS_GLOBAL int32_t *)P.cw_act_start, *act = (const MS_GLOBAL int32_t *)P.cw_act,
                             *load_start = (const MS_GLOBAL int32_t *)P.cw_load_start, *loads = (const MS_GLOBAL int32_t *)P.cw_load;
-    for (int i = tid; i < n; i += NT) z[i] = P.y[i];
+    if constexpr (!ZG) for (int i = tid; i < n; i += NT) z[i] = P.y[i];
     auto fetch_tiles = [&](int pnl) {                         // tiles entering the window at panel pnl: S -> LDS, one tile per wave and trip (waves 1..7; wave 0 factors)
         for (int e = load_start[pnl] + wave - 1; e < load_start[pnl + 1]; e += NW - 1) {
             const int ea = loads[2 * e], eb = loads[2 * e + 1], bi = ea & 0xFFFF, si = ea >> 16, bj = eb & 0xFFFF, sj = eb >> 16;
@@ -1529,7 +1534,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     }
     { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
     if (P.cw_W > 0) {                                  // the active front fits the LDS: right-looking, one workgroup (banded systems of any size)
-        if (lead) cholesky_window(P, lds);
+        if (lead) { if (P.cw_zglobal) cholesky_window<true>(P, lds); else cholesky_window<false>(P, lds); }
     } else if (P.panG) {                               // too large for an LDS panel: factor across the team, substitute back in one workgroup
         cholesky_factor_team(P, lds);
         if (lead) chol_back_substitute(P, lds, threadIdx.x, threadIdx.x & 63, threadIdx.x >> 6);
@@ -1677,7 +1682,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     const double tm0 = tm_now();
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; };
-    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
+    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
@@ -1983,7 +1988,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 R.cw_act_start.push_back((int32_t)R.cw_act.size());
             }
             if (W == 1) W = 2;                                               // the back substitution double-buffers a column (<= W tiles) in the W x W tile area
-            R.cw_W = (R.fused && nblk < 65536 && W >= 1 && W < 256 && ((size_t)W * W * CT + (size_t)((n6i + 15) & ~15) + 16 + 16 * (size_t)W + 32 + 16) * sizeof(double) <= kLdsBytes) ? W : 0;
+            const size_t fixed = ((size_t)W * W * CT + 16 + 16 * (size_t)W + 32 + 16) * sizeof(double), zbytes = (size_t)((n6i + 15) & ~15) * sizeof(double);
+            const bool fits = R.fused && nblk < 65536 && W >= 1 && W < 256;
+            R.cw_W = fits && fixed <= kLdsBytes ? W : 0;
+            R.cw_zglobal = fixed + zbytes > kLdsBytes;                       // a long trajectory: the tiles fit, the 8 n bytes of the rhs do not -- it stays in global memory
         }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
@@ -2071,7 +2079,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.env16 = PTR(int32_t, env16);
         H.act_start = PTR(int32_t, act_start); H.act_blk = PTR(int32_t, act_blk);
         H.fs_cs = PTR(int32_t, fs_cs);
-        H.cw_W = R.cw_W; H.cw_slot = PTR(int32_t, cw_slot); H.cw_act_start = PTR(int32_t, cw_act_start); H.cw_act = PTR(int32_t, cw_act);
+        H.cw_W = R.cw_W; H.cw_zglobal = R.cw_zglobal ? 1 : 0; H.cw_slot = PTR(int32_t, cw_slot); H.cw_act_start = PTR(int32_t, cw_act_start); H.cw_act = PTR(int32_t, cw_act);
         H.cw_load_start = PTR(int32_t, cw_load_start); H.cw_load = PTR(int32_t, cw_load);
         for (int set = 0; set < 2; ++set) {
             FsSet &F = H.fs[set];
