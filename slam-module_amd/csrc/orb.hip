@@ -1151,7 +1151,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     int rc = MS_OK;
     auto A = [&](int r) { if (rc == MS_OK) rc = r; };
     A(dev_calloc(ctx, &o->d_geom, 1));
-    A(dev_calloc(ctx, &o->d_slab, B * G.slab_stride + 256));   // + slack: k_describe copies 40-byte patch rows whose last (unused) byte may lie one past a plane
+    A(dev_calloc(ctx, &o->d_slab, B * G.slab_stride + 256));   // + slack (round 1's k_describe could touch one byte past the last plane; today's window loads stay inside the level)
     A(dev_calloc(ctx, &o->d_cand, B * G.cand_stride));
     A(dev_calloc(ctx, &o->d_cand_count, B * MS_MAX_LEVELS));
     A(dev_calloc(ctx, &o->d_det_count, B * MS_MAX_LEVELS));
