@@ -360,10 +360,10 @@ __global__ __launch_bounds__(256) void k_blur(FrameSrc src, TileLevels TL, TileM
 // five barriers, one returning atomic per tile), not ALU-bound, and needs the occupancy.
 //   phase A1  compass pre-test on EVERY position, in registers, two pixels per instruction: a lane owns
 //             one dword (4 pixels) of a row, the even/odd bytes are two 16-bit lanes; the sign bits of
-//             (centre+t - ring) and (ring - (centre-t)) are counted for the ring pixels N, S, E, W.
-//             An arc of 9 contiguous ring pixels always covers two of those four, so a pixel with fewer
-//             than two brighter AND fewer than two darker compass pixels cannot be a corner (exact
-//             reject).  Survivors are compacted into an LDS list.
+//             (centre+t - ring) and (ring - (centre-t)) are formed for the ring pixels N, S, E, W.
+//             An arc of 9 contiguous ring pixels always covers N or S and E or W (see compass_pass), so a
+//             pixel without a brighter pixel in each opposite pair AND without a darker one in each cannot
+//             be a corner (exact reject).  Survivors are compacted into an LDS list.
 //   phase A2  dense over the survivors: the FAST score itself (max over the 16 arcs of 9 of min(c-r) / min(r-c)) on packed
 //             16-bit lanes (two ring pixels per v_pk_min/max_i16), ring bytes through the vector cache; a pixel is a
 //             corner iff score > threshold, so no separate mask test is needed; scores go to the LDS score tile
@@ -389,9 +389,11 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) {      // number of
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b))); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b))); }
 __device__ __forceinline__ uint32_t compass_pass(uint32_t n, uint32_t s_, uint32_t e, uint32_t w, uint32_t hi, uint32_t lo) {
+    // Round 2: a tighter exact reject for two operations less.  The complement of an arc of 9 is an arc of 7, which cannot hold two ring
+    // pixels that are 8 apart: every arc of 9 contains N or S, and E or W.  So a brighter corner needs max(N, S) > c + t AND max(E, W) > c + t
+    // (a darker one min(N, S) < c - t AND min(E, W) < c - t) -- one pixel from EACH opposite pair, not any two of the four.
     const uint32_t a = pk_max(n, s_), b = pk_min(n, s_), c = pk_max(e, w), d = pk_min(e, w);
-    const uint32_t p = pk_min(a, c), q = pk_max(b, d);                    // the two middle values of the four
-    return pk_sub(hi, pk_max(p, q)) | pk_sub(pk_min(p, q), lo);
+    return pk_sub(hi, pk_min(a, c)) | pk_sub(pk_max(b, d), lo);
 }
 
 // FAST score = max over the 16 arcs of 9 of min(c - r) and of min(r - c), on packed 16-bit lanes: P[k] = (d[k], d[k+8]) with
