@@ -367,7 +367,7 @@ __device__ __noinline__ double team_reduce(const BaProb &P, double v, double *s_
     const double b = is_max ? block_max(v, s_red) : block_sum(v, s_red);
     if (P.team == 1) return b;
     const int T = P.team, rank = (int)(blockIdx.x % (unsigned)T);
-    double *slot = P.red + (size_t)(seq & 1) * T;
+    double *slot = P.red + (size_t)(seq & 1) * 2 * T;
     ++seq;
     if (threadIdx.x == 0) slot[rank] = b;
     team_sync(P);
@@ -376,8 +376,23 @@ __device__ __noinline__ double team_reduce(const BaProb &P, double v, double *s_
     return t;
 }
 
+// Two sums over the team behind ONE barrier (the robust chi2 of the new state and the step's gain denominator are needed together)
+__device__ __noinline__ double team_reduce2(const BaProb &P, double v1, double v2, double *s_red, int &seq, double &out2) {
+    const double b1 = block_sum(v1, s_red), b2 = block_sum(v2, s_red);
+    if (P.team == 1) { out2 = b2; return b1; }
+    const int T = P.team, rank = (int)(blockIdx.x % (unsigned)T);
+    double *slot = P.red + (size_t)(seq & 1) * 2 * T;
+    ++seq;
+    if (threadIdx.x == 0) { slot[rank] = b1; slot[T + rank] = b2; }
+    team_sync(P);
+    double t1 = slot[0], t2 = slot[T];
+    for (int r = 1; r < T; ++r) { t1 += slot[r]; t2 += slot[T + r]; }
+    out2 = t2;
+    return t1;
+}
+
 // robust chi2 of the current state (activeRobustChi2); optionally stores the plain chi2 per observation
-__device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool store, int &seq) {
+__device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool store, int &seq, double extra = 0.0, double *extra_sum = nullptr) {
     const BaProb &P = P_;
     double *s_red = s_red_;
     BA_IDS
@@ -397,6 +412,7 @@ __device__ __noinline__ double eval_chi2(const BaProb &P_, double *s_red_, bool 
         const double *W = P.edge_info + 36 * (size_t)k;
         for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) acc += e[i] * W[6 * i + j] * e[j];
     }
+    if (extra_sum) return team_reduce2(P, acc, extra, s_red, seq, *extra_sum);     // a second, unrelated sum rides on the same barrier
     return team_reduce(P, acc, s_red, false, seq);
 }
 
@@ -1523,8 +1539,7 @@ __device__ __noinline__ void point_backsub(const BaProb &P_) {
 __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long long *cyc) {
     long long t0 = clock64();
     const bool lead = P.team == 1 || blockIdx.x % (unsigned)P.team == 0;
-    if (lead && threadIdx.x == 0) P.flag[0] = 1;
-    team_sync(P);
+    // P.flag[0] ("this damped solve is sound") is 1 on entry: the caller sets it behind a barrier that every reader of the previous value has passed
     const bool fused = P.fused != 0;
     if (fused) schur_fused(P, lambda, lds, cyc);
     else {
@@ -1565,6 +1580,7 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     // restart from the initial estimates
     for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose0[i];
     for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] = P.point0[i];
+    if (gt == 0) P.flag[0] = 1;
     team_sync(P);
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, stop = 0;
@@ -1595,6 +1611,10 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
             for (int i = gt; i < 3 * P.n_point; i += GT) P.point_bk[i] = P.point[i];
             const bool ok2 = solve_step(P, lambda, lds, cyc);
             tt = clock64();
+            // re-arm the flag for the next damped solve: on the good path every workgroup has read it before point_backsub's barrier; on the
+            // (rare) failed path an extra barrier separates the reads from the write.  The barriers that follow order it before the next solve's phases.
+            if (!ok2) team_sync(P);
+            if (gt == 0) P.flag[0] = 1;
             if (ok2) {
                 for (int fp = gt; fp < P.np_free; fp += GT) {
                     const int pi = P.free2pose[fp];
@@ -1607,14 +1627,14 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
                 team_sync(P);
             }
             cyc[4] += clock64() - tt; tt = clock64();
-            temp = ok2 ? eval_chi2(P, s_red, false, seq) : DBL_MAX;
-            cyc[0] += clock64() - tt;
-            double sc = 0;
+            double sc = 0, scale = 0;
             if (ok2) {
                 for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
                 for (int i = gt; i < 3 * P.n_point; i += GT) sc += P.dl[i] * (lambda * P.dl[i] + P.bl[i]);
             }
-            const double scale = team_reduce(P, sc, s_red, false, seq) + 1e-3;
+            temp = ok2 ? eval_chi2(P, s_red, false, seq, sc, &scale) : DBL_MAX;     // chi2 of the new state and the gain denominator behind one team barrier
+            scale += 1e-3;
+            cyc[0] += clock64() - tt;
             rho = (current - temp) / scale;
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
@@ -2023,7 +2043,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.Y = bump(R.fused ? 8 : 18 * ((size_t)Q.n_obs + 1) * D); O.zrow = bump((n6 + 16) * D);
         O.dinv = bump((n6 + 16) * D);
         O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
-        O.bar = bump(256); O.red = bump(2 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
+        O.bar = bump(256); O.red = bump(4 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
     }
     const double tm1 = tm_now();
     ms_ba *B = new ms_ba();
