@@ -112,7 +112,10 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out);
 void ms_orb_destroy(ms_orb *orb);
 
 /* Optional camera validity mask (stand-in for tracker::Camera::isValidPixel, orb_extractor.cpp:101,
- * :231): width*height bytes in host memory, 0 = invalid.  NULL clears it (all pixels valid). */
+ * :231): width*height bytes in host memory, 0 = invalid.  NULL clears it (all pixels valid).  The mask is sampled at the
+ * rounded level-0 position of a keypoint; the reference evaluates the camera model at the sub-pixel position, so the two can
+ * differ at the rim of the valid region.  host/mi355slam/orb_extractor.hpp's predicate overload of detectAndExtract applies the
+ * model itself to the output coordinates and reproduces the reference exactly. */
 int ms_orb_set_valid_mask(ms_orb *orb, const uint8_t *mask_host);
 
 /* detectAndExtract for a batch of frames.

@@ -8,6 +8,7 @@
 // Same call shape, same output order (tracker points first, then level-major), same early return on zero keypoints;
 // pyramid + detector are built lazily on the first frame like orb_extractor.cpp:80-81.
 #pragma once
+#include <functional>
 #include "common.hpp"
 
 namespace mi355slam {
@@ -17,6 +18,22 @@ struct OrbExtractor {
     virtual void detectAndExtract(const ImageView &img, const std::uint8_t *cameraValidMask,
                                   const std::vector<TrackPoint> &tracks, KeyPointVector &keyPoints,
                                   std::vector<int> &keyPointTrackIds) = 0;
+    // The same call with the camera model itself: isValidPixel(x, y) is evaluated on the host at exactly the sub-pixel positions the reference
+    // passes to tracker::Camera::isValidPixel -- pt.x, pt.y of a tracker point (orb_extractor.cpp:101) and kp.pt.x * scale, kp.pt.y * scale of a
+    // detected corner (:231), the same float32 products the output carries (:153-162) -- so the surviving set equals the reference's at the rim of
+    // the valid region too.  Dropping after description instead of before changes nothing: no later step depends on the dropped points.
+    void detectAndExtract(const ImageView &img, const std::function<bool(float, float)> &isValidPixel,
+                          const std::vector<TrackPoint> &tracks, KeyPointVector &keyPoints, std::vector<int> &keyPointTrackIds) {
+        detectAndExtract(img, static_cast<const std::uint8_t *>(nullptr), tracks, keyPoints, keyPointTrackIds);
+        if (!isValidPixel) return;
+        std::size_t n = 0;
+        for (std::size_t i = 0; i < keyPoints.size(); ++i)
+            if (isValidPixel(keyPoints[i].pt.x, keyPoints[i].pt.y)) { keyPoints[n] = keyPoints[i]; keyPointTrackIds[n] = keyPointTrackIds[i]; ++n; }
+        keyPoints.resize(n); keyPointTrackIds.resize(n);
+    }
+    void detectAndExtract(const ImageView &img, std::nullptr_t, const std::vector<TrackPoint> &tracks, KeyPointVector &keyPoints, std::vector<int> &keyPointTrackIds) {
+        detectAndExtract(img, static_cast<const std::uint8_t *>(nullptr), tracks, keyPoints, keyPointTrackIds);     // every pixel valid
+    }
     // ImagePyramid::getLevel / getBlurredLevel (image_pyramid.hpp:24-25): CPU-readable copy of one level
     virtual std::vector<std::uint8_t> getLevel(std::size_t level, bool blurred, int &w, int &h) = 0;
     // FeatureDetector::detect (feature_detector.hpp:20-22): per-level corners of the last frame

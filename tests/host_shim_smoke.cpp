@@ -50,6 +50,25 @@ int main(int argc, char **argv) {
     extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, nullptr, {TrackPoint{100.f, 100.f, 7}}, kps, ids);
     std::printf("keypoints %zu (first track id %d)\n", kps.size(), ids.empty() ? -99 : ids[0]);
     if (kps.size() < 50 || ids[0] != 7) return 3;
+    {   // camera validity with the model itself (sub-pixel positions, orb_extractor.cpp:101,:231) next to the rasterised mask
+        auto valid = [&](float x, float y) { const float dx = x - 160.25f, dy = y - 119.75f; return dx * dx + dy * dy < 95.5f * 95.5f; };
+        KeyPointVector exact, rast; std::vector<int> exactIds, rastIds;
+        extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, valid, {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, exact, exactIds);
+        std::size_t want = 0; bool same = true;
+        KeyPointVector all; std::vector<int> allIds;
+        extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, nullptr, {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, all, allIds);
+        for (std::size_t i = 0; i < all.size(); ++i) {
+            if (!valid(all[i].pt.x, all[i].pt.y)) continue;
+            same = same && want < exact.size() && exact[want].pt.x == all[i].pt.x && exact[want].pt.y == all[i].pt.y && exact[want].descriptor == all[i].descriptor && exactIds[want] == allIds[i];
+            ++want;
+        }
+        std::vector<std::uint8_t> mask((std::size_t)W * H);
+        for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) mask[(std::size_t)y * W + x] = valid((float)x, (float)y);
+        extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, mask.data(), {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, rast, rastIds);
+        extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, nullptr, {TrackPoint{100.f, 100.f, 7}}, kps, ids);   // back to the unmasked state
+        std::printf("validity: %zu of %zu keypoints inside (rasterised mask keeps %zu)\n", exact.size(), all.size(), rast.size());
+        if (!same || want != exact.size() || exact.size() >= all.size() || exact.empty() || exactIds[0] != 7 || std::find(exactIds.begin(), exactIds.end(), 8) != exactIds.end()) return 12;
+    }
     // match the frame against itself through the triangulation matcher (identity geometry -> epipolar residual is 0/0 guarded by E != 0)
     for (auto &kp : kps) { kp.bearing = {(kp.pt.x - W / 2) / 300.0, (kp.pt.y - H / 2) / 300.0, 1.0}; }
     KeyframeFeatures f; f.keyPoints = &kps; f.usable.assign(kps.size(), 1);
