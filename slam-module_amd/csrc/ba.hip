@@ -98,6 +98,7 @@ struct BaProb {
     FsSet fs[2];
     int32_t fused;                           // 1: schur_fused / point_backsub_fused (no Hpl / Y records exist); 0: the record-based path
     // windowed Cholesky (cholesky_window): the active front of the factorisation as W x W tiles of 16 x 16 in LDS; 0 = front too wide
+    int32_t cw_meta_lds;                     // 1: the five index arrays below are staged in LDS for the factorisation (they fit beside the tiles)
     int32_t cw_W, cw_zglobal;                // tiles per side of the window; 1: the rhs vector stays in global memory (it does not fit the LDS beside the tiles)
     const int32_t *cw_slot;                  // [nblk] LDS slot (row and column index in the tile grid) of 16-row block b while it is active
     const int32_t *cw_act_start, *cw_act;    // per panel p: the other active blocks (block | slot << 16), ascending
@@ -1126,25 +1127,35 @@ __device__ __forceinline__ bool chol_factor_diag(const double *pan, int nb, int 
     // factor the nb x nb diagonal block in REGISTERS: lane i holds row i (16 doubles), the pivot and the column
     // entries L[c][j] are wave-uniform v_readlane broadcasts.  Same operations in the same order as the textbook
     // loop over LDS it replaces (26.7 k -> ~4 k cycles per block); a short last block is padded with identity.
+    // Only the lower triangle (c <= lane) is meaningful on return: the entries above the diagonal take part in the same
+    // instructions unmasked (a mask per column cost more than the whole update) and hold garbage nobody reads.
+    const int ln = lane & 15;                                  // lanes 16..63 mirror 0..15: their loads stay inside the tile
+    if (nb == NB) {
 #pragma unroll
-    for (int c = 0; c < NB; ++c) r[c] = (lane < nb && c < nb) ? pan[lane * LD + c] : (lane == c ? 1.0 : 0.0);
+        for (int c = 0; c < NB; ++c) r[c] = pan[ln * LD + c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) r[c] = (ln < nb && c < nb) ? pan[ln * LD + c] : (ln == c ? 1.0 : 0.0);
+    }
     bool ok = true;
     di = 1.0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const double d = readlane_d(r[j], j);
-        if (j < nb && (!(d > 0) || !isfinite(d))) ok = false;
+        // positive and finite (normal or denormal), else the block is not positive definite: carry on with 1.0 so that nothing overflows
+        const bool okj = __builtin_amdgcn_class(d, 0x180);     // +denormal | +normal
+        if (j < nb && !okj) ok = false;
         // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision to ~1 ulp; sqrt + division were 2/3 of this chain)
-        const double dd = d > 0 ? d : 1.0;
+        const double dd = okj ? d : 1.0;
         double y = __builtin_amdgcn_rsq(dd);
         y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
         y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
-        r[j] = lane == j ? dd * y : (lane > j ? r[j] * y : r[j]);
+        r[j] = lane == j ? dd * y : r[j] * y;
         if (lane == j) di = y;
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) {
             const double lcj = readlane_d(r[j], c);
-            if (lane >= c) r[c] -= r[j] * lcj;
+            r[c] -= r[j] * lcj;
         }
     }
     return ok;
@@ -1247,9 +1258,23 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
 // that are not factored yet -- is a handful of blocks: they are kept as W x W tiles of 16 x 16 doubles in LDS (slots assigned by the
 // host, a block keeps its slot while it is active), every tile is read from S once when its later block enters, updated in LDS
 // (v_mfma_f64_16x16x4_f64, operands from LDS), and written once when its column is factored.  The rhs is forward-substituted along.
+// Stamps inside cholesky_window (build with -DMS_CW_PROF, read with tools/ba_chol_prof.py): per-thread cycle sums in registers, thread 0's and
+// thread 64's written out once per call (a stamp that went through memory cost a round trip of its own and drained the prefetches it was meant to time).
+#ifdef MS_CW_PROF
+__device__ long long g_cwprof[48];
+#define CWP_DECL long long cwt = clock64(), cwacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define CWP(i) do { const long long _t = clock64(); cwacc[i] += _t - cwt; cwt = _t; } while (0)
+#define CWP_FLUSH do { if (tid == 0) { for (int i = 0; i < 24; ++i) g_cwprof[i] += cwacc[i]; g_cwprof[7] += 1; } if (tid == 64) { for (int i = 0; i < 24; ++i) g_cwprof[24 + i] += cwacc[i]; } } while (0)
+#else
+#define CWP_DECL
+#define CWP(i) do { } while (0)
+#define CWP_FLUSH do { } while (0)
+#endif
 constexpr int CT_LD = 18;                 // doubles per tile row (16 + 2: the 32-byte operand reads of 16 rows fall into different banks)
 constexpr int CT = 16 * CT_LD;            // doubles per tile
-template <bool ZG>   // ZG: the rhs / solution vector stays in global memory (P.y): systems whose n doubles do not fit the LDS beside the tiles (global BA of a long trajectory)
+// ML: the per-panel index arrays (slots, active blocks, entering tiles) are copied to LDS first -- every step below starts from them, and as global
+//     loads their two dependent round trips per step were a fifth of the factorisation of a 50-keyframe window
+template <bool ZG, bool ML>   // ZG: the rhs / solution vector stays in global memory (P.y): systems whose n doubles do not fit the LDS beside the tiles (global BA of a long trajectory)
 __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = P.n6, W = P.cw_W, nblk = (n + 15) / 16;
@@ -1259,13 +1284,29 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
     MS_LDS double *tvec;                                      // [16] reciprocal pivots of the current panel
     if constexpr (ZG) { z = (MS_GLOBAL double *)P.y; tvec = tiles + W * W * CT; }
     else { z = tiles + W * W * CT; tvec = z + ((n + 15) & ~15); }
+    MS_LDS double *LT = tvec + 16 + 16 * W + 32;               // [16][16] L11 transposed (after part and dv, below)
+    MS_LDS double *dvec = LT + 256;                            // ML: [n] reciprocal pivots (a global store by the factoring wave would meet the panel's barrier with its round trip still out)
     const MS_GLOBAL double *Sg = (const MS_GLOBAL double *)P.S;
     MS_GLOBAL double *Sw = (MS_GLOBAL double *)P.S;
-    const MS_GLOBAL int32_t *slot = (const MS_GLOBAL int32_t *)P.cw_slot, *act_start = (const MS_GLOBAL int32_t *)P.cw_act_start, *act = (const MS_GLOBAL int32_t *)P.cw_act,
-                            *load_start = (const MS_GLOBAL int32_t *)P.cw_load_start, *loads = (const MS_GLOBAL int32_t *)P.cw_load;
-    if constexpr (!ZG) for (int i = tid; i < n; i += NT) z[i] = P.y[i];
-    auto fetch_tiles = [&](int pnl) {                         // tiles entering the window at panel pnl: S -> LDS, one tile per wave and trip (waves 1..7; wave 0 factors)
-        for (int e = load_start[pnl] + wave - 1; e < load_start[pnl + 1]; e += NW - 1) {
+    const MS_GLOBAL int32_t *gslot = (const MS_GLOBAL int32_t *)P.cw_slot, *gact_start = (const MS_GLOBAL int32_t *)P.cw_act_start, *gact = (const MS_GLOBAL int32_t *)P.cw_act,
+                            *gload_start = (const MS_GLOBAL int32_t *)P.cw_load_start, *gloads = (const MS_GLOBAL int32_t *)P.cw_load;
+    typedef typename std::conditional<ML, const MS_LDS int32_t *, const MS_GLOBAL int32_t *>::type mptr_t;
+    mptr_t slot, act_start, act, load_start, loads;
+    if constexpr (ML) {
+        MS_LDS int32_t *mb = (MS_LDS int32_t *)(LT + 256 + ((n + 15) & ~15));
+        const int nact = gact_start[nblk], nload = gload_start[nblk];
+        MS_LDS int32_t *m_slot = mb, *m_as = m_slot + nblk, *m_ls = m_as + nblk + 1, *m_act = m_ls + nblk + 1, *m_ld = m_act + nact;
+        for (int i = tid; i < nblk; i += NT) m_slot[i] = gslot[i];
+        for (int i = tid; i <= nblk; i += NT) { m_as[i] = gact_start[i]; m_ls[i] = gload_start[i]; }
+        for (int i = tid; i < nact; i += NT) m_act[i] = gact[i];
+        for (int i = tid; i < 2 * nload; i += NT) m_ld[i] = gloads[i];
+        slot = m_slot; act_start = m_as; load_start = m_ls; act = m_act; loads = m_ld;
+        __syncthreads();
+    } else { slot = gslot; act_start = gact_start; act = gact; load_start = gload_start; loads = gloads; }
+    if constexpr (!ZG) for (int i = tid; i < ((n + 15) & ~15); i += NT) z[i] = i < n ? P.y[i] : 0.0;
+    CWP_DECL
+    auto fetch_tiles = [&](int pnl, int skip) {               // tiles entering the window at panel pnl: S -> LDS, one tile per wave and trip (waves 1..7; wave 0 factors)
+        for (int e = load_start[pnl] + skip + wave - 1; e < load_start[pnl + 1]; e += NW - 1) {
             const int ea = loads[2 * e], eb = loads[2 * e + 1], bi = ea & 0xFFFF, si = ea >> 16, bj = eb & 0xFFFF, sj = eb >> 16;
             MS_LDS double *t = tiles + (si * W + sj) * CT;
             const int c = lane & 15, gc = 16 * bj + c;
@@ -1281,11 +1322,18 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         const int c0 = 16 * pnl, nb = min(16, n - c0), sp = slot[pnl];
         MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
         double r[NB], di;
+        CWP(3);
         const bool ok = chol_factor_diag<CT_LD>((const double *)Lpp, nb, lane, r, di);
+        CWP(14);
+        // L11 into the tile (the garbage above the diagonal goes along: nothing reads it) and transposed into LT: column j of L11 as a contiguous row for phase A
+        if (lane < NB) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) if (lane < nb && c <= lane) Lpp[lane * CT_LD + c] = r[c];
-        if (lane < NB) tvec[lane] = di;
-        if (lane < nb) P.dinv[c0 + lane] = di;
+            for (int c = 0; c < NB / 2; ++c) reinterpret_cast<MS_LDS d2_t *>(Lpp + lane * CT_LD)[c] = d2_t{r[2 * c], r[2 * c + 1]};
+#pragma unroll
+            for (int c = 0; c < NB; ++c) LT[c * NB + lane] = r[c];
+            tvec[lane] = di;
+        }
+        if (lane < nb) { if constexpr (ML) dvec[c0 + lane] = di; else P.dinv[c0 + lane] = di; }
         if (!ok && lane == 0) P.flag[0] = 0;
     };
     auto update_pair = [&](int si, int sj, int sp) {         // tile(si, sj) -= tile(si, sp) tile(sj, sp)^T
@@ -1302,7 +1350,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) C[(qd + 4 * reg) * CT_LD + row] -= acc[reg];
     };
-    if (nblk > 0 && wave > 0) fetch_tiles(0);
+    if (nblk > 0 && wave > 0) fetch_tiles(0, 0);
     if (nblk > 0 && wave == 0) {                              // panel 0's diagonal tile is wave 0's, like every later one
         MS_LDS double *t = tiles + (slot[0] * W + slot[0]) * CT;
         const int c = lane & 15;
@@ -1312,40 +1360,79 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
     __syncthreads();
     if (wave == 0 && nblk > 0) factor_diag(0);
     __syncthreads();
+    CWP(0);
     for (int p = 0; p < nblk; ++p) {
         const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
         MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
         // A. rows below: x L11^T = a (a thread per row), and the panel's part of the rhs
         const int a0 = act_start[p], m = act_start[p + 1] - a0;
-        for (int idx = tid; idx < 16 * m; idx += NT) {
-            const int sb = act[a0 + (idx >> 4)] >> 16;
-            MS_LDS double *row = tiles + (sb * W + sp) * CT + (idx & 15) * CT_LD;
-            double x[NB];
+        // (column form: x_j = a_j / L_jj, then a_k -= x_j L_kj for k > j -- the same operations on every a_k in the same order as the dot-product
+        //  form, but the 15 - j updates of a step are independent of each other; column j of L11 is row j of LT)
+        auto solve_row = [&](double (&a)[NB]) {
+            if (nb == NB) {
+                // row j + 1 of LT is requested before step j computes (the scheduler, left alone, put each row's reads right before their use: 16 exposed LDS latencies)
+                const MS_LDS d2_t *LT2 = reinterpret_cast<const MS_LDS d2_t *>(LT), *tv2 = reinterpret_cast<const MS_LDS d2_t *>(tvec);
+                d2_t tv[NB / 2], buf[2][NB / 2];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (j < nb) {
-                    double sacc = row[j];
-                    for (int k = 0; k < j; ++k) sacc -= x[k] * Lpp[j * CT_LD + k];
-                    x[j] = sacc * tvec[j];
+                for (int k = 0; k < NB / 2; ++k) tv[k] = tv2[k];
+#pragma unroll
+                for (int k = 0; k < NB / 2; ++k) buf[0][k] = LT2[k];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j + 1 < NB) {
+#pragma unroll
+                        for (int k = (j + 2) / 2; k < NB / 2; ++k) buf[(j + 1) & 1][k] = LT2[(j + 1) * (NB / 2) + k];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a[j] *= (j & 1) ? tv[j / 2].y : tv[j / 2].x;
+#pragma unroll
+                    for (int k = j + 1; k < NB; ++k) a[k] -= a[j] * ((k & 1) ? buf[j & 1][k / 2].y : buf[j & 1][k / 2].x);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {                                          // the short last block
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < nb) {
+                        double sacc = a[j];
+#pragma unroll
+                        for (int k = 0; k < j; ++k) sacc -= a[k] * Lpp[j * CT_LD + k];
+                        a[j] = sacc * tvec[j];
+                    }
                 }
             }
+        };
+        // (the panel's piece of the rhs is one more row when it lives in LDS: it rides in the wave that has lanes to spare)
+        for (int idx = tid; idx < 16 * m + (ZG ? 0 : 1); idx += NT) {
+            MS_LDS double *row = tiles;
+            if (idx < 16 * m) row = tiles + ((act[a0 + (idx >> 4)] >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
+            else if constexpr (!ZG) row = z + c0;
+            double x[NB];
+            MS_LDS d2_t *row2 = reinterpret_cast<MS_LDS d2_t *>(row);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) if (j < nb) row[j] = x[j];
+            for (int j = 0; j < NB / 2; ++j) { const d2_t v = row2[j]; x[2 * j] = v.x; x[2 * j + 1] = v.y; }
+            CWP(15);
+            solve_row(x);
+            CWP(16);
+            if (nb == NB) {
+#pragma unroll
+                for (int j = 0; j < NB / 2; ++j) row2[j] = d2_t{x[2 * j], x[2 * j + 1]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) if (j < nb) row[j] = x[j];
+            }
+            CWP(17);
         }
-        if (tid == NT - 1) {
+        if (ZG && tid == NT - 1) {
             double x[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (j < nb) {
-                    double sacc = z[c0 + j];
-                    for (int k = 0; k < j; ++k) sacc -= x[k] * Lpp[j * CT_LD + k];
-                    x[j] = sacc * tvec[j];
-                }
-            }
+            for (int j = 0; j < NB; ++j) x[j] = j < nb ? z[c0 + j] : 0.0;
+            solve_row(x);
 #pragma unroll
             for (int j = 0; j < NB; ++j) if (j < nb) z[c0 + j] = x[j];
         }
+        CWP(1);
         __syncthreads();
+        CWP(2);
         // B. look-ahead: wave 0 brings the NEXT diagonal tile up to date (its update by this panel, or its first fetch) and factors it at
         //    once -- the serial pivot chain runs beside the trailing update, the rhs update, the write-back of column p and the fetch of the
         //    tiles that enter at the next panel, which the other seven waves share
@@ -1365,93 +1452,183 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                CWP(3);
                 factor_diag(p + 1);
+                CWP(4);
             }
         } else {
-            int q = 0;
-            for (int i = 0; i < m; ++i) {
-                const int si = act[a0 + i] >> 16;
-                for (int j = 0; j <= i; ++j) {
-                    if (next_active && i == 0) continue;                      // (p+1, p+1): wave 0's
-                    if ((q++ % (NW - 1)) + 1 != wave) continue;
-                    update_pair(si, act[a0 + j] >> 16, sp);
+            // the tiles that enter at the next panel are requested FIRST and parked in registers: their trip to L2 runs beside the updates
+            // and the write-back below (slots released a panel ago -- the host delays the reuse -- so the LDS stores at the end overwrite nothing in use)
+            const int le = p + 1 < nblk ? load_start[p + 2] : 0, e0 = p + 1 < nblk ? load_start[p + 1] + wave - 1 : 0;
+            double pf[4] = {0, 0, 0, 0};
+            int pf_dst = -1;
+            if (e0 < le) {
+                const int ea = loads[2 * e0], eb = loads[2 * e0 + 1], bi = ea & 0xFFFF, bj = eb & 0xFFFF, c = lane & 15, gc = 16 * bj + c;
+                pf_dst = ((ea >> 16) * W + (eb >> 16)) * CT + (lane >> 4) * CT_LD + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int gr = 16 * bi + (lane >> 4) + 4 * k; if (gr < n && gc < n) pf[k] = Sg[(size_t)gr * n + gc]; }
+            }
+            CWP(18);
+            // trailing update: pair q of the lower triangle of the m active blocks (row-major: (0,0), (1,0), (1,1), (2,0) ...) goes to wave 1 + q % 7;
+            // (0,0) is the next diagonal tile when block p+1 is active already -- wave 0 has it
+            {
+                const int npair = m * (m + 1) / 2;
+                for (int q = wave - 1; q < npair; q += NW - 1) {
+                    int i = (int)((__builtin_sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+                    if ((i + 1) * (i + 2) / 2 <= q) ++i;               // (guard the float root at the triangle's corners)
+                    if (i * (i + 1) / 2 > q) --i;
+                    const int j = q - i * (i + 1) / 2;
+                    if (next_active && q == 0) continue;
+                    update_pair(act[a0 + i] >> 16, act[a0 + j] >> 16, sp);
                 }
             }
+            CWP(19);
             const int t7 = tid - 64, N7 = NT - 64;
-            for (int idx = t7; idx < 16 * m; idx += N7) {
+            for (int idx = t7; idx < 16 * m; idx += N7) {         // the rhs below the panel: z_b -= L[b,p] z_p
                 const int ea = act[a0 + (idx >> 4)], gr = 16 * (ea & 0xFFFF) + (idx & 15);
                 if (gr >= n) continue;
                 const MS_LDS double *row = tiles + ((ea >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
                 double sacc = z[gr];
-                for (int k = 0; k < nb; ++k) sacc -= row[k] * z[c0 + k];
+                if (!ZG && nb == NB) {
+                    const MS_LDS d2_t *row2 = reinterpret_cast<const MS_LDS d2_t *>(row);
+                    d2_t rv[NB / 2];
+#pragma unroll
+                    for (int k = 0; k < NB / 2; ++k) rv[k] = row2[k];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) sacc -= ((k & 1) ? rv[k / 2].y : rv[k / 2].x) * z[c0 + k];
+                } else {
+                    for (int k = 0; k < nb; ++k) sacc -= row[k] * z[c0 + k];
+                }
                 z[gr] = sacc;
             }
-            for (int idx = t7; idx < 256 * (m + 1); idx += N7) {
-                const int t = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
-                const int ea = t == 0 ? (p | (sp << 16)) : act[a0 + t - 1], gr = 16 * (ea & 0xFFFF) + r;
-                if (gr >= n || c >= nb || (t == 0 && c > r)) continue;
-                Sw[(size_t)gr * n + c0 + c] = tiles[((ea >> 16) * W + sp) * CT + r * CT_LD + c];
+            CWP(20);
+            // column p of L goes out: tile wave-1 (+7 ...) of the panel's m + 1, four rows of 16 per lane and trip
+            for (int t = wave - 1; t <= m; t += NW - 1) {
+                const int ea = t == 0 ? (p | (sp << 16)) : act[a0 + t - 1], c = lane & 15;
+                const MS_LDS double *src = tiles + ((ea >> 16) * W + sp) * CT + (lane >> 4) * CT_LD + c;
+                double v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = src[4 * k * CT_LD];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = (lane >> 4) + 4 * k, gr = 16 * (ea & 0xFFFF) + r;
+                    if (gr < n && c < nb && (t > 0 || c <= r)) Sw[(size_t)gr * n + c0 + c] = v[k];
+                }
             }
-            if (p + 1 < nblk) fetch_tiles(p + 1);             // slots released a panel ago (the host delays the reuse): nothing above reads them
+            CWP(21);
+            if (pf_dst >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tiles[pf_dst + 4 * k * CT_LD] = pf[k];
+            }
+            CWP(22);
+            if (p + 1 < nblk) fetch_tiles(p + 1, NW - 1);     // a front that brings in more than seven tiles at once: the rest the plain way
         }
+        if (wave != 0) CWP(23);
         __syncthreads();
+        CWP(5);
     }
     // back substitution L^T x = z, panels in reverse, again in LDS: column p of L (the tiles this loop wrote out above) comes back one panel
     // ahead of its use (double buffer in the tile area), a thread per (active block, column) forms L[b,p]^T x_b, wave 0 solves the 16 x 16
     // triangle as a lane recurrence.  Two barriers per panel; the version that reads rows of S from L2 spent a third of the factorisation's time here.
     MS_LDS double *part = tvec + 16;                          // [16 * W] partial dot products, then [2][16] reciprocal pivots
     MS_LDS double *dv = part + 16 * W;
-    auto fetch_col = [&](int pnl, int buf) {
+    auto fetch_col = [&](int pnl, int buf, int t0) {          // tiles t0 + wave, + NW, ... of column pnl
         const int fa0 = act_start[pnl], fm = act_start[pnl + 1] - fa0;
-        for (int t = wave; t <= fm; t += NW) {
+        for (int t = t0 + wave; t <= fm; t += NW) {
             const int b = t == 0 ? pnl : (act[fa0 + t - 1] & 0xFFFF);
             MS_LDS double *dst = tiles + (buf * W + t) * CT;
             const int c = lane & 15, gc = 16 * pnl + c;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = (lane >> 4) + 4 * k, gr = 16 * b + r;
-                dst[r * CT_LD + c] = (gr < n && gc < n && (t > 0 || c <= r)) ? Sg[(size_t)gr * n + gc] : 0.0;
+                dst[r * CT_LD + c] = (gr < n && gc < n && (t > 0 || c < r)) ? Sg[(size_t)gr * n + gc] : 0.0;   // (the diagonal tile: strictly lower part -- the pivots come as reciprocals in dv)
             }
         }
-        if (wave == NW - 1 && lane < 16) dv[16 * buf + lane] = 16 * pnl + lane < n ? P.dinv[16 * pnl + lane] : 0.0;
+        if (t0 == 0 && wave == NW - 1 && lane < 16) dv[16 * buf + lane] = 16 * pnl + lane < n ? (ML ? dvec[16 * pnl + lane] : P.dinv[16 * pnl + lane]) : 0.0;
     };
     __syncthreads();                                          // the last panel's stores to S are done (same workgroup: visible through L1 after the barrier's waitcnt)
-    if (nblk > 0) fetch_col(nblk - 1, 0);
+    if (nblk > 0) fetch_col(nblk - 1, 0, 0);
     __syncthreads();
+    CWP(6);
     for (int p = nblk - 1; p >= 0; --p) {
         const int c0 = 16 * p, nb = min(16, n - c0), buf = (nblk - 1 - p) & 1;
         const int a0 = act_start[p], m = act_start[p + 1] - a0;
-        if (p > 0) fetch_col(p - 1, buf ^ 1);
+        // column p-1 is requested now and parked in registers (tile `wave` of it; a column of more than NW tiles fetches the rest the plain way):
+        // it reaches the other buffer at the end of this step, after a whole step of latency cover
+        double pf[4] = {0, 0, 0, 0}, pf_dv = 0;
+        int pf_dst = -1;
+        if (p > 0) {
+            const int fa0 = act_start[p - 1], fm = act_start[p] - fa0;
+            if (wave <= fm) {
+                const int b = wave == 0 ? p - 1 : (act[fa0 + wave - 1] & 0xFFFF), c = lane & 15, gc = 16 * (p - 1) + c;
+                pf_dst = ((buf ^ 1) * W + wave) * CT + (lane >> 4) * CT_LD + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int r = (lane >> 4) + 4 * k, gr = 16 * b + r; if (gr < n && gc < n && (wave > 0 || c < r)) pf[k] = Sg[(size_t)gr * n + gc]; }
+            }
+            if (wave == NW - 1 && lane < 16 && 16 * (p - 1) + lane < n) pf_dv = ML ? dvec[16 * (p - 1) + lane] : P.dinv[16 * (p - 1) + lane];
+        }
         if (tid < 16 * m) {
             const int t = 1 + (tid >> 4), c = tid & 15, b = act[a0 + t - 1] & 0xFFFF;
             const MS_LDS double *T = tiles + (buf * W + t) * CT;
             double sum = 0;
+            if (!ZG || 16 * b + 16 <= n) {                     // (the LDS copy of z is padded with zeros to a whole block, and so are the tiles)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const int gr = 16 * b + r; if (gr < n) sum += T[r * CT_LD + c] * z[gr]; }
+                for (int r = 0; r < 16; ++r) sum += T[r * CT_LD + c] * z[16 * b + r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const int gr = 16 * b + r; if (gr < n) sum += T[r * CT_LD + c] * z[gr]; }
+            }
             part[tid] = sum;
         }
+        CWP(8);
         __syncthreads();
+        CWP(9);
         if (wave == 0) {
             const MS_LDS double *T0 = tiles + (buf * W) * CT;
-            double rr = 0, di = 0, xk = 0, col[NB];
+            double rr = 0, di = 0, col[NB];
             if (lane < nb) { rr = z[c0 + lane]; for (int t = 0; t < m; ++t) rr -= part[16 * t + lane]; di = dv[16 * buf + lane]; }
+            if (nb == NB) {                                    // (the tile holds zeros on and above its diagonal: col[j] is zero for lanes >= j)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? T0[j * CT_LD + lane] : 0.0;       // L[c0 + j][c0 + lane], j > lane
+                for (int j = 0; j < NB; ++j) col[j] = T0[j * CT_LD + (lane & 15)];
 #pragma unroll
-            for (int j = NB - 1; j >= 0; --j) {
-                if (j < nb) {                                  // uniform
-                    const double xj = readlane_d(rr, j) * readlane_d(di, j);
-                    if (lane == j) xk = xj;
-                    rr -= col[j] * xj;                         // col[j] is zero for lanes >= j
+                for (int j = NB - 1; j >= 0; --j) {
+                    const double xj = readlane_d(rr * di, j);  // lane j's rr is final here: x_j
+                    rr -= col[j] * xj;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? T0[j * CT_LD + lane] : 0.0;       // L[c0 + j][c0 + lane], j > lane
+#pragma unroll
+                for (int j = NB - 1; j >= 0; --j) {
+                    if (j < nb) {                              // uniform
+                        const double xj = readlane_d(rr * di, j);
+                        rr -= col[j] * xj;
+                    }
                 }
             }
-            if (lane < nb) z[c0 + lane] = xk;
+            if (lane < nb) z[c0 + lane] = rr * di;
         }
+        CWP(10);
+        if (pf_dst >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tiles[pf_dst + 4 * k * CT_LD] = pf[k];
+        }
+        if (p > 0) {
+            if (wave == NW - 1 && lane < 16) dv[16 * (buf ^ 1) + lane] = pf_dv;
+            fetch_col(p - 1, buf ^ 1, NW);
+        }
+        CWP(11);
         __syncthreads();
+        CWP(12);
     }
     for (int i = tid; i < n; i += NT) P.dp[i] = z[i];
     __syncthreads();
+    CWP(13);
+    CWP_FLUSH;
 }
+#ifdef MS_CW_PROF
+extern "C" int ms_debug_cwprof(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cwprof), sizeof(long long) * 48); }
+#endif
 
 // The same factorisation for systems whose panel does not fit the LDS (more than kMaxFreePoses free poses: global bundle
 // adjustment, bundle_adjuster.cpp:493-604), spread over the team: the row tiles of a panel are updated by all waves of all
@@ -1549,7 +1726,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     }
     { const long long t1 = clock64(); cyc[2] += t1 - t0; t0 = t1; }
     if (P.cw_W > 0) {                                  // the active front fits the LDS: right-looking, one workgroup (banded systems of any size)
-        if (lead) { if (P.cw_zglobal) cholesky_window<true>(P, lds); else cholesky_window<false>(P, lds); }
+        if (lead) { if (P.cw_zglobal) cholesky_window<true, false>(P, lds); else if (P.cw_meta_lds) cholesky_window<false, true>(P, lds); else cholesky_window<false, false>(P, lds); }
     } else if (P.panG) {                               // too large for an LDS panel: factor across the team, substitute back in one workgroup
         cholesky_factor_team(P, lds);
         if (lead) chol_back_substitute(P, lds, threadIdx.x, threadIdx.x & 63, threadIdx.x >> 6);
@@ -1702,7 +1879,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     const double tm0 = tm_now();
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; };
-    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
+    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
     size_t total = 0;
@@ -2008,10 +2185,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 R.cw_act_start.push_back((int32_t)R.cw_act.size());
             }
             if (W == 1) W = 2;                                               // the back substitution double-buffers a column (<= W tiles) in the W x W tile area
-            const size_t fixed = ((size_t)W * W * CT + 16 + 16 * (size_t)W + 32 + 16) * sizeof(double), zbytes = (size_t)((n6i + 15) & ~15) * sizeof(double);
+            const size_t fixed = ((size_t)W * W * CT + 16 + 16 * (size_t)W + 32 + 256 + 16) * sizeof(double), zbytes = (size_t)((n6i + 15) & ~15) * sizeof(double);
             const bool fits = R.fused && nblk < 65536 && W >= 1 && W < 256;
             R.cw_W = fits && fixed <= kLdsBytes ? W : 0;
             R.cw_zglobal = fixed + zbytes > kLdsBytes;                       // a long trajectory: the tiles fit, the 8 n bytes of the rhs do not -- it stays in global memory
+            const size_t meta = 4 * (R.cw_slot.size() + R.cw_act_start.size() + R.cw_load_start.size() + R.cw_act.size() + R.cw_load.size());
+            R.cw_meta_lds = R.cw_W > 0 && fixed + 2 * zbytes + meta <= kLdsBytes;      // (and the reciprocal pivots: another n doubles)
         }
         const size_t n6 = 6 * (size_t)R.np_free, D = sizeof(double);
         Off &O = off[p];
@@ -2099,7 +2278,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.env16 = PTR(int32_t, env16);
         H.act_start = PTR(int32_t, act_start); H.act_blk = PTR(int32_t, act_blk);
         H.fs_cs = PTR(int32_t, fs_cs);
-        H.cw_W = R.cw_W; H.cw_zglobal = R.cw_zglobal ? 1 : 0; H.cw_slot = PTR(int32_t, cw_slot); H.cw_act_start = PTR(int32_t, cw_act_start); H.cw_act = PTR(int32_t, cw_act);
+        H.cw_W = R.cw_W; H.cw_zglobal = R.cw_zglobal ? 1 : 0; H.cw_meta_lds = R.cw_meta_lds ? 1 : 0; H.cw_slot = PTR(int32_t, cw_slot); H.cw_act_start = PTR(int32_t, cw_act_start); H.cw_act = PTR(int32_t, cw_act);
         H.cw_load_start = PTR(int32_t, cw_load_start); H.cw_load = PTR(int32_t, cw_load);
         for (int set = 0; set < 2; ++set) {
             FsSet &F = H.fs[set];

@@ -47,9 +47,10 @@ while done < N:
         g = ba.download(i)
         rg, rw = ba_synth.residuals_fast(p, g["pose"], g["point"]), ba_synth.residuals_fast(p, w["pose"], w["point"])
         ok = np.abs(rg - rw).max() < 1e-5 and abs(g["stats"]["chi2_final"] - w["stats"]["chi2_final"]) <= 1e-7 * abs(w["stats"]["chi2_final"]) + 1e-8
-        ok = ok and (g["stats"]["iters"], g["stats"]["stop"]) == (w["stats"]["iters"], w["stats"]["stop"])
-        # the trial count may differ only once the solve has converged (a gauge-free window whose gain ratio is rounding noise): same answer to 1e-8
-        ok = ok and (g["stats"]["trials"] == w["stats"]["trials"] or np.abs(rg - rw).max() < 1e-8)
+        # the LM trajectory (iterations, trials, stop reason) must be the oracle's, except once the solve has converged and the gain ratio is
+        # rounding noise (then a trial more or less is taken at the same estimate): same answer to 1e-8
+        same_path = (g["stats"]["iters"], g["stats"]["trials"], g["stats"]["stop"]) == (w["stats"]["iters"], w["stats"]["trials"], w["stats"]["stop"])
+        ok = ok and (same_path or (g["stats"]["iters"] == w["stats"]["iters"] and np.abs(rg - rw).max() < 1e-8))
         done += 1
         if not ok:
             bad += 1
