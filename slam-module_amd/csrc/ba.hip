@@ -31,6 +31,7 @@
 #include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -1120,16 +1121,68 @@ __device__ __forceinline__ void chol_panel_update(const BaProb &P, int c0, int n
     }
 }
 
-// Factor the nb x nb diagonal block held as pan[row * NB + col] in the registers of one wave; returns false when a pivot is not
-// positive.  On return lane i holds row i of L in r[], di = 1 / L[i][i].
+// d -= bcast(s, lane C of each 16-lane row) * t in ONE instruction: gfx950's only 64-bit DPP control is row_newbcast, and v_fmac_f64 takes it --
+// the rank-1 updates of the register Cholesky below were two v_readlane + s_nop + v_fma each (4 issue slots and a trip through the SGPR file).
+// `fresh`: s was written by the preceding VALU instruction (DPP reads need two wait states after a VALU write; inline asm is opaque to the
+// compiler's hazard recogniser).
+template <int C, bool FRESH>
+__device__ __forceinline__ void fmac_neg_rowbcast(double &d, double s, double t) {
+    if constexpr (FRESH) asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(t), "n"(C));
+    else asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(t), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ double rowbcast_d(double s) {      // lane C of each 16-lane row to the whole row
+    double d;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(s), "n"(C));
+    return d;
+}
+template <int J, int... Cs>
+__device__ __forceinline__ void chol_rank1(double (&r)[NB], std::integer_sequence<int, Cs...>) {
+    (fmac_neg_rowbcast<J + 1 + Cs, Cs == 0>(r[J + 1 + Cs], r[J], r[J]), ...);      // r[c] -= L[c][j] L[i][j], c = j+1 .. 15
+}
+template <int J>
+__device__ __forceinline__ void chol_step(double (&r)[NB], int nb, int ln, double &di, bool &ok) {
+    const double d = rowbcast_d<J>(r[J]);                      // the pivot, in every lane
+    // positive and finite (normal or denormal), else the block is not positive definite: carry on with 1.0 so that nothing overflows
+    const bool okj = __builtin_amdgcn_class(d, 0x180);         // +denormal | +normal
+    if (J < nb && !okj) ok = false;
+    // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision to ~1 ulp; sqrt + division were 2/3 of this chain)
+    const double dd = okj ? d : 1.0;
+    double y = __builtin_amdgcn_rsq(dd);
+    y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
+    y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
+    r[J] = (ln == J ? dd : r[J]) * y;
+    if (ln == J) di = y;
+    chol_rank1<J>(r, std::make_integer_sequence<int, NB - 1 - J>{});
+}
+template <int... Js>
+__device__ __forceinline__ void chol_steps(double (&r)[NB], int nb, int ln, double &di, bool &ok, std::integer_sequence<int, Js...>) {
+    (chol_step<Js>(r, nb, ln, di, ok), ...);
+}
+
+// the 16 x 16 triangle of the back substitution as a lane recurrence, last row first: x_j = rr_j di_j is final in lane j when step j comes
+// (col[j] is zero for lanes >= j), and rr -= col[j] x_j takes it as a row broadcast inside the fmac
+template <int... Js>
+__device__ __forceinline__ void backsub_steps(double &rr, double di, const double (&col)[NB], std::integer_sequence<int, Js...>) {
+    (fmac_neg_rowbcast<NB - 1 - Js, true>(rr, rr * di, col[NB - 1 - Js]), ...);
+}
+
+// rr -= sum over r of t1[r] * x_r, x_r = lane r of x in each 16-lane row (the tile next to the diagonal in the back substitution)
+template <int... Rs>
+__device__ __forceinline__ void backsub_adjacent(double &rr, double x, const double (&t1)[NB], std::integer_sequence<int, Rs...>) {
+    (fmac_neg_rowbcast<Rs, Rs == 0>(rr, x, t1[Rs]), ...);
+}
+
+// Factor the nb x nb diagonal block held as pan[row * LD + col], in the registers of one wave; returns false when a pivot is not
+// positive.  On return lane i (and its mirrors i + 16, + 32, + 48) holds row i of L in r[], di = 1 / L[i][i].
 template <int LD = NB>
 __device__ __forceinline__ bool chol_factor_diag(const double *pan, int nb, int lane, double (&r)[NB], double &di) {
-    // factor the nb x nb diagonal block in REGISTERS: lane i holds row i (16 doubles), the pivot and the column
-    // entries L[c][j] are wave-uniform v_readlane broadcasts.  Same operations in the same order as the textbook
-    // loop over LDS it replaces (26.7 k -> ~4 k cycles per block); a short last block is padded with identity.
+    // factor the nb x nb diagonal block in REGISTERS: lane i holds row i (16 doubles); the pivot and the column entries L[c][j] reach the other
+    // lanes as DPP row broadcasts.  Same operations in the same order as the textbook loop over LDS it replaces (26.7 k cycles per block there,
+    // ~5 k with v_readlane broadcasts, half of that with the broadcast inside the fmac); a short last block is padded with identity.
     // Only the lower triangle (c <= lane) is meaningful on return: the entries above the diagonal take part in the same
     // instructions unmasked (a mask per column cost more than the whole update) and hold garbage nobody reads.
-    const int ln = lane & 15;                                  // lanes 16..63 mirror 0..15: their loads stay inside the tile
+    const int ln = lane & 15;                                  // the four 16-lane rows of the wave hold the same 16 matrix rows: a row broadcast serves each alike
     if (nb == NB) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) r[c] = pan[ln * LD + c];
@@ -1139,25 +1192,8 @@ __device__ __forceinline__ bool chol_factor_diag(const double *pan, int nb, int 
     }
     bool ok = true;
     di = 1.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double d = readlane_d(r[j], j);
-        // positive and finite (normal or denormal), else the block is not positive definite: carry on with 1.0 so that nothing overflows
-        const bool okj = __builtin_amdgcn_class(d, 0x180);     // +denormal | +normal
-        if (j < nb && !okj) ok = false;
-        // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision to ~1 ulp; sqrt + division were 2/3 of this chain)
-        const double dd = okj ? d : 1.0;
-        double y = __builtin_amdgcn_rsq(dd);
-        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
-        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
-        r[j] = lane == j ? dd * y : r[j] * y;
-        if (lane == j) di = y;
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-            const double lcj = readlane_d(r[j], c);
-            r[c] -= r[j] * lcj;
-        }
-    }
+    asm volatile("s_nop 4");                                   // (an EXEC write by a VALU compare right before the first DPP read would need five wait states)
+    chol_steps(r, nb, ln, di, ok, std::make_integer_sequence<int, NB>{});
     return ok;
 }
 
@@ -1304,6 +1340,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         __syncthreads();
     } else { slot = gslot; act_start = gact_start; act = gact; load_start = gload_start; loads = gloads; }
     if constexpr (!ZG) for (int i = tid; i < ((n + 15) & ~15); i += NT) z[i] = i < n ? P.y[i] : 0.0;
+    if constexpr (ML) { if (tid < 16) dvec[((n + 15) & ~15) - 16 + tid] = 0.0; }      // (the pad of the last block; the pivots overwrite the rest)
     CWP_DECL
     auto fetch_tiles = [&](int pnl, int skip) {               // tiles entering the window at panel pnl: S -> LDS, one tile per wave and trip (waves 1..7; wave 0 factors)
         for (int e = load_start[pnl] + skip + wave - 1; e < load_start[pnl + 1]; e += NW - 1) {
@@ -1532,7 +1569,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
     // triangle as a lane recurrence.  Two barriers per panel; the version that reads rows of S from L2 spent a third of the factorisation's time here.
     MS_LDS double *part = tvec + 16;                          // [16 * W] partial dot products, then [2][16] reciprocal pivots
     MS_LDS double *dv = part + 16 * W;
-    auto fetch_col = [&](int pnl, int buf, int t0) {          // tiles t0 + wave, + NW, ... of column pnl
+    auto fetch_col = [&](int pnl, int buf, int t0, bool with_dv) {          // tiles t0 + wave, + NW, ... of column pnl
         const int fa0 = act_start[pnl], fm = act_start[pnl + 1] - fa0;
         for (int t = t0 + wave; t <= fm; t += NW) {
             const int b = t == 0 ? pnl : (act[fa0 + t - 1] & 0xFFFF);
@@ -1544,10 +1581,86 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
                 dst[r * CT_LD + c] = (gr < n && gc < n && (t > 0 || c < r)) ? Sg[(size_t)gr * n + gc] : 0.0;   // (the diagonal tile: strictly lower part -- the pivots come as reciprocals in dv)
             }
         }
-        if (t0 == 0 && wave == NW - 1 && lane < 16) dv[16 * buf + lane] = 16 * pnl + lane < n ? (ML ? dvec[16 * pnl + lane] : P.dinv[16 * pnl + lane]) : 0.0;
+        if (with_dv && t0 == 0 && wave == NW - 1 && lane < 16) dv[16 * buf + lane] = 16 * pnl + lane < n ? (ML ? dvec[16 * pnl + lane] : P.dinv[16 * pnl + lane]) : 0.0;
     };
     __syncthreads();                                          // the last panel's stores to S are done (same workgroup: visible through L1 after the barrier's waitcnt)
-    if (nblk > 0) fetch_col(nblk - 1, 0, 0);
+    if constexpr (!ZG && ML) {
+        // Everything in LDS (a sliding window): the chain x_{p+1} -> x_p runs in wave 0 alone, ONE barrier per panel.  Only the tile next to the
+        // diagonal, L[p+1,p], needs the x that has just been found: wave 0 takes it from its own registers (x_{p+1} sits in lane k of each 16-lane
+        // row; the product is 16 row-broadcast fmacs) and goes straight into the triangle recurrence.  The tiles further down the column, L[b,p],
+        // b >= p+2, were applied to z_p a step earlier by wave 1, while wave 0 was busy with panel p+1; the columns arrive two steps ahead of
+        // wave 0 (three buffers of W tiles in the tile area), parked in registers while they travel.
+        const int ln = lane & 15;
+        for (int q = nblk - 1; q >= nblk - 2 && q >= 0; --q) fetch_col(q, q % 3, 0, false);
+        __syncthreads();
+        CWP(6);
+        double xprev = 0;
+        for (int p = nblk - 1; p >= 0; --p) {
+            const int c0 = 16 * p;
+            double pf[4] = {0, 0, 0, 0};
+            int pf_dst = -1;
+            if (p > 1) {                                       // column p-2: tile `wave` of it into registers now, into its buffer at the end of the step
+                const int q = p - 2, fa0 = act_start[q], fm = act_start[q + 1] - fa0;
+                if (wave <= fm) {
+                    const int b = wave == 0 ? q : (act[fa0 + wave - 1] & 0xFFFF), c = ln, gc = 16 * q + c;
+                    pf_dst = ((q % 3) * W + wave) * CT + (lane >> 4) * CT_LD + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int r = (lane >> 4) + 4 * k, gr = 16 * b + r; if (gr < n && gc < n && (wave > 0 || c < r)) pf[k] = Sg[(size_t)gr * n + gc]; }
+                }
+            }
+            CWP(8);
+            if (wave == 0) {
+                const int a0 = act_start[p], m = act_start[p + 1] - a0;
+                const bool adjacent = m > 0 && (act[a0] & 0xFFFF) == p + 1;
+                const MS_LDS double *T0 = tiles + ((p % 3) * W) * CT, *T1 = T0 + CT;
+                double rr = z[c0 + ln], col[NB];
+                const double di = dvec[c0 + ln];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) col[j] = T0[j * CT_LD + ln];          // L[c0 + j][c0 + lane], zero on and above the diagonal
+                if (adjacent) {
+                    double t1[NB];
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) t1[r] = T1[r * CT_LD + ln];
+                    backsub_adjacent(rr, xprev, t1, std::make_integer_sequence<int, NB>{});
+                }
+                backsub_steps(rr, di, col, std::make_integer_sequence<int, NB>{});
+                xprev = rr * di;
+                if (lane < NB) z[c0 + lane] = xprev;
+                CWP(10);
+            } else if (wave == 1 && p > 0) {
+                // z_{p-1} -= sum over the blocks b >= p+1 of column p-1 of L[b,p-1]^T x_b (all of them final): the four 16-lane rows share the tiles out,
+                // their sums meet in `part`
+                const int q = p - 1, a0 = act_start[q], m = act_start[q + 1] - a0;
+                const int first = (m > 0 && (act[a0] & 0xFFFF) == q + 1) ? 1 : 0, rq = lane >> 4;
+                double sum = 0;
+                for (int e = first + rq; e < m; e += 4) {
+                    const int b = act[a0 + e] & 0xFFFF;
+                    const MS_LDS double *T = tiles + ((q % 3) * W + e + 1) * CT;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += T[r * CT_LD + ln] * z[16 * b + r];
+                }
+                part[lane] = sum;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NB) z[16 * q + lane] -= (part[lane] + part[16 + lane]) + (part[32 + lane] + part[48 + lane]);
+                CWP(10);
+            }
+            if (pf_dst >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tiles[pf_dst + 4 * k * CT_LD] = pf[k];
+            }
+            if (p > 1) fetch_col(p - 2, (p - 2) % 3, NW, false);
+            CWP(11);
+            __syncthreads();
+            CWP(12);
+        }
+        for (int i = tid; i < n; i += NT) P.dp[i] = z[i];
+        __syncthreads();
+        CWP(13);
+        CWP_FLUSH;
+        return;
+    }
+    if (nblk > 0) fetch_col(nblk - 1, 0, 0, true);
     __syncthreads();
     CWP(6);
     for (int p = nblk - 1; p >= 0; --p) {
@@ -1590,11 +1703,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
             if (nb == NB) {                                    // (the tile holds zeros on and above its diagonal: col[j] is zero for lanes >= j)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) col[j] = T0[j * CT_LD + (lane & 15)];
-#pragma unroll
-                for (int j = NB - 1; j >= 0; --j) {
-                    const double xj = readlane_d(rr * di, j);  // lane j's rr is final here: x_j
-                    rr -= col[j] * xj;
-                }
+                backsub_steps(rr, di, col, std::make_integer_sequence<int, NB>{});
             } else {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) col[j] = (j < nb && lane < j) ? T0[j * CT_LD + lane] : 0.0;       // L[c0 + j][c0 + lane], j > lane
@@ -1615,7 +1724,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         }
         if (p > 0) {
             if (wave == NW - 1 && lane < 16) dv[16 * (buf ^ 1) + lane] = pf_dv;
-            fetch_col(p - 1, buf ^ 1, NW);
+            fetch_col(p - 1, buf ^ 1, NW, false);
         }
         CWP(11);
         __syncthreads();
@@ -2184,7 +2293,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 for (int b : active) if (b != pnl) R.cw_act.push_back(b | (R.cw_slot[b] << 16));
                 R.cw_act_start.push_back((int32_t)R.cw_act.size());
             }
-            if (W == 1) W = 2;                                               // the back substitution double-buffers a column (<= W tiles) in the W x W tile area
+            if (W < 3) W = 3;                                                // the back substitution keeps three columns (<= W tiles each) in the W x W tile area
             const size_t fixed = ((size_t)W * W * CT + 16 + 16 * (size_t)W + 32 + 256 + 16) * sizeof(double), zbytes = (size_t)((n6i + 15) & ~15) * sizeof(double);
             const bool fits = R.fused && nblk < 65536 && W >= 1 && W < 256;
             R.cw_W = fits && fixed <= kLdsBytes ? W : 0;
