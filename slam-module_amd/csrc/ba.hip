@@ -1173,6 +1173,36 @@ __device__ __forceinline__ void backsub_adjacent(double &rr, double x, const dou
     (fmac_neg_rowbcast<Rs, Rs == 0>(rr, x, t1[Rs]), ...);
 }
 
+// the block already in registers (lane ln and its mirrors: row ln); rows / columns from nb on must hold the identity
+__device__ __forceinline__ bool chol_factor_regs(double (&r)[NB], int nb, int ln, double &di) {
+    bool ok = true;
+    di = 1.0;
+    asm volatile("s_nop 4");                                   // (an EXEC write by a VALU compare right before the first DPP read would need five wait states)
+    chol_steps(r, nb, ln, di, ok, std::make_integer_sequence<int, NB>{});
+    return ok;
+}
+
+// x L11^T = a for one row per lane (a[] in, x out), L11 as rows in r[] of the lanes of the same 16-lane row, di = 1 / L[ln][ln]: column form,
+// x_j = a_j / L_jj, then a_k -= L_kj x_j for k > j with L_kj broadcast inside the fmac -- no operand comes from memory
+template <int J, int... Ks>
+__device__ __forceinline__ void tri_solve_step(double (&a)[NB], const double (&r)[NB], double di, std::integer_sequence<int, Ks...>) {
+    a[J] *= rowbcast_d<J>(di);
+    (fmac_neg_rowbcast<J + 1 + Ks, false>(a[J + 1 + Ks], r[J], a[J]), ...);
+}
+template <int... Js>
+__device__ __forceinline__ void tri_solve_rows(double (&a)[NB], const double (&r)[NB], double di, std::integer_sequence<int, Js...>) {
+    (tri_solve_step<Js>(a, r, di, std::make_integer_sequence<int, NB - 1 - Js>{}), ...);
+}
+// c[C] -= sum over j of x_C[j] x[j]: column C of X X^T for the lane's row (x_C = the row held by lane C of the same 16-lane row)
+template <int C, int... Js>
+__device__ __forceinline__ void syrk_col(double &cc, const double (&x)[NB], std::integer_sequence<int, Js...>) {
+    (fmac_neg_rowbcast<C, false>(cc, x[Js], x[Js]), ...);
+}
+template <int... Cs>
+__device__ __forceinline__ void syrk_rows(double (&c)[NB], const double (&x)[NB], std::integer_sequence<int, Cs...>) {
+    (syrk_col<Cs>(c[Cs], x, std::make_integer_sequence<int, NB>{}), ...);
+}
+
 // Factor the nb x nb diagonal block held as pan[row * LD + col], in the registers of one wave; returns false when a pivot is not
 // positive.  On return lane i (and its mirrors i + 16, + 32, + 48) holds row i of L in r[], di = 1 / L[i][i].
 template <int LD = NB>
@@ -1190,11 +1220,7 @@ __device__ __forceinline__ bool chol_factor_diag(const double *pan, int nb, int 
 #pragma unroll
         for (int c = 0; c < NB; ++c) r[c] = (ln < nb && c < nb) ? pan[ln * LD + c] : (ln == c ? 1.0 : 0.0);
     }
-    bool ok = true;
-    di = 1.0;
-    asm volatile("s_nop 4");                                   // (an EXEC write by a VALU compare right before the first DPP read would need five wait states)
-    chol_steps(r, nb, ln, di, ok, std::make_integer_sequence<int, NB>{});
-    return ok;
+    return chol_factor_regs(r, nb, ln, di);
 }
 
 // Back substitution L^T x = z with xs[n] in LDS (z = the forward-substituted rhs in P.y on entry; P.dp on exit).
@@ -1387,128 +1413,126 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) C[(qd + 4 * reg) * CT_LD + row] -= acc[reg];
     };
-    if (nblk > 0 && wave > 0) fetch_tiles(0, 0);
-    if (nblk > 0 && wave == 0) {                              // panel 0's diagonal tile is wave 0's, like every later one
-        MS_LDS double *t = tiles + (slot[0] * W + slot[0]) * CT;
-        const int c = lane & 15;
+    if constexpr (!ZG && ML) {
+        // Everything the factorisation touches per panel is in LDS or registers.  Wave 0 carries the serial chain in REGISTERS from one diagonal
+        // block to the next: with L11(p) still in r[] it solves the tile next to the diagonal, L[p+1,p] (one row per lane, L11 entries as row
+        // broadcasts), forms block (p+1,p+1) -= L[p+1,p] L[p+1,p]^T the same way and factors it -- no LDS round trip, no barrier inside the chain.
+        // Waves 1, 2 solve the other tiles of the column and the rhs against L11(p) read back from its tile (16 rows per 16-lane row);
+        // after the panel's first barrier waves 1..7 do the trailing pairs on the matrix cores, the rhs update, the write-back and the fetch
+        // of the tiles that enter next, beside wave 0's update + factor.  Two barriers per panel.
+        const int ln = lane & 15, grp = lane >> 4;
+        double r[NB], di = 1.0;                                // wave 0: L11 of the current panel, row ln (the same in the four 16-lane rows)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int r = (lane >> 4) + 4 * k; t[r * CT_LD + c] = (r < n && c < n) ? Sg[(size_t)r * n + c] : 0.0; }
-    }
-    __syncthreads();
-    if (wave == 0 && nblk > 0) factor_diag(0);
-    __syncthreads();
-    CWP(0);
-    for (int p = 0; p < nblk; ++p) {
-        const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
-        MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
-        // A. rows below: x L11^T = a (a thread per row), and the panel's part of the rhs
-        const int a0 = act_start[p], m = act_start[p + 1] - a0;
-        // (column form: x_j = a_j / L_jj, then a_k -= x_j L_kj for k > j -- the same operations on every a_k in the same order as the dot-product
-        //  form, but the 15 - j updates of a step are independent of each other; column j of L11 is row j of LT)
-        auto solve_row = [&](double (&a)[NB]) {
-            if (nb == NB) {
-                // row j + 1 of LT is requested before step j computes (the scheduler, left alone, put each row's reads right before their use: 16 exposed LDS latencies)
-                const MS_LDS d2_t *LT2 = reinterpret_cast<const MS_LDS d2_t *>(LT), *tv2 = reinterpret_cast<const MS_LDS d2_t *>(tvec);
-                d2_t tv[NB / 2], buf[2][NB / 2];
+        for (int c = 0; c < NB; ++c) r[c] = 0.0;
+        auto publish = [&](int pnl, const double (&rr)[NB], double dd, bool ok) {       // L11 -> its tile, reciprocal pivots -> tvec / dvec
+            const int c0 = 16 * pnl, nb = min(16, n - c0), sp = slot[pnl];
+            MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
+            if (lane < NB) {
 #pragma unroll
-                for (int k = 0; k < NB / 2; ++k) tv[k] = tv2[k];
-#pragma unroll
-                for (int k = 0; k < NB / 2; ++k) buf[0][k] = LT2[k];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (j + 1 < NB) {
-#pragma unroll
-                        for (int k = (j + 2) / 2; k < NB / 2; ++k) buf[(j + 1) & 1][k] = LT2[(j + 1) * (NB / 2) + k];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    a[j] *= (j & 1) ? tv[j / 2].y : tv[j / 2].x;
-#pragma unroll
-                    for (int k = j + 1; k < NB; ++k) a[k] -= a[j] * ((k & 1) ? buf[j & 1][k / 2].y : buf[j & 1][k / 2].x);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {                                          // the short last block
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (j < nb) {
-                        double sacc = a[j];
-#pragma unroll
-                        for (int k = 0; k < j; ++k) sacc -= a[k] * Lpp[j * CT_LD + k];
-                        a[j] = sacc * tvec[j];
-                    }
-                }
+                for (int c = 0; c < NB / 2; ++c) reinterpret_cast<MS_LDS d2_t *>(Lpp + lane * CT_LD)[c] = d2_t{rr[2 * c], rr[2 * c + 1]};
+                tvec[lane] = dd;
+                if (lane < nb) dvec[c0 + lane] = dd;
             }
+            if (!ok && lane == 0) P.flag[0] = 0;
         };
-        // (the panel's piece of the rhs is one more row when it lives in LDS: it rides in the wave that has lanes to spare)
-        for (int idx = tid; idx < 16 * m + (ZG ? 0 : 1); idx += NT) {
-            MS_LDS double *row = tiles;
-            if (idx < 16 * m) row = tiles + ((act[a0 + (idx >> 4)] >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
-            else if constexpr (!ZG) row = z + c0;
-            double x[NB];
-            MS_LDS d2_t *row2 = reinterpret_cast<MS_LDS d2_t *>(row);
+        auto global_diag_rows = [&](int blk, double (&c)[NB]) {                       // rows of a diagonal block straight from S, identity beyond n
+            const int nb1 = min(16, n - 16 * blk);
 #pragma unroll
-            for (int j = 0; j < NB / 2; ++j) { const d2_t v = row2[j]; x[2 * j] = v.x; x[2 * j + 1] = v.y; }
-            CWP(15);
-            solve_row(x);
-            CWP(16);
-            if (nb == NB) {
-#pragma unroll
-                for (int j = 0; j < NB / 2; ++j) row2[j] = d2_t{x[2 * j], x[2 * j + 1]};
-            } else {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) if (j < nb) row[j] = x[j];
-            }
-            CWP(17);
+            for (int cc = 0; cc < NB; ++cc) c[cc] = (ln < nb1 && cc < nb1) ? Sg[(size_t)(16 * blk + ln) * n + 16 * blk + cc] : (ln == cc ? 1.0 : 0.0);
+        };
+        if (nblk > 0 && wave > 0) fetch_tiles(0, 0);
+        if (nblk > 0 && wave == 0) {
+            global_diag_rows(0, r);
+            const bool ok = chol_factor_regs(r, min(16, n), ln, di);
+            publish(0, r, di, ok);
         }
-        if (ZG && tid == NT - 1) {
-            double x[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) x[j] = j < nb ? z[c0 + j] : 0.0;
-            solve_row(x);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) if (j < nb) z[c0 + j] = x[j];
-        }
-        CWP(1);
         __syncthreads();
-        CWP(2);
-        // B. look-ahead: wave 0 brings the NEXT diagonal tile up to date (its update by this panel, or its first fetch) and factors it at
-        //    once -- the serial pivot chain runs beside the trailing update, the rhs update, the write-back of column p and the fetch of the
-        //    tiles that enter at the next panel, which the other seven waves share
-        const bool next_active = m > 0 && (act[a0] & 0xFFFF) == p + 1;       // block p+1 is in the window already (else it enters at p+1)
-        if (wave == 0) {
-            if (p + 1 < nblk) {
-                const int s1 = slot[p + 1];
-                if (next_active) update_pair(s1, s1, sp);
-                else {
-                    MS_LDS double *t = tiles + (s1 * W + s1) * CT;
-                    const int c = lane & 15, gc = 16 * (p + 1) + c;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int r = (lane >> 4) + 4 * k, gr = 16 * (p + 1) + r;
-                        t[r * CT_LD + c] = (gr < n && gc < n) ? Sg[(size_t)gr * n + gc] : 0.0;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                CWP(3);
-                factor_diag(p + 1);
-                CWP(4);
-            }
-        } else {
-            // the tiles that enter at the next panel are requested FIRST and parked in registers: their trip to L2 runs beside the updates
-            // and the write-back below (slots released a panel ago -- the host delays the reuse -- so the LDS stores at the end overwrite nothing in use)
-            const int le = p + 1 < nblk ? load_start[p + 2] : 0, e0 = p + 1 < nblk ? load_start[p + 1] + wave - 1 : 0;
+        CWP(0);
+        for (int p = 0; p < nblk; ++p) {
+            const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
+            const int a0 = act_start[p], m = act_start[p + 1] - a0;
+            const bool has_next = p + 1 < nblk, next_active = m > 0 && (act[a0] & 0xFFFF) == p + 1;
+            const int s1 = has_next ? slot[p + 1] : 0, nb1 = has_next ? min(16, n - c0 - 16) : 0;
+            double x[NB], cg[NB];                              // wave 0: the solved row of L[p+1,p]; the rows of block p+1 when it only enters now
             double pf[4] = {0, 0, 0, 0};
             int pf_dst = -1;
-            if (e0 < le) {
-                const int ea = loads[2 * e0], eb = loads[2 * e0 + 1], bi = ea & 0xFFFF, bj = eb & 0xFFFF, c = lane & 15, gc = 16 * bj + c;
-                pf_dst = ((ea >> 16) * W + (eb >> 16)) * CT + (lane >> 4) * CT_LD + c;
+            if (wave == 0) {
+                if (has_next && next_active) {
+                    MS_LDS d2_t *row2 = reinterpret_cast<MS_LDS d2_t *>(tiles + (s1 * W + sp) * CT + ln * CT_LD);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int gr = 16 * bi + (lane >> 4) + 4 * k; if (gr < n && gc < n) pf[k] = Sg[(size_t)gr * n + gc]; }
+                    for (int j = 0; j < NB / 2; ++j) { const d2_t v = row2[j]; x[2 * j] = v.x; x[2 * j + 1] = v.y; }
+                    tri_solve_rows(x, r, di, std::make_integer_sequence<int, NB>{});
+                    if (lane < NB) {
+#pragma unroll
+                        for (int j = 0; j < NB / 2; ++j) row2[j] = d2_t{x[2 * j], x[2 * j + 1]};
+                    }
+                    // block (p+1,p+1) has had every earlier panel's update since the last barrier: this panel's goes on top right away, from the rows just
+                    // solved -- X X^T on the matrix core with both operands out of x[] (lane (row, g) supplies X[row][4 kk + g]); the result comes back as
+                    // four columns of the lane's own row (g, g+4, g+8, g+12: the product is symmetric), is taken off the tile in LDS and the whole row read back
+                    {
+                        d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const double xs = grp == 0 ? x[4 * kk] : grp == 1 ? x[4 * kk + 1] : grp == 2 ? x[4 * kk + 2] : x[4 * kk + 3];
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, xs, acc, 0, 0, 0);
+                        }
+                        MS_LDS double *Crow = tiles + (s1 * W + s1) * CT + ln * CT_LD;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) Crow[grp + 4 * reg] -= acc[reg];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const MS_LDS d2_t *C2 = reinterpret_cast<const MS_LDS d2_t *>(Crow);
+#pragma unroll
+                        for (int j = 0; j < NB / 2; ++j) { const d2_t v = C2[j]; cg[2 * j] = v.x; cg[2 * j + 1] = v.y; }
+                    }
+                    if (nb1 < NB) {
+#pragma unroll
+                        for (int cc = 0; cc < NB; ++cc) cg[cc] = (ln < nb1 && cc < nb1) ? cg[cc] : (ln == cc ? 1.0 : 0.0);
+                    }
+                } else if (has_next) global_diag_rows(p + 1, cg);
+            } else {
+                // the tiles that enter at the next panel are requested FIRST and parked in registers: their trip to L2 runs beside everything below
+                // (slots released a panel ago -- the host delays the reuse -- so the LDS stores at the end of the panel overwrite nothing in use)
+                const int le = has_next ? load_start[p + 2] : 0, e0 = has_next ? load_start[p + 1] + wave - 1 : 0;
+                if (e0 < le) {
+                    const int ea = loads[2 * e0], eb = loads[2 * e0 + 1], bi = ea & 0xFFFF, bj = eb & 0xFFFF, gc = 16 * bj + ln;
+                    pf_dst = ((ea >> 16) * W + (eb >> 16)) * CT + grp * CT_LD + ln;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int gr = 16 * bi + grp + 4 * k; if (gr < n && gc < n) pf[k] = Sg[(size_t)gr * n + gc]; }
+                }
+                // the other tiles of column p and the rhs: entry e of the panel's list per 16-lane row (e == m: the rhs)
+                const int first = next_active ? 1 : 0, e = 4 * (wave - 1) + grp + first;
+                if (4 * (wave - 1) + first <= m) {
+                    const MS_LDS d2_t *L2 = reinterpret_cast<const MS_LDS d2_t *>(tiles + (sp * W + sp) * CT + ln * CT_LD);
+                    double lr[NB], a[NB];
+#pragma unroll
+                    for (int j = 0; j < NB / 2; ++j) { const d2_t v = L2[j]; lr[2 * j] = v.x; lr[2 * j + 1] = v.y; }
+                    const double ldi = tvec[ln];
+                    MS_LDS double *row = e < m ? tiles + ((act[a0 + e] >> 16) * W + sp) * CT + ln * CT_LD : (MS_LDS double *)z + c0;
+                    MS_LDS d2_t *row2 = reinterpret_cast<MS_LDS d2_t *>(row);
+#pragma unroll
+                    for (int j = 0; j < NB / 2; ++j) { const d2_t v = row2[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+                    tri_solve_rows(a, lr, ldi, std::make_integer_sequence<int, NB>{});
+                    if (e < m || (e == m && ln == 0)) {
+#pragma unroll
+                        for (int j = 0; j < NB / 2; ++j) row2[j] = d2_t{a[2 * j], a[2 * j + 1]};
+                    }
+                }
             }
-            CWP(18);
-            // trailing update: pair q of the lower triangle of the m active blocks (row-major: (0,0), (1,0), (1,1), (2,0) ...) goes to wave 1 + q % 7;
-            // (0,0) is the next diagonal tile when block p+1 is active already -- wave 0 has it
-            {
+            CWP(1);
+            __syncthreads();
+            CWP(2);
+            if (wave == 0) {
+                if (has_next) {
+#pragma unroll
+                    for (int cc = 0; cc < NB; ++cc) r[cc] = cg[cc];
+                    const bool ok = chol_factor_regs(r, nb1, ln, di);
+                    publish(p + 1, r, di, ok);
+                }
+                CWP(4);
+            } else {
+                // trailing update: pair q of the lower triangle of the m active blocks (row-major: (0,0), (1,0), (1,1), (2,0) ...) goes to wave 1 + q % 7;
+                // (0,0) is the next diagonal tile when block p+1 is active already -- wave 0 has it
                 const int npair = m * (m + 1) / 2;
                 for (int q = wave - 1; q < npair; q += NW - 1) {
                     int i = (int)((__builtin_sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
@@ -1518,51 +1542,223 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
                     if (next_active && q == 0) continue;
                     update_pair(act[a0 + i] >> 16, act[a0 + j] >> 16, sp);
                 }
-            }
-            CWP(19);
-            const int t7 = tid - 64, N7 = NT - 64;
-            for (int idx = t7; idx < 16 * m; idx += N7) {         // the rhs below the panel: z_b -= L[b,p] z_p
-                const int ea = act[a0 + (idx >> 4)], gr = 16 * (ea & 0xFFFF) + (idx & 15);
-                if (gr >= n) continue;
-                const MS_LDS double *row = tiles + ((ea >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
-                double sacc = z[gr];
-                if (!ZG && nb == NB) {
-                    const MS_LDS d2_t *row2 = reinterpret_cast<const MS_LDS d2_t *>(row);
+                CWP(19);
+                const int t7 = tid - 64, N7 = NT - 64;
+                for (int idx = t7; idx < 16 * m; idx += N7) {         // the rhs below the panel: z_b -= L[b,p] z_p
+                    const int ea = act[a0 + (idx >> 4)], gr = 16 * (ea & 0xFFFF) + (idx & 15);
+                    if (gr >= n) continue;
+                    const MS_LDS d2_t *row2 = reinterpret_cast<const MS_LDS d2_t *>(tiles + ((ea >> 16) * W + sp) * CT + (idx & 15) * CT_LD);
+                    double sacc = z[gr];
                     d2_t rv[NB / 2];
 #pragma unroll
                     for (int k = 0; k < NB / 2; ++k) rv[k] = row2[k];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) sacc -= ((k & 1) ? rv[k / 2].y : rv[k / 2].x) * z[c0 + k];
-                } else {
-                    for (int k = 0; k < nb; ++k) sacc -= row[k] * z[c0 + k];
+                    z[gr] = sacc;
                 }
-                z[gr] = sacc;
-            }
-            CWP(20);
-            // column p of L goes out: tile wave-1 (+7 ...) of the panel's m + 1, four rows of 16 per lane and trip
-            for (int t = wave - 1; t <= m; t += NW - 1) {
-                const int ea = t == 0 ? (p | (sp << 16)) : act[a0 + t - 1], c = lane & 15;
-                const MS_LDS double *src = tiles + ((ea >> 16) * W + sp) * CT + (lane >> 4) * CT_LD + c;
-                double v[4];
+                CWP(20);
+                // column p of L goes out: tile wave-1 (+7 ...) of the panel's m + 1, four rows of 16 per lane and trip
+                for (int t = wave - 1; t <= m; t += NW - 1) {
+                    const int ea = t == 0 ? (p | (sp << 16)) : act[a0 + t - 1];
+                    const MS_LDS double *src = tiles + ((ea >> 16) * W + sp) * CT + grp * CT_LD + ln;
+                    double v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = src[4 * k * CT_LD];
+                    for (int k = 0; k < 4; ++k) v[k] = src[4 * k * CT_LD];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int r = (lane >> 4) + 4 * k, gr = 16 * (ea & 0xFFFF) + r;
-                    if (gr < n && c < nb && (t > 0 || c <= r)) Sw[(size_t)gr * n + c0 + c] = v[k];
+                    for (int k = 0; k < 4; ++k) {
+                        const int rr = grp + 4 * k, gr = 16 * (ea & 0xFFFF) + rr;
+                        if (gr < n && ln < nb && (t > 0 || ln <= rr)) Sw[(size_t)gr * n + c0 + ln] = v[k];
+                    }
                 }
-            }
-            CWP(21);
-            if (pf_dst >= 0) {
+                CWP(21);
+                if (pf_dst >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) tiles[pf_dst + 4 * k * CT_LD] = pf[k];
+                    for (int k = 0; k < 4; ++k) tiles[pf_dst + 4 * k * CT_LD] = pf[k];
+                }
+                CWP(22);
+                if (has_next) fetch_tiles(p + 1, NW - 1);             // a front that brings in more than seven tiles at once: the rest the plain way
             }
-            CWP(22);
-            if (p + 1 < nblk) fetch_tiles(p + 1, NW - 1);     // a front that brings in more than seven tiles at once: the rest the plain way
+            __syncthreads();
+            CWP(5);
         }
-        if (wave != 0) CWP(23);
+    } else {
+        if (nblk > 0 && wave > 0) fetch_tiles(0, 0);
+        if (nblk > 0 && wave == 0) {                              // panel 0's diagonal tile is wave 0's, like every later one
+            MS_LDS double *t = tiles + (slot[0] * W + slot[0]) * CT;
+            const int c = lane & 15;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) { const int r = (lane >> 4) + 4 * k; t[r * CT_LD + c] = (r < n && c < n) ? Sg[(size_t)r * n + c] : 0.0; }
+        }
         __syncthreads();
-        CWP(5);
+        if (wave == 0 && nblk > 0) factor_diag(0);
+        __syncthreads();
+        CWP(0);
+        for (int p = 0; p < nblk; ++p) {
+            const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
+            MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
+            // A. rows below: x L11^T = a (a thread per row), and the panel's part of the rhs
+            const int a0 = act_start[p], m = act_start[p + 1] - a0;
+            // (column form: x_j = a_j / L_jj, then a_k -= x_j L_kj for k > j -- the same operations on every a_k in the same order as the dot-product
+            //  form, but the 15 - j updates of a step are independent of each other; column j of L11 is row j of LT)
+            auto solve_row = [&](double (&a)[NB]) {
+                if (nb == NB) {
+                    // row j + 1 of LT is requested before step j computes (the scheduler, left alone, put each row's reads right before their use: 16 exposed LDS latencies)
+                    const MS_LDS d2_t *LT2 = reinterpret_cast<const MS_LDS d2_t *>(LT), *tv2 = reinterpret_cast<const MS_LDS d2_t *>(tvec);
+                    d2_t tv[NB / 2], buf[2][NB / 2];
+    #pragma unroll
+                    for (int k = 0; k < NB / 2; ++k) tv[k] = tv2[k];
+    #pragma unroll
+                    for (int k = 0; k < NB / 2; ++k) buf[0][k] = LT2[k];
+    #pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        if (j + 1 < NB) {
+    #pragma unroll
+                            for (int k = (j + 2) / 2; k < NB / 2; ++k) buf[(j + 1) & 1][k] = LT2[(j + 1) * (NB / 2) + k];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        a[j] *= (j & 1) ? tv[j / 2].y : tv[j / 2].x;
+    #pragma unroll
+                        for (int k = j + 1; k < NB; ++k) a[k] -= a[j] * ((k & 1) ? buf[j & 1][k / 2].y : buf[j & 1][k / 2].x);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {                                          // the short last block
+    #pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        if (j < nb) {
+                            double sacc = a[j];
+    #pragma unroll
+                            for (int k = 0; k < j; ++k) sacc -= a[k] * Lpp[j * CT_LD + k];
+                            a[j] = sacc * tvec[j];
+                        }
+                    }
+                }
+            };
+            // (the panel's piece of the rhs is one more row when it lives in LDS: it rides in the wave that has lanes to spare)
+            for (int idx = tid; idx < 16 * m + (ZG ? 0 : 1); idx += NT) {
+                MS_LDS double *row = tiles;
+                if (idx < 16 * m) row = tiles + ((act[a0 + (idx >> 4)] >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
+                else if constexpr (!ZG) row = z + c0;
+                double x[NB];
+                MS_LDS d2_t *row2 = reinterpret_cast<MS_LDS d2_t *>(row);
+    #pragma unroll
+                for (int j = 0; j < NB / 2; ++j) { const d2_t v = row2[j]; x[2 * j] = v.x; x[2 * j + 1] = v.y; }
+                CWP(15);
+                solve_row(x);
+                CWP(16);
+                if (nb == NB) {
+    #pragma unroll
+                    for (int j = 0; j < NB / 2; ++j) row2[j] = d2_t{x[2 * j], x[2 * j + 1]};
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < NB; ++j) if (j < nb) row[j] = x[j];
+                }
+                CWP(17);
+            }
+            if (ZG && tid == NT - 1) {
+                double x[NB];
+    #pragma unroll
+                for (int j = 0; j < NB; ++j) x[j] = j < nb ? z[c0 + j] : 0.0;
+                solve_row(x);
+    #pragma unroll
+                for (int j = 0; j < NB; ++j) if (j < nb) z[c0 + j] = x[j];
+            }
+            CWP(1);
+            __syncthreads();
+            CWP(2);
+            // B. look-ahead: wave 0 brings the NEXT diagonal tile up to date (its update by this panel, or its first fetch) and factors it at
+            //    once -- the serial pivot chain runs beside the trailing update, the rhs update, the write-back of column p and the fetch of the
+            //    tiles that enter at the next panel, which the other seven waves share
+            const bool next_active = m > 0 && (act[a0] & 0xFFFF) == p + 1;       // block p+1 is in the window already (else it enters at p+1)
+            if (wave == 0) {
+                if (p + 1 < nblk) {
+                    const int s1 = slot[p + 1];
+                    if (next_active) update_pair(s1, s1, sp);
+                    else {
+                        MS_LDS double *t = tiles + (s1 * W + s1) * CT;
+                        const int c = lane & 15, gc = 16 * (p + 1) + c;
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int r = (lane >> 4) + 4 * k, gr = 16 * (p + 1) + r;
+                            t[r * CT_LD + c] = (gr < n && gc < n) ? Sg[(size_t)gr * n + gc] : 0.0;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    CWP(3);
+                    factor_diag(p + 1);
+                    CWP(4);
+                }
+            } else {
+                // the tiles that enter at the next panel are requested FIRST and parked in registers: their trip to L2 runs beside the updates
+                // and the write-back below (slots released a panel ago -- the host delays the reuse -- so the LDS stores at the end overwrite nothing in use)
+                const int le = p + 1 < nblk ? load_start[p + 2] : 0, e0 = p + 1 < nblk ? load_start[p + 1] + wave - 1 : 0;
+                double pf[4] = {0, 0, 0, 0};
+                int pf_dst = -1;
+                if (e0 < le) {
+                    const int ea = loads[2 * e0], eb = loads[2 * e0 + 1], bi = ea & 0xFFFF, bj = eb & 0xFFFF, c = lane & 15, gc = 16 * bj + c;
+                    pf_dst = ((ea >> 16) * W + (eb >> 16)) * CT + (lane >> 4) * CT_LD + c;
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int gr = 16 * bi + (lane >> 4) + 4 * k; if (gr < n && gc < n) pf[k] = Sg[(size_t)gr * n + gc]; }
+                }
+                CWP(18);
+                // trailing update: pair q of the lower triangle of the m active blocks (row-major: (0,0), (1,0), (1,1), (2,0) ...) goes to wave 1 + q % 7;
+                // (0,0) is the next diagonal tile when block p+1 is active already -- wave 0 has it
+                {
+                    const int npair = m * (m + 1) / 2;
+                    for (int q = wave - 1; q < npair; q += NW - 1) {
+                        int i = (int)((__builtin_sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+                        if ((i + 1) * (i + 2) / 2 <= q) ++i;               // (guard the float root at the triangle's corners)
+                        if (i * (i + 1) / 2 > q) --i;
+                        const int j = q - i * (i + 1) / 2;
+                        if (next_active && q == 0) continue;
+                        update_pair(act[a0 + i] >> 16, act[a0 + j] >> 16, sp);
+                    }
+                }
+                CWP(19);
+                const int t7 = tid - 64, N7 = NT - 64;
+                for (int idx = t7; idx < 16 * m; idx += N7) {         // the rhs below the panel: z_b -= L[b,p] z_p
+                    const int ea = act[a0 + (idx >> 4)], gr = 16 * (ea & 0xFFFF) + (idx & 15);
+                    if (gr >= n) continue;
+                    const MS_LDS double *row = tiles + ((ea >> 16) * W + sp) * CT + (idx & 15) * CT_LD;
+                    double sacc = z[gr];
+                    if (!ZG && nb == NB) {
+                        const MS_LDS d2_t *row2 = reinterpret_cast<const MS_LDS d2_t *>(row);
+                        d2_t rv[NB / 2];
+    #pragma unroll
+                        for (int k = 0; k < NB / 2; ++k) rv[k] = row2[k];
+    #pragma unroll
+                        for (int k = 0; k < NB; ++k) sacc -= ((k & 1) ? rv[k / 2].y : rv[k / 2].x) * z[c0 + k];
+                    } else {
+                        for (int k = 0; k < nb; ++k) sacc -= row[k] * z[c0 + k];
+                    }
+                    z[gr] = sacc;
+                }
+                CWP(20);
+                // column p of L goes out: tile wave-1 (+7 ...) of the panel's m + 1, four rows of 16 per lane and trip
+                for (int t = wave - 1; t <= m; t += NW - 1) {
+                    const int ea = t == 0 ? (p | (sp << 16)) : act[a0 + t - 1], c = lane & 15;
+                    const MS_LDS double *src = tiles + ((ea >> 16) * W + sp) * CT + (lane >> 4) * CT_LD + c;
+                    double v[4];
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = src[4 * k * CT_LD];
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = (lane >> 4) + 4 * k, gr = 16 * (ea & 0xFFFF) + r;
+                        if (gr < n && c < nb && (t > 0 || c <= r)) Sw[(size_t)gr * n + c0 + c] = v[k];
+                    }
+                }
+                CWP(21);
+                if (pf_dst >= 0) {
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) tiles[pf_dst + 4 * k * CT_LD] = pf[k];
+                }
+                CWP(22);
+                if (p + 1 < nblk) fetch_tiles(p + 1, NW - 1);     // a front that brings in more than seven tiles at once: the rest the plain way
+            }
+            if (wave != 0) CWP(23);
+            __syncthreads();
+            CWP(5);
+        }
     }
     // back substitution L^T x = z, panels in reverse, again in LDS: column p of L (the tiles this loop wrote out above) comes back one panel
     // ahead of its use (double buffer in the tile area), a thread per (active block, column) forms L[b,p]^T x_b, wave 0 solves the 16 x 16
@@ -1595,11 +1791,13 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         __syncthreads();
         CWP(6);
         double xprev = 0;
+        bool adjacent = false;                                 // block p+1 is coupled to panel p (the last panel has nothing below it)
         for (int p = nblk - 1; p >= 0; --p) {
             const int c0 = 16 * p;
             double pf[4] = {0, 0, 0, 0};
             int pf_dst = -1;
-            if (p > 1) {                                       // column p-2: tile `wave` of it into registers now, into its buffer at the end of the step
+            auto request_tile = [&]() {                        // column p-2: tile `wave` of it into registers now, into its buffer at the end of the step
+                if (p <= 1) return;
                 const int q = p - 2, fa0 = act_start[q], fm = act_start[q + 1] - fa0;
                 if (wave <= fm) {
                     const int b = wave == 0 ? q : (act[fa0 + wave - 1] & 0xFFFF), c = ln, gc = 16 * q + c;
@@ -1607,43 +1805,48 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { const int r = (lane >> 4) + 4 * k, gr = 16 * b + r; if (gr < n && gc < n && (wave > 0 || c < r)) pf[k] = Sg[(size_t)gr * n + gc]; }
                 }
-            }
+            };
             CWP(8);
             if (wave == 0) {
-                const int a0 = act_start[p], m = act_start[p + 1] - a0;
-                const bool adjacent = m > 0 && (act[a0] & 0xFFFF) == p + 1;
+                // everything this step reads is addressed without the index lists (they were read a step ago): the loads go out together
                 const MS_LDS double *T0 = tiles + ((p % 3) * W) * CT, *T1 = T0 + CT;
-                double rr = z[c0 + ln], col[NB];
+                double rr = z[c0 + ln], col[NB], t1[NB];
                 const double di = dvec[c0 + ln];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) col[j] = T0[j * CT_LD + ln];          // L[c0 + j][c0 + lane], zero on and above the diagonal
                 if (adjacent) {
-                    double t1[NB];
 #pragma unroll
                     for (int r = 0; r < NB; ++r) t1[r] = T1[r * CT_LD + ln];
-                    backsub_adjacent(rr, xprev, t1, std::make_integer_sequence<int, NB>{});
                 }
+                int a0n = 0, mn = 0, firstn = -1;              // the next step's coupling flag: its two dependent index reads hide behind this step's arithmetic
+                if (p > 0) { a0n = act_start[p - 1]; mn = act_start[p] - a0n; if (mn > 0) firstn = act[a0n] & 0xFFFF; }
+                if (adjacent) backsub_adjacent(rr, xprev, t1, std::make_integer_sequence<int, NB>{});
                 backsub_steps(rr, di, col, std::make_integer_sequence<int, NB>{});
                 xprev = rr * di;
                 if (lane < NB) z[c0 + lane] = xprev;
+                adjacent = firstn == p;
+                request_tile();
                 CWP(10);
-            } else if (wave == 1 && p > 0) {
-                // z_{p-1} -= sum over the blocks b >= p+1 of column p-1 of L[b,p-1]^T x_b (all of them final): the four 16-lane rows share the tiles out,
-                // their sums meet in `part`
-                const int q = p - 1, a0 = act_start[q], m = act_start[q + 1] - a0;
-                const int first = (m > 0 && (act[a0] & 0xFFFF) == q + 1) ? 1 : 0, rq = lane >> 4;
-                double sum = 0;
-                for (int e = first + rq; e < m; e += 4) {
-                    const int b = act[a0 + e] & 0xFFFF;
-                    const MS_LDS double *T = tiles + ((q % 3) * W + e + 1) * CT;
+            } else {
+                request_tile();
+                if (wave == 1 && p > 0) {
+                    // z_{p-1} -= sum over the blocks b >= p+1 of column p-1 of L[b,p-1]^T x_b (all of them final): the four 16-lane rows share the tiles out,
+                    // their sums meet in `part`
+                    const int q = p - 1, a0 = act_start[q], m = act_start[q + 1] - a0;
+                    const int first = (m > 0 && (act[a0] & 0xFFFF) == q + 1) ? 1 : 0, rq = lane >> 4;
+                    double sum = 0;
+                    for (int e = first + rq; e < m; e += 4) {
+                        const int b = act[a0 + e] & 0xFFFF;
+                        const MS_LDS double *T = tiles + ((q % 3) * W + e + 1) * CT;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sum += T[r * CT_LD + ln] * z[16 * b + r];
+                        for (int r = 0; r < 16; ++r) sum += T[r * CT_LD + ln] * z[16 * b + r];
+                    }
+                    part[lane] = sum;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < NB) z[16 * q + lane] -= (part[lane] + part[16 + lane]) + (part[32 + lane] + part[48 + lane]);
+                    CWP(10);
                 }
-                part[lane] = sum;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < NB) z[16 * q + lane] -= (part[lane] + part[16 + lane]) + (part[32 + lane] + part[48 + lane]);
-                CWP(10);
             }
             if (pf_dst >= 0) {
 #pragma unroll

@@ -15,14 +15,11 @@ lib.ms_debug_cwprof(a); d = [x - y for x, y in zip(list(a), b0)]
 w1raw = d[24:48]
 st = ba.download(0)["stats"]
 print("ms", ms, "trials", st["trials"], "calls", d[7], st["phase_cycles"])
-names = ["init", "A", "A-wait", "B-update-next", "B-factor", "B-wait", "bs-init", "", "bs-part", "bs-wait1", "bs-recur", "bs-store", "bs-wait2", "bs-out", "factor-core", "A-load", "A-solve", "A-store"]
-d7 = d[7]; d[7] = 0
-tot = sum(d[:18])
-d = d[:7] + [0] + d[8:]
-d.insert(0, 0); d.pop(0)
-for n, v in zip(names, d[:18]): print("%-14s %9.0f cyc/call  %5.1f%%" % (n, v / max(d7, 1), 100 * v / tot))
-print("total per call", tot / max(d7, 1))
-
-w1 = d[24:48] if len(d) >= 48 else None
-for n, i in (("w1 prefetch-issue", 18), ("w1 update pairs", 19), ("w1 z update", 20), ("w1 write-back", 21), ("w1 pf store (load wait)", 22), ("w1 rest", 23), ("w1 barrier wait", 5), ("w1 A", 1), ("w1 A-wait", 2)):
-    print("%-26s %9.0f cyc/call" % (n, w1raw[i] / max(d7, 1)))
+names = {0: "init", 1: "seg1 work", 2: "barrier 1", 4: "seg2 work", 5: "barrier 2", 6: "bs init", 8: "bs prefetch issue", 10: "bs chain", 11: "bs store", 12: "bs barrier", 13: "bs out",
+         19: "w pairs", 20: "w z update", 21: "w write-back", 22: "w pf store"}
+d7 = max(d[7], 1)
+for who, v in (("wave 0", d[:24]), ("wave 1", w1raw)):
+    tot = sum(x for i, x in enumerate(v) if i != 7)
+    print(who, "total per call %.0f" % (tot / d7))
+    for i, x in enumerate(v):
+        if i != 7 and x: print("   %-20s %9.0f cyc/call %5.1f%%" % (names.get(i, str(i)), x / d7, 100 * x / tot))
