@@ -298,6 +298,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ __forceinline__ double readlane_d(double v, int l) {          // wave-uniform broadcast of lane l's double (l uniform)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+__device__ __forceinline__ void lds_addd(MS_LDS double *p, double v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        // ds_add_f64
+}
 __device__ double block_sum(double v, double *s_red) {
     v = wave_sum_d(v);
     __syncthreads();
@@ -334,7 +337,10 @@ __device__ double block_max(double v, double *s_red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                               \
     const int T_ = P.team, rank_ = T_ > 1 ? (int)(blockIdx.x % (unsigned)T_) : 0;                                \
     const int gt = rank_ * NT + tid, GT = T_ * NT, gw = rank_ * NW + wave, GW = T_ * NW;                         \
-    (void)lane; (void)wave; (void)gt; (void)GT; (void)gw; (void)GW;
+    /* per-item loops with long bodies (a thread per point, a wave per edge): consecutive items go to DIFFERENT workgroups -- 2000 points */ \
+    /* on the first 2000 threads of a team are four workgroups at two waves per SIMD while 28 workgroups watch */                          \
+    const int gts = tid * T_ + rank_, gws = (NW - 1 - wave) * T_ + rank_;                                        \
+    (void)lane; (void)wave; (void)gt; (void)GT; (void)gw; (void)GW; (void)gts; (void)gws;
 
 __device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, uint32_t T) {
     if (T == 1) { __syncthreads(); return; }
@@ -450,15 +456,112 @@ __device__ __forceinline__ void poseobs_data(const BaProb &P, int o, int l, Pose
 }
 
 // ---------------------------------------------------------------- linearisation
+#ifdef MS_LIN_PROF
+__device__ long long g_lin[32 * 8 * 6];
+extern "C" int ms_debug_linprof(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin), sizeof(g_lin)); }
+#define LINP(i) do { if (lane == 0 && rank_ < 32) g_lin[(rank_ * 8 + wave) * 6 + i] = clock64() - lin_t0; } while (0)
+#else
+#define LINP(i) do { } while (0)
+#endif
 __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     const BaProb &P = P_;
     BA_IDS
     const int n6 = P.n6;
+#ifdef MS_LIN_PROF
+    const long long lin_t0 = clock64();
+#endif
     for (size_t i = gt; i < (size_t)n6 * n6; i += GT) P.Hpp[i] = 0;
     for (int i = gt; i < n6; i += GT) P.bp[i] = 0;
+    LINP(0);
     team_sync(P);
+    LINP(1);
+    // A team on a window whose sums fit the LDS: a THREAD PER OBSERVATION, once.  Workgroup r takes the points [n r / T, n (r+1) / T) and with them a
+    // contiguous run of the point-major observation list; each thread evaluates its observation (error, both Jacobians) and adds the point's
+    // Hll / bl terms and the pose's diagonal-block / gradient terms into two LDS tables with ds_add_f64.  The point table goes out with plain
+    // stores (the workgroup owns its points), the pose table with one global atomic per non-zero entry.  The thread-per-point loop below took
+    // 51 k cycles for its 62 points per workgroup (ten observations one after another), the wave-per-pose-slice pass after it another 50 k --
+    // each a walk over all observations with most of the lanes idle.  The SE3 edges keep their waves (the last ones of every workgroup), side by side with this.
+    const int lin_l0 = T_ > 1 ? (int)((long long)P.n_point * rank_ / T_) : 0, lin_l1 = T_ > 1 ? (int)((long long)P.n_point * (rank_ + 1) / T_) : 0;
+    const bool obs_par = T_ > 1 && P.fused && (size_t)NW * CH * 36 + 9 * (size_t)((P.n_point + T_ - 1) / T_ + 1) + 27 * (size_t)P.np_free + 64 <= kLdsBytes / 8;
+    if (obs_par) {
+        const int edge_waves_w = min(P.n_edge, GW / 2);        // the same split as below: waves with gws < edge_waves_w evaluate edges
+        MS_LDS double *ptab = (MS_LDS double *)lds_ + NW * CH * 36, *qtab = ptab + 9 * (lin_l1 - lin_l0);     // [points][H 6 | b 3], [free poses][A 21 | g 6]
+        __shared__ int s_lin_arrive;
+        const int n_ptab = 9 * (lin_l1 - lin_l0), n_qtab = 27 * P.np_free;
+        for (int i = tid; i < n_ptab + n_qtab; i += NT) ptab[i] = 0;
+        if (tid == 0) s_lin_arrive = 0;
+        __syncthreads();
+        const bool edge_wave = gws < edge_waves_w;
+        // the waves that have no edge: the observations of the workgroup's points, one per thread
+        int n_work_waves = 0;
+        for (int w = 0; w < NW; ++w) n_work_waves += ((NW - 1 - w) * T_ + rank_ < edge_waves_w) ? 0 : 1;
+        int my_slot = 0;
+        for (int w = 0; w < wave; ++w) my_slot += ((NW - 1 - w) * T_ + rank_ < edge_waves_w) ? 0 : 1;
+        if (!edge_wave) {
+            const int o_lo = P.pt_start[lin_l0], o_hi = P.pt_start[lin_l1];
+            for (int idx = o_lo + my_slot * 64 + lane; idx < o_hi; idx += 64 * n_work_waves) {
+                const int o = P.pt_obs[idx], pi = P.obs_pose[o], l = P.obs_point[o];
+                double pose[7], X[3], uv[2];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) pose[q] = P.pose[7 * (size_t)pi + q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) X[q] = P.point[3 * (size_t)l + q];
+                uv[0] = P.obs_uv[2 * (size_t)o]; uv[1] = P.obs_uv[2 * (size_t)o + 1];
+                const double info = P.obs_info[o];
+                const int fp = P.pidx[pi];
+                const bool lfree = !(P.point_fixed && P.point_fixed[l]);
+                double e[2], Jp[12], Jl[6];
+                proj_edge<true>(pose, X, uv, e, Jp, Jl);
+                const double chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+                double r, w;
+                huber(chi2, P.huber, r, w);
+                const double wi = w * info;
+                if (lfree) {
+                    MS_LDS double *t = ptab + 9 * (l - lin_l0);
+                    lds_addd(t + 0, wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3])); lds_addd(t + 1, wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4])); lds_addd(t + 2, wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]));
+                    lds_addd(t + 3, wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4])); lds_addd(t + 4, wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5])); lds_addd(t + 5, wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]));
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) lds_addd(t + 6 + a, -(Jl[a] * e[0] + Jl[3 + a] * e[1]) * wi);
+                }
+                if (fp >= 0) {
+                    MS_LDS double *t = qtab + 27 * fp;
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        lds_addd(t + 21 + a, -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi);
+#pragma unroll
+                        for (int b = a; b < 6; ++b) lds_addd(t + k++, wi * (Jp[a] * Jp[b] + Jp[6 + a] * Jp[6 + b]));
+                    }
+                }
+            }
+            // the working waves meet on an LDS counter (the edge waves are busy for ~20 k cycles more: a workgroup barrier would wait for them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) {
+                __hip_atomic_fetch_add(&s_lin_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(&s_lin_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_work_waves) __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int wt = my_slot * 64 + lane, WT = 64 * n_work_waves;
+            for (int i = wt; i < n_ptab; i += WT) {
+                const int lp = i / 9, c = i - 9 * lp, l = lin_l0 + lp;
+                if (c < 6) P.Hll[6 * (size_t)l + c] = ptab[i]; else P.bl[3 * (size_t)l + c - 6] = ptab[i];
+            }
+            for (int i = wt; i < n_qtab; i += WT) {
+                const double v = qtab[i];
+                if (v == 0) continue;
+                const int fp = i / 27, c = i - 27 * fp;
+                if (c >= 21) { atomicAdd(&P.bp[6 * fp + c - 21], v); continue; }
+                int a = 0, rem = c;
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int b = a + rem;
+                atomicAdd(&P.Hpp[(size_t)(6 * fp + a) * n6 + 6 * fp + b], v);
+                if (b != a) atomicAdd(&P.Hpp[(size_t)(6 * fp + b) * n6 + 6 * fp + a], v);
+            }
+        }
+    }
     // per point: Hll, bl, Hpl
-    for (int l = gt; l < P.n_point; l += GT) {
+    for (int l = obs_par ? P.n_point : gts; l < P.n_point; l += GT) {
         const bool lfree = !(P.point_fixed && P.point_fixed[l]);
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const double X[3] = {P.point[3 * (size_t)l], P.point[3 * (size_t)l + 1], P.point[3 * (size_t)l + 2]};
@@ -498,13 +601,14 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) P.bl[3 * (size_t)l + a] = b[a];
     }
+    LINP(2);
     // per free pose: Hpp diagonal block + bp (a wave per pose, lanes over its observations).  A team cuts every pose's observations into
     // slices so that all its waves have work, adds the slices' sums with fp64 atomics, and lets the first waves take the SE3 edges at the
     // same time (one wave per edge, ~27 k cycles each): both only ADD into Hpp / bp, so no barrier is needed between them.
     const int edge_waves = T_ > 1 ? min(P.n_edge, GW / 2) : 0;
-    const int PW = GW - edge_waves, pw = gw - edge_waves;
+    const int PW = GW - edge_waves, pw = gws - edge_waves;      // (gws: the edges land on the last waves of every workgroup, the point loop above kept the first ones busy)
     const int n_slice = T_ > 1 ? max(1, min(8, PW / max(P.np_free, 1))) : 1;
-    for (int u = pw; pw >= 0 && u < P.np_free * n_slice; u += PW) {
+    for (int u = pw; !obs_par && pw >= 0 && u < P.np_free * n_slice; u += PW) {
         const int fp = u / n_slice, sl = u - fp * n_slice;
         const int pi = P.free2pose[fp];
         double pose[7];
@@ -556,6 +660,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             }
         }
     }
+    LINP(3);
     if (T_ == 1) team_sync(P);
     // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior).  One workgroup: in rounds of 128, a LANE per edge evaluates it (error, both
     // 6x6 Jacobians; the edges of a round run side by side instead of one after another) and parks the result in LDS, then the
@@ -564,7 +669,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     // A wave per edge (every lane computing the same edge) took 190 k cycles per linearisation at 49 edges -- as long as 20 k observations.
     if (T_ > 1) {     // a team: one WAVE per edge, the team's waves side by side (every lane evaluates the edge; lane (a, b) < 36 forms the block entries)
         MS_LDS double *slab = (MS_LDS double *)lds_ + (size_t)wave * (CH * 36);      // [Ji 36][Jj 36][W 36][We 6]
-        for (int k = gw; gw < edge_waves && k < P.n_edge; k += edge_waves) {
+        for (int k = gws; gws < edge_waves && k < P.n_edge; k += edge_waves) {
             const int vi = P.edge_i[k], vj = P.edge_j[k], fi = P.pidx[vi], fj = P.pidx[vj];
             if (fi < 0 && fj < 0) continue;                                       // wave-uniform
             double e[6], Ji[36], Jj[36];
@@ -650,7 +755,9 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             __syncthreads();
         }
     }
+    LINP(4);
     team_sync(P);
+    LINP(5);
 }
 
 // The (observation a, observation b) pairs of a chunk, one per record piece this lane moves (9 pieces per lane) ...
@@ -999,7 +1106,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 __device__ __noinline__ void point_backsub_fused(const BaProb &P_, double lambda) {
     const BaProb &P = P_;
     BA_IDS
-    for (int l = gt; l < P.n_point; l += GT) {
+    for (int l = gts; l < P.n_point; l += GT) {
         double *dq = P.dl + 3 * (size_t)l;
         if (P.point_fixed && P.point_fixed[l]) { dq[0] = dq[1] = dq[2] = 0; continue; }
         double r[3] = {P.bl[3 * (size_t)l], P.bl[3 * (size_t)l + 1], P.bl[3 * (size_t)l + 2]};

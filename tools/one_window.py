@@ -1,5 +1,6 @@
+"""One C4 window on a team, timed alone: milliseconds per solve and the in-kernel phase cycles of the lead workgroup."""
 import sys, os
-R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("slam-module_amd", "tests"): sys.path.insert(0, os.path.join(R, p))
 import numpy as np, mi355slam, ba_synth
 ctx = mi355slam.Context(0)
