@@ -1103,9 +1103,59 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 
 // dl = (Hll + lambda I)^-1 (bl - sum_a W_a^T dp_a) with W_a = w info Jp^T Jl recomputed from the (unchanged) state:
 // W_a^T x = w info (Jl_row0 (Jp_row0 . x) + Jl_row1 (Jp_row1 . x))
-__device__ __noinline__ void point_backsub_fused(const BaProb &P_, double lambda) {
+__device__ __noinline__ void point_backsub_fused(const BaProb &P_, double lambda, double *lds_) {
     const BaProb &P = P_;
     BA_IDS
+    // a team: a thread per OBSERVATION again (like the linearisation): workgroup r owns the points [n r / T, n (r+1) / T), starts an LDS table
+    // from their bl, every observation takes its W^T dp off it with ds_add_f64, then a thread per point solves the 3 x 3 system
+    const int bs_l0 = T_ > 1 ? (int)((long long)P.n_point * rank_ / T_) : 0, bs_l1 = T_ > 1 ? (int)((long long)P.n_point * (rank_ + 1) / T_) : 0;
+    const bool obs_par = T_ > 1 && 3 * (size_t)((P.n_point + T_ - 1) / T_ + 1) <= kLdsBytes / 8;
+    if (obs_par) {
+        MS_LDS double *rtab = (MS_LDS double *)lds_;
+        for (int i = tid; i < 3 * (bs_l1 - bs_l0); i += NT) rtab[i] = P.bl[3 * (size_t)bs_l0 + i];
+        __syncthreads();
+        const int o_lo = P.pt_start[bs_l0], o_hi = P.pt_start[bs_l1];
+        for (int idx = o_lo + tid; idx < o_hi; idx += NT) {
+            const int o = P.pt_obs[idx], pi = P.obs_pose[o], l = P.obs_point[o], fa = P.pidx[pi];
+            if (fa < 0 || (P.point_fixed && P.point_fixed[l])) continue;       // an observation from a fixed pose moves nothing here
+            double pose[7], X[3], uv[2], x[6];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) pose[q] = P.pose[7 * (size_t)pi + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) X[q] = P.point[3 * (size_t)l + q];
+            uv[0] = P.obs_uv[2 * (size_t)o]; uv[1] = P.obs_uv[2 * (size_t)o + 1];
+            const double info = P.obs_info[o];
+            load6(P.dp + 6 * fa, x);
+            double e[2], Jp[12], Jl[6];
+            proj_edge<true>(pose, X, uv, e, Jp, Jl);
+            const double chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+            double rho, w;
+            huber(chi2, P.huber, rho, w);
+            const double wi = w * info;
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { s0 += Jp[a] * x[a]; s1 += Jp[6 + a] * x[a]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lds_addd(rtab + 3 * (l - bs_l0) + c, -(wi * (Jl[c] * s0 + Jl[3 + c] * s1)));
+        }
+        __syncthreads();
+        for (int l = bs_l0 + tid; l < bs_l1; l += NT) {
+            double *dq = P.dl + 3 * (size_t)l;
+            if (P.point_fixed && P.point_fixed[l]) { dq[0] = dq[1] = dq[2] = 0; continue; }
+            const double r[3] = {rtab[3 * (l - bs_l0)], rtab[3 * (l - bs_l0) + 1], rtab[3 * (l - bs_l0) + 2]};
+            double H[6];
+            load6(P.Hll + 6 * (size_t)l, H);
+            const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e2 = H[4], f = H[5] + lambda;
+            const double A = d * f - e2 * e2, B = c * e2 - b * f, C = b * e2 - c * d;
+            const double id = 1.0 / (a * A + b * B + c * C);
+            const double h0 = A * id, h1 = B * id, h2 = C * id, h3 = (a * f - c * c) * id, h4 = (b * c - a * e2) * id, h5 = (a * d - b * b) * id;
+            dq[0] = h0 * r[0] + h1 * r[1] + h2 * r[2];
+            dq[1] = h1 * r[0] + h3 * r[1] + h4 * r[2];
+            dq[2] = h2 * r[0] + h4 * r[1] + h5 * r[2];
+        }
+        team_sync(P);
+        return;
+    }
     for (int l = gts; l < P.n_point; l += GT) {
         double *dq = P.dl + 3 * (size_t)l;
         if (P.point_fixed && P.point_fixed[l]) { dq[0] = dq[1] = dq[2] = 0; continue; }
@@ -2154,7 +2204,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
     const bool ok = P.flag[0] != 0;
     if (!ok) return false;
-    if (fused) point_backsub_fused(P, lambda); else point_backsub(P);
+    if (fused) point_backsub_fused(P, lambda, lds); else point_backsub(P);
     cyc[4] += clock64() - t0;
     return true;
 }
