@@ -14,7 +14,7 @@ import csv, sys, collections
 # condensed: per kernel and counter, dispatches and totals (the raw file has one row per dispatch and counter)
 acc = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = (r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", ""), r["Counter_Name"])
+    k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], r["Counter_Name"])
     a = acc.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
 w = csv.writer(open(sys.argv[2], "w")); w.writerow(["kernel", "counter", "dispatches", "sum", "mean_per_dispatch"])
 for (k, c), (n, v) in acc.items(): w.writerow([k, c, n, v, v / n])
