@@ -977,12 +977,13 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 #pragma unroll
         for (int q = 0; q < 36; ++q) acc[q] = 0;
         int key = -1;                                              // fa << 16 | fb of the block held in acc
+        const int fs_run = T_ > 1 ? 5 : FS_RUN;      // (a team's fine pass has ~75 batches per workgroup: runs of 1 / 2 / 3 / 4 / 5 / 7 gave 2.22 / 2.08 / 2.00 / 1.99 / 1.96 / 1.98 ms per C4 window -- fewer block flushes against a longer tail)
         for (;;) {
         int b_lo = 0;
-        if (lane == 0) b_lo = pb0 + FS_RUN * atomicAdd(&s_fs_next, 1);
+        if (lane == 0) b_lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
         b_lo = __builtin_amdgcn_readfirstlane(b_lo);
         if (b_lo >= pb1) break;
-        const int b_hi = min(b_lo + FS_RUN, pb1);
+        const int b_hi = min(b_lo + fs_run, pb1);
         i4_t rec = {0, 0, 0, -1};
         int o0 = 0, nobs = 0;
         { o0 = b_obs[b_lo]; nobs = b_obs[b_lo + 1] - o0; if (lane < nobs) rec = pobs4[o0 + lane]; }
