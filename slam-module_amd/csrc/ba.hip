@@ -56,8 +56,10 @@ struct FsSet {
     const int32_t *pobs;                     // per lane slot: observation, pose vertex, point, free pose index (int4)
     const uint16_t *pairs;                   // chunks of 8 pairs (a_lane | b_lane << 8, 0xFFFF = none): the pairs of a chunk fall into the same block (pose a,
                                              // pose b); a batch's chunks are sorted by block
-    const int32_t *rowoff;                   // [np_free] offset (doubles) of pose row fa inside its pass's tile
-    const int32_t *yoff;                     // [n_pass] offset of the pass's rhs segment (6 doubles per row) = size of its matrix part
+    const int32_t *rowoff;                   // per pass, concatenated: offset (doubles) of pose row r0 + i inside the pass's tile
+    const int32_t *yoff;                     // [n_pass][2]: offset of the pass's rhs segment (6 doubles per row) = size of its matrix part; start of the pass in rowoff
+    int32_t by_points;                       // 0: a pass owns its rows of S (every point that touches them is visited; plain stores).  1: a pass owns a SET OF POINTS
+                                             // (each point visited once in the whole launch); the passes' row ranges overlap and their sums meet in S through atomics
 };
 
 struct BaProb {
@@ -943,7 +945,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
     MS_LDS double *stage = (MS_LDS double *)lds_ + (size_t)wave * (FS_OB * 18);
     MS_LDS int32_t *meta = (MS_LDS int32_t *)((MS_LDS double *)lds_ + kFsStageDoubles) + wave * FS_OB;
     MS_LDS double *tile = (MS_LDS double *)lds_ + kFsStageDoubles + kFsMetaDoubles;
-    const MS_GLOBAL int32_t *cs = (const MS_GLOBAL int32_t *)P.fs_cs, *rowoff = (const MS_GLOBAL int32_t *)F.rowoff, *env = (const MS_GLOBAL int32_t *)P.env16;
+    const MS_GLOBAL int32_t *cs = (const MS_GLOBAL int32_t *)P.fs_cs, *env = (const MS_GLOBAL int32_t *)P.env16;
     const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)F.pobs;
     const MS_GLOBAL u4_t *chunks = (const MS_GLOBAL u4_t *)F.pairs;
     const MS_GLOBAL uint16_t *pairs16 = (const MS_GLOBAL uint16_t *)F.pairs;
@@ -951,17 +953,33 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
     const MS_GLOBAL int32_t *b_obs = (const MS_GLOBAL int32_t *)F.b_obs_start, *b_run = (const MS_GLOBAL int32_t *)F.b_run_start;
     const MS_GLOBAL double *Hpp = (const MS_GLOBAL double *)P.Hpp;
     MS_GLOBAL double *Sg = (MS_GLOBAL double *)P.S;
+    const bool by_pts = F.by_points != 0;
+    if (by_pts) {
+        // the passes own points, not rows: S <- Hpp + lambda I (envelope part; zeros from the 16-row block's envelope up to it) and y <- bp first, by the whole
+        // team, then every pass takes its points' products off them with atomics
+        for (int row = gw; row < n; row += GW) {
+            const int fa = row / 6, c0 = cs[fa], len = 6 * fa + 6 - c0, z0 = env[row >> 4] & ~15;
+            const MS_GLOBAL double *hrow = Hpp + (size_t)row * n + c0;
+            MS_GLOBAL double *srow = Sg + (size_t)row * n;
+            for (int c = z0 + lane; c < c0; c += 64) srow[c] = 0.0;
+            for (int c = lane; c < len; c += 64) srow[c0 + c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
+        }
+        for (int i = gt; i < n; i += GT) P.y[i] = P.bp[i];
+        team_sync(P);
+    }
     for (int pass = rank_; pass < F.n_pass; pass += T_) {
-        const int r0 = F.row0[pass], r1 = F.row1[pass], yoff = F.yoff[pass];
+        const int r0 = F.row0[pass], r1 = F.row1[pass], yoff = F.yoff[2 * pass];
+        const MS_GLOBAL int32_t *rowoff = (const MS_GLOBAL int32_t *)F.rowoff + F.yoff[2 * pass + 1] - r0;      // rowoff[fa] for the rows of this pass
         const long long tp0 = clock64();
-        // tile <- Hpp (the envelope part of the pass's rows) + lambda I, rhs segment <- bp
+        // tile <- Hpp (the envelope part of the pass's rows) + lambda I, rhs segment <- bp (or zeros: a pass that owns points only collects their sums)
         for (int rr = wave; rr < 6 * (r1 - r0); rr += NW) {
             const int fa = r0 + rr / 6, i = rr - 6 * (rr / 6), row = 6 * fa + i, c0 = cs[fa], len = 6 * fa + 6 - c0;
             MS_LDS double *trow = tile + rowoff[fa] + i * len;
             const MS_GLOBAL double *hrow = Hpp + (size_t)row * n + c0;
-            for (int c = lane; c < len; c += 64) trow[c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
+            if (by_pts) { for (int c = lane; c < len; c += 64) trow[c] = 0.0; }
+            else for (int c = lane; c < len; c += 64) trow[c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
         }
-        for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = P.bp[6 * r0 + i];
+        for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = by_pts ? 0.0 : P.bp[6 * r0 + i];
         if (tid == 0) s_fs_next = 0;
         __syncthreads();
         const long long tp1 = clock64();
@@ -977,7 +995,9 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 #pragma unroll
         for (int q = 0; q < 36; ++q) acc[q] = 0;
         int key = -1;                                              // fa << 16 | fb of the block held in acc
-        const int fs_run = T_ > 1 ? 5 : FS_RUN;      // (a team's fine pass has ~75 batches per workgroup: runs of 1 / 2 / 3 / 4 / 5 / 7 gave 2.22 / 2.08 / 2.00 / 1.99 / 1.96 / 1.98 ms per C4 window -- fewer block flushes against a longer tail)
+        // runs per hand-out: a row pass of a team has ~75 batches per workgroup (runs of 1 / 2 / 3 / 4 / 5 / 7 gave 2.22 / 2.08 / 2.00 / 1.99 / 1.96 / 1.98 ms per C4 window:
+        // fewer block flushes against a longer tail); a pass that owns points has ~10, one at a time
+        const int fs_run = by_pts ? 1 : (T_ > 1 ? 5 : FS_RUN);
         for (;;) {
         int b_lo = 0;
         if (lane == 0) b_lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
@@ -1093,10 +1113,14 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             const int fa = r0 + rr / 6, i = rr - 6 * (rr / 6), row = 6 * fa + i, c0 = cs[fa], len = 6 * fa + 6 - c0, z0 = env[row >> 4] & ~15;
             const MS_LDS double *trow = tile + rowoff[fa] + i * len;
             MS_GLOBAL double *srow = Sg + (size_t)row * n;
+            if (by_pts) { for (int c = lane; c < len; c += 64) { const double v = trow[c]; if (v != 0) atomicAdd(P.S + (size_t)row * n + c0 + c, v); } continue; }
             for (int c = z0 + lane; c < c0; c += 64) srow[c] = 0.0;
             for (int c = lane; c < len; c += 64) srow[c0 + c] = trow[c];
         }
-        for (int i = tid; i < 6 * (r1 - r0); i += NT) P.y[6 * r0 + i] = tile[yoff + i];
+        for (int i = tid; i < 6 * (r1 - r0); i += NT) {
+            if (by_pts) { const double v = tile[yoff + i]; if (v != 0) atomicAdd(&P.y[6 * r0 + i], v); }
+            else P.y[6 * r0 + i] = tile[yoff + i];
+        }
         __syncthreads();
     }
     team_sync(P);
@@ -2348,7 +2372,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     auto tm_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tm0 = tm_now();
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; };
+    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; bool by_points = false; };
     struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
     std::vector<Prep> prep(n);
@@ -2494,38 +2518,76 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             for (int set = 0; set < 2 && ok; ++set) {
                 if (set != R.fs_only) continue;
                 FsHost &F = R.fs[set];
-                // coarse set: as many rows per pass as the tile takes.  Fine set: one pass per workgroup of the team the launch will get, cut so that
-                // the passes carry about the same number of block products (a row's cost = its observations' partners on earlier poses: rows at the
-                // start of the window are cheap, and an even row count per pass left a third of the team waiting for the rest)
-                std::vector<double> rowcost(np, 1.0), cum(np + 1, 0.0);
-                if (set == 1)
-                    for (int l = 0; l < Q.n_point; ++l)
-                        for (int jj = fp_start[l]; jj < fp_start[l + 1]; ++jj) rowcost[fp_f[jj]] += 2.0 * (jj - fp_start[l] + 1);
-                for (int f = 0; f < np; ++f) cum[f + 1] = cum[f] + rowcost[f];
+                // coarse set (set 0): as many rows per pass as the tile takes
                 const int want_passes = set == 0 ? 1 : std::max(1, std::min(pred_team, np));
-                F.rowoff.assign(np, 0);
-                int r = 0;
-                while (r < np) {                                          // greedy row ranges under the tile budget
-                    int r1 = r, used = 0;
-                    const double stop = set == 0 ? 1e300 : cum[np] * (double)(F.row0.size() + 1) / want_passes;
-                    while (r1 < np) {
-                        const int need = 36 * (r1 - first[r1] + 1) + 6;
-                        if (used + need > kFsTileDoubles) break;
-                        if (r1 > r && cum[r1 + 1] - 0.5 * rowcost[r1] > stop) break;
-                        used += need; ++r1;
-                    }
+                auto add_pass = [&](int r, int r1) {                      // rows [r, r1): their envelope parts side by side in the tile, then the rhs segment
                     F.row0.push_back(r); F.row1.push_back(r1);
+                    F.yoff.push_back(0); F.yoff.push_back((int32_t)F.rowoff.size());
                     int off2 = 0;
-                    for (int f = r; f < r1; ++f) { F.rowoff[f] = off2; off2 += 36 * (f - first[f] + 1); }
-                    F.yoff.push_back(off2);
-                    r = r1;
+                    for (int f = r; f < r1; ++f) { F.rowoff.push_back(off2); off2 += 36 * (f - first[f] + 1); }
+                    F.yoff[F.yoff.size() - 2] = off2;
+                };
+                auto tile_need = [&](int r, int r1) { int u = 0; for (int f = r; f < r1; ++f) u += 36 * (f - first[f] + 1) + 6; return u; };
+                // set 1 (teams): the POINTS are dealt out, not the rows -- a pass is a run of points (in the order of their first pose) with about 1 / team of the
+                // block products; its rows are the poses those points see (they overlap with the neighbours': the sums meet in S through atomics).  Every
+                // observation is then linearised once per damped solve.  (Row passes made each of the 32 workgroups re-evaluate every point that touches its
+                // one or two rows: 8x the observations, 75 batches per workgroup instead of 10.)
+                std::vector<std::vector<int32_t>> group_pts;
+                F.by_points = false;
+                if (set == 1) {
+                    std::vector<std::pair<uint32_t, int32_t>> order;      // (first pose << 16 | last pose, point)
+                    double total_cost = 0;
+                    for (int l = 0; l < Q.n_point; ++l) {
+                        const int k = fp_start[l + 1] - fp_start[l];
+                        if (k == 0) continue;
+                        order.emplace_back(((uint32_t)fp_f[fp_start[l]] << 16) | (uint32_t)fp_f[fp_start[l + 1] - 1], l);
+                        total_cost += 8.0 * k + 0.5 * k * (k + 1);
+                    }
+                    std::sort(order.begin(), order.end());
+                    double acc_cost = 0;
+                    int g_lo = np, g_hi = 0;
+                    group_pts.emplace_back();
+                    for (const auto &e : order) {
+                        const int l = e.second, k = fp_start[l + 1] - fp_start[l], lo = std::min(g_lo, (int)(e.first >> 16)), hi = std::max(g_hi, (int)(e.first & 0xFFFF) + 1);
+                        const bool full = !group_pts.back().empty() && (tile_need(lo, hi) > kFsTileDoubles ||
+                                          ((int)group_pts.size() < want_passes && acc_cost >= total_cost * (double)group_pts.size() / want_passes));
+                        if (full) { add_pass(g_lo, g_hi); group_pts.emplace_back(); g_lo = (int)(e.first >> 16); g_hi = (int)(e.first & 0xFFFF) + 1; }
+                        else { g_lo = lo; g_hi = hi; }
+                        group_pts.back().push_back(l);
+                        acc_cost += 8.0 * k + 0.5 * k * (k + 1);
+                    }
+                    if (!group_pts.back().empty()) add_pass(g_lo, g_hi); else group_pts.pop_back();
+                    F.by_points = true;
+                    // a point seen from poses so far apart that the rows between them do not fit the tile (scattered covisibility): row passes for this window
+                    for (size_t ps = 0; ps < F.row0.size(); ++ps) if (tile_need(F.row0[ps], F.row1[ps]) > kFsTileDoubles) F.by_points = false;
+                    if (!F.by_points) { F.row0.clear(); F.row1.clear(); F.yoff.clear(); F.rowoff.clear(); group_pts.clear(); }
+                }
+                if (!F.by_points) {
+                    int r = 0;
+                    while (r < np) {                                      // greedy row ranges under the tile budget
+                        int r1 = r, used = 0;
+                        while (r1 < np) {
+                            const int need = 36 * (r1 - first[r1] + 1) + 6;
+                            if (used + need > kFsTileDoubles) break;
+                            used += need; ++r1;
+                        }
+                        add_pass(r, r1);
+                        r = r1;
+                    }
                 }
                 F.batch_start.push_back(0); F.b_obs_start.push_back(0); F.b_run_start.push_back(0);
-                F.pobs.reserve(4 * fp_f.size() * (set ? 6 : 2)); F.pairs.reserve(8 * fp_f.size());
+                F.pobs.reserve(4 * fp_f.size() * 2); F.pairs.reserve(8 * fp_f.size());
                 std::fill(stamp.begin(), stamp.end(), -1);
                 for (size_t ps = 0; ps < F.row0.size(); ++ps) {
                     const int r0 = F.row0[ps], r1 = F.row1[ps];
                     pts.clear();
+                    if (F.by_points) {
+                        for (int l : group_pts[ps]) {
+                            uint64_t h = 1469598103934665603ull; int fmin = 0x7fff, fmax = 0, kk = 0;
+                            for (int jj = fp_start[l]; jj < fp_start[l + 1]; ++jj) { h = (h ^ (uint64_t)fp_f[jj]) * 1099511628211ull; fmin = std::min(fmin, (int)fp_f[jj]); fmax = fp_f[jj]; ++kk; }
+                            pts.emplace_back(((uint64_t)fmin << 48) | ((uint64_t)fmax << 32) | ((uint64_t)(kk & 0xFF) << 24) | (h & 0xFFFFFFull), l);
+                        }
+                    } else
                     for (int fa = r0; fa < r1; ++fa)
                         for (int ii = R.fstart[fa]; ii < R.fstart[fa + 1]; ++ii) {
                             const int l = Q.obs_point[R.fobs[ii]];
@@ -2757,7 +2819,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             F.n_pass = (int32_t)R.fs[set].row0.size();
             F.row0 = PTR(int32_t, fs_row0[set]); F.row1 = PTR(int32_t, fs_row1[set]); F.batch_start = PTR(int32_t, fs_batch[set]);
             F.b_obs_start = PTR(int32_t, fs_bobs[set]); F.b_run_start = PTR(int32_t, fs_brun[set]); F.b_fmt = PTR(int32_t, fs_bfmt[set]); F.pobs = PTR(int32_t, fs_pobs[set]);
-            F.pairs = PTR(uint16_t, fs_pairs[set]); F.rowoff = PTR(int32_t, fs_rowoff[set]); F.yoff = PTR(int32_t, fs_yoff[set]);
+            F.pairs = PTR(uint16_t, fs_pairs[set]); F.rowoff = PTR(int32_t, fs_rowoff[set]); F.yoff = PTR(int32_t, fs_yoff[set]); F.by_points = R.fs[set].by_points ? 1 : 0;
         }
         if (R.fused) H.fs[1 - R.fs_only] = H.fs[R.fs_only];          // the set that was not built aliases the one that was
         H.fused = R.fused ? 1 : 0;
