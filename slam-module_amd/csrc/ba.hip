@@ -2761,11 +2761,18 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     }
     const double tm1 = tm_now();
     ms_ba *B = new ms_ba();
-    B->ctx = c; B->n = n; B->arena_bytes = total;
-    if (hipMalloc(reinterpret_cast<void **>(&B->d_arena), total) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&B->d_probs), sizeof(BaProb) * n) != hipSuccess) {
-        if (B->d_arena) (void)hipFree(B->d_arena);
-        delete B;
-        return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes", total);
+    B->ctx = c; B->n = n;
+    {   // ONE device block per handle (arena + the problem descriptors behind it), taken from the context's cache of destroyed handles when one is large enough
+        const size_t probs_at = ms_align_up(total, 256), need = probs_at + sizeof(BaProb) * n;
+        int best = -1;
+        for (int i = 0; i < 4; ++i)
+            if (c->ba_cache[i].p && c->ba_cache[i].bytes >= need && (best < 0 || c->ba_cache[i].bytes < c->ba_cache[best].bytes)) best = i;
+        if (best >= 0) { B->d_arena = static_cast<char *>(c->ba_cache[best].p); B->arena_bytes = c->ba_cache[best].bytes; c->ba_cache[best] = {}; }
+        else {
+            if (hipMalloc(reinterpret_cast<void **>(&B->d_arena), need) != hipSuccess) { delete B; return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes", need); }
+            B->arena_bytes = need;
+        }
+        B->d_probs = reinterpret_cast<BaProb *>(B->d_arena + probs_at);
     }
     (void)hipMemsetAsync(B->d_arena, 0, total, c->stream);
     B->host.resize(n); B->dims.assign(problems, problems + n);
@@ -2847,8 +2854,17 @@ void ms_ba_destroy(ms_ba *B) {
     if (!B) return;
     (void)hipSetDevice(B->ctx->device);
     (void)hipStreamSynchronize(B->ctx->stream);
-    if (B->d_arena) (void)hipFree(B->d_arena);
-    if (B->d_probs) (void)hipFree(B->d_probs);
+    if (B->d_arena) {                                               // back to the context's cache; when that is full the smallest block goes
+        ms_ctx *c = B->ctx;
+        int slot = -1;
+        for (int i = 0; i < 4; ++i) if (!c->ba_cache[i].p) { slot = i; break; }
+        if (slot < 0) {
+            int small = 0;
+            for (int i = 1; i < 4; ++i) if (c->ba_cache[i].bytes < c->ba_cache[small].bytes) small = i;
+            if (c->ba_cache[small].bytes < B->arena_bytes) { (void)hipFree(c->ba_cache[small].p); c->ba_cache[small] = {}; slot = small; }
+        }
+        if (slot >= 0) { c->ba_cache[slot].p = B->d_arena; c->ba_cache[slot].bytes = B->arena_bytes; } else (void)hipFree(B->d_arena);
+    }
     delete B;
 }
 

@@ -46,6 +46,7 @@ void ms_ctx_destroy(ms_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->scratch) (void)hipFree(c->scratch);
+    for (auto &b : c->ba_cache) if (b.p) (void)hipFree(b.p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto &e : c->slots) if (e) (void)hipEventDestroy(e);
