@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--ba-steps", type=int, default=3)
     ap.add_argument("--c5-frames", type=int, default=40, help="frames per sequence in the C5 leg")
     ap.add_argument("--c5-keyframe-every", type=int, default=5)
+    ap.add_argument("--c5-native", action="store_true", help="drive the C5 sequences from C++ threads (tools/c5_native.cpp) instead of Python threads")
     ap.add_argument("--plumbing", action="store_true", help="no GPU work: launcher / rendezvous / aggregation only (gloo)")
     ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="with --plumbing: this rank exits with code 3 (launcher test)")
     ap.add_argument("--master-port", type=int, default=0)
@@ -685,35 +686,76 @@ def bench_c5(R, args):
     from mi355slam import shard
     mine = [s for s in range(N_SEQ) if shard.sequence_of(s, R.world) == R.rank]
     F = args.c5_frames
-    start = threading.Event()
-    runners = []
+    import numpy as np
+    seq_frames, seq_windows = [], []
     for s in mine:
         g = synth.SequenceSynth(W, H, 2000 + s, 2 * (F - 1), F - 1)
-        import numpy as np
-        frames = np.stack([g.frame(2 * i, i) for i in range(F)])
-        windows = [] if args.no_ba else [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + 16 * s + k) for k in range(4)]
-        runners.append(SequenceRunner(R.local_rank, s, frames, windows, args.c5_keyframe_every, start))
-    for r in runners:
-        r.start()
-    for r in runners:
-        r.ready.wait()
-    R.barrier()
-    t0 = time.perf_counter()
-    start.set()
-    for r in runners:
-        r.join()
-    R.barrier()
-    dt = time.perf_counter() - t0
-    errs = [r.error for r in runners if r.error]
-    if errs:
-        raise errs[0]
-    frames_total, dt_max = R.aggregate(sum(r.frames_done for r in runners), dt)
-    ba_total, _ = R.aggregate(sum(r.ba_done for r in runners), dt)
+        seq_frames.append(np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(F)])))
+        seq_windows.append([] if args.no_ba else [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + 16 * s + k) for k in range(4)])
+    native = _c5_native_lib() if args.c5_native else None
+    if native is not None and mine:
+        # the sequences' threads are C++ (tools/c5_native.cpp, the C ABI and nothing else).  Measured equal to the Python threads below (3.4 k frames/s + 690 BA/s
+        # for 8 sequences on one GPU either way): the leg is bound by how many small kernels of 8 streams the GPU runs side by side, not by the interpreter
+        import ctypes as C
+        import mi355slam
+        windows = [w for ws in seq_windows[:1] for w in ws]       # the same four windows for every sequence of this rank (distinct per rank)
+        structs, keep = zip(*[mi355slam._ba_struct(w, 10) for w in windows]) if windows else ((), ())
+        warr = (mi355slam.BaProblemC * max(len(structs), 1))(*structs)
+        fptr = (C.c_void_p * len(mine))(*[f.ctypes.data for f in seq_frames])
+        native.c5_prepare.restype = C.c_void_p
+        job = native.c5_prepare(R.local_rank, len(mine), F, W, H, fptr, warr, len(structs), args.c5_keyframe_every, LEVELS, C.c_float(SCALE), MAX_KPTS, FAST_THR, C.c_float(LOWE_RATIO))
+        if not job:
+            raise RuntimeError("c5_prepare failed")
+        secs, seq_s = C.c_double(), (C.c_double * len(mine))()
+        fd, bd_, lm = (C.c_int32 * len(mine))(), (C.c_int32 * len(mine))(), (C.c_int32 * len(mine))()
+        err = C.create_string_buffer(512)
+        R.barrier()
+        t0 = time.perf_counter()
+        rc = native.c5_go(C.c_void_p(job), C.byref(secs), seq_s, fd, bd_, lm, err, 512)
+        R.barrier()
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("c5 native driver: %s (status %d)" % (err.value.decode(), rc))
+        frames_mine, ba_mine, matches, driver = sum(fd), sum(bd_), list(lm), "native (tools/c5_native.cpp: one C++ thread per sequence on the C ABI)"
+        del keep
+    else:
+        start = threading.Event()
+        runners = [SequenceRunner(R.local_rank, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start) for k, s in enumerate(mine)]
+        for r in runners:
+            r.start()
+        for r in runners:
+            r.ready.wait()
+        R.barrier()
+        t0 = time.perf_counter()
+        start.set()
+        for r in runners:
+            r.join()
+        R.barrier()
+        dt = time.perf_counter() - t0
+        errs = [r.error for r in runners if r.error]
+        if errs:
+            raise errs[0]
+        frames_mine, ba_mine, matches, driver = sum(r.frames_done for r in runners), sum(r.ba_done for r in runners), [r.matches for r in runners], "python threads (SequenceRunner)"
+    frames_total, dt_max = R.aggregate(frames_mine, dt)
+    ba_total, _ = R.aggregate(ba_mine, dt)
     return {"workload": "8 independent 720p sequences x %d frames; per frame extract -> match vs previous -> ratio test; every %d-th frame a local BA of a new "
                         "C4 window (create + solve + download); sequence s on GPU s mod N, one host thread + context per sequence" % (F, args.c5_keyframe_every),
+            "driver": driver,
             "scaling": "strong (8 sequences in total)", "frames_per_s": round(frames_total / dt_max, 1), "ba_per_s": round(ba_total / dt_max, 1),
-            "seconds": round(dt_max, 4), "per_gpu": [round(v, 1) for v in R.gather(sum(r.frames_done for r in runners) / dt)],
-            "sequences_per_gpu": R.gather(len(mine)), "last_frame_matches": [r.matches for r in runners]}
+            "seconds": round(dt_max, 4), "per_gpu": [round(v, 1) for v in R.gather(frames_mine / dt)],
+            "sequences_per_gpu": R.gather(len(mine)), "last_frame_matches": matches}
+
+
+def _c5_native_lib():
+    """The native C5 driver built next to the library (make -C slam-module_amd/csrc), or None."""
+    import ctypes as C
+    path = os.path.join(ROOT, "slam-module_amd", "lib", "libc5native.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path)
+    except OSError:
+        return None
 
 
 def ctx_download(ctx, dev_ptr, nbytes):
