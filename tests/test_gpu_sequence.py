@@ -57,3 +57,43 @@ def test_eight_frame_sequence_matches_oracle(oracle):
         raise r.error
     assert seen["frames"] == F and r.frames_done == F and seen["ba"] == 2 and r.ba_done == 2        # keyframes 0 and 5
     assert seen["matches"] > 3000                                    # the sequence really matches frame to frame
+
+
+def test_native_driver_counts_what_the_python_driver_counts():
+    """bench.py --c5-native (tools/c5_native.cpp, C++ threads on the C ABI) against bench.SequenceRunner on the same two sequences: frames,
+    bundle adjustments and the last frame's accepted matches."""
+    import ctypes as C
+    import bench
+    import mi355slam
+    import synth
+    lib = bench._c5_native_lib()
+    assert lib is not None, "slam-module_amd/lib/libc5native.so is missing (make -C slam-module_amd/csrc)"
+    F, S = 6, 2
+    seqs = []
+    for s in range(S):
+        g = synth.SequenceSynth(bench.W, bench.H, 2100 + s, 2 * (F - 1), F - 1)
+        seqs.append(np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(F)])))
+    windows = [ba_synth.make_problem_fast(20, 500, 8, seed=80 + k) for k in range(2)]
+    start = threading.Event(); start.set()
+    runners = [bench.SequenceRunner(0, s, seqs[s], windows, 5, start) for s in range(S)]
+    for r in runners:
+        r.start()
+    for r in runners:
+        r.join()
+        if r.error is not None:
+            raise r.error
+    structs, keep = zip(*[mi355slam._ba_struct(w, 10) for w in windows])
+    warr = (mi355slam.BaProblemC * len(structs))(*structs)
+    fptr = (C.c_void_p * S)(*[f.ctypes.data for f in seqs])
+    lib.c5_prepare.restype = C.c_void_p
+    job = lib.c5_prepare(0, S, F, bench.W, bench.H, fptr, warr, len(structs), 5, bench.LEVELS, C.c_float(bench.SCALE), bench.MAX_KPTS, bench.FAST_THR, C.c_float(bench.LOWE_RATIO))
+    assert job
+    secs, seq_s = C.c_double(), (C.c_double * S)()
+    fd, bd, lm = (C.c_int32 * S)(), (C.c_int32 * S)(), (C.c_int32 * S)()
+    err = C.create_string_buffer(512)
+    rc = lib.c5_go(C.c_void_p(job), C.byref(secs), seq_s, fd, bd, lm, err, 512)
+    assert rc == 0, err.value
+    del keep
+    assert list(fd) == [r.frames_done for r in runners] == [F] * S
+    assert list(bd) == [r.ba_done for r in runners] == [2] * S
+    assert list(lm) == [r.matches for r in runners] and min(lm) > 500
