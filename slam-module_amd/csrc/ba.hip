@@ -2854,6 +2854,11 @@ void ms_ba_destroy(ms_ba *B) {
     if (!B) return;
     (void)hipSetDevice(B->ctx->device);
     (void)hipStreamSynchronize(B->ctx->stream);
+    {   // every team launch of this stream has finished: its entries leave the admission list now, before the stream itself can go away (an event
+        // queried after its stream was destroyed answered "operation not permitted on an event last recorded in a capturing stream" once in ~20 runs)
+        std::lock_guard<std::mutex> lk(g_team_mu);
+        for (TeamLaunch &t : g_team_live[B->ctx->device & 63]) if (t.live && t.stream == B->ctx->stream) t.live = false;
+    }
     if (B->d_arena) {                                               // back to the context's cache; when that is full the smallest block goes
         ms_ctx *c = B->ctx;
         int slot = -1;
@@ -2918,7 +2923,10 @@ int ms_ba_solve(ms_ba *B) {
         const int need = B->n * team;
         int in_use = 0;
         for (TeamLaunch &t : live) {                                   // retire what has finished; launches of this stream precede the new one anyway
-            if (t.live && hipEventQuery(t.ev) == hipSuccess) t.live = false;
+            if (t.live) {                                              // anything but "not ready" retires the entry (an error: the stream it was recorded on is gone)
+                const hipError_t q = hipEventQuery(t.ev);
+                if (q != hipErrorNotReady) { t.live = false; if (q != hipSuccess) (void)hipGetLastError(); }
+            }
             if (t.live && t.stream != c->stream) in_use += t.wgs;
         }
         for (TeamLaunch &t : live) {                                   // oldest first: wait (on the device) for as many as it takes to make room

@@ -599,8 +599,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(FrameSrc src, const PyrGe
 // decided -- the unique fixed point is exactly the greedy result; the first `quota` kept corners are output.
 constexpr int kGridCells = 8192;
 
-template <bool SPACED>   // SPACED: some level has a minimum keypoint distance (uses 66 KB more LDS for the grid)
-__global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t *__restrict__ cand, const int32_t *__restrict__ cand_count,
+// NTH: threads per block.  256 for a batch (thousands of blocks); 1024 when only a few frames are in flight -- a level's candidates are then walked by ONE block
+// five times (four radix passes and the gather), and a single 720p frame's level 0 has tens of thousands of them: 54 us of a frame's 143 us with 256 threads.
+template <bool SPACED, int NTH>   // SPACED: some level has a minimum keypoint distance (uses 66 KB more LDS for the grid)
+__global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t *__restrict__ cand, const int32_t *__restrict__ cand_count,
                                                 const uint8_t *__restrict__ valid_mask,
                                                 int16_t *__restrict__ det_x, int16_t *__restrict__ det_y, uint8_t *__restrict__ det_score,
                                                 int32_t *__restrict__ det_count) {
@@ -621,9 +623,9 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
         uint32_t prefix = 0, mask = 0;
         if (tid == 0) s_k = want;
         for (int shift = 24; shift >= 0; shift -= 8) {
-            s_hist[tid] = 0;
+            if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += 256) {
+            for (int i = tid; i < n; i += NTH) {
                 const uint32_t k = keys[i];
                 if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
             }
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (want > 0)
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += NTH) {
             const uint32_t k = keys[i];
             if (k <= kth) { const int p = atomicAdd(&s_cnt, 1); if (p < kMaxQuota) s_key[p] = k; }
         }
@@ -651,11 +653,11 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
     const int m = min(s_cnt, kMaxQuota);
     int np2 = 1;
     while (np2 < m) np2 <<= 1;
-    for (int i = m + tid; i < np2; i += 256) s_key[i] = 0xFFFFFFFFu;
+    for (int i = m + tid; i < np2; i += NTH) s_key[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 256) {
+            for (int i = tid; i < np2; i += NTH) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const uint32_t a = s_key[i], b = s_key[ixj];
@@ -672,21 +674,21 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
         int cell = min_dist;
         while (((G.w + cell - 1) / cell) * ((G.h + cell - 1) / cell) > kGridCells) ++cell;
         const int gw = (G.w + cell - 1) / cell, gh = (G.h + cell - 1) / cell;
-        for (int i = tid; i < gw * gh; i += 256) s_head[i] = -1;
+        for (int i = tid; i < gw * gh; i += NTH) s_head[i] = -1;
         __syncthreads();
-        for (int i = tid; i < m; i += 256) {
+        for (int i = tid; i < m; i += NTH) {
             const int idx = (int)(s_key[i] & 0xFFFFFFu), y = idx / G.w, x = idx - y * G.w;
             s_x[i] = (int16_t)x; s_y[i] = (int16_t)y; s_state[i] = 0;
         }
         __syncthreads();
-        for (int i = tid; i < m; i += 256)                      // cell lists (their internal order does not matter)
+        for (int i = tid; i < m; i += NTH)                      // cell lists (their internal order does not matter)
             s_next[i] = (int16_t)atomicExch(&s_head[(s_y[i] / cell) * gw + s_x[i] / cell], i);
         __syncthreads();
         const int d2 = min_dist * min_dist;
         for (int round = 0; round < kMaxQuota; ++round) {
             if (tid == 0) s_open = 0;
             __syncthreads();
-            for (int i = tid; i < m; i += 256) {
+            for (int i = tid; i < m; i += NTH) {
                 if (s_state[i]) continue;
                 const int x = s_x[i], y = s_y[i], cx = x / cell, cy = y / cell;
                 bool rejected = false, waiting = false;
@@ -714,25 +716,25 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
     if (tid == 0) { s_run = 0; s_kept = 0; }
     __syncthreads();
     const int W0 = g->width, H0 = g->height;
-    for (int base = 0; base < m; base += 256) {
+    for (int base = 0; base < m; base += 256) {                  // chunks of 256 (threads beyond 256 only keep the barriers company)
         const int i = base + tid;
         int x = 0, y = 0, sc = 0, keep = 0;
-        if (i < m) {
+        if (i < m && tid < 256) {
             const uint32_t k = s_key[i];
             const int idx = (int)(k & 0xFFFFFFu);
             y = idx / G.w; x = idx - y * G.w; sc = 255 - (int)(k >> 24);
             keep = spaced ? (s_state[i] == 1) : 1;
         }
-        s_scan2[tid] = keep;
+        if (tid < 256) s_scan2[tid] = keep;
         __syncthreads();
         for (int off = 1; off < 256; off <<= 1) {
-            const int v = tid >= off ? s_scan2[tid - off] : 0;
+            const int v = (tid >= off && tid < 256) ? s_scan2[tid - off] : 0;
             __syncthreads();
-            s_scan2[tid] += v;
+            if (tid < 256) s_scan2[tid] += v;
             __syncthreads();
         }
         const int kept_before = s_kept;
-        int ok = keep && (kept_before + s_scan2[tid] - 1 < quota);        // maxTracks = quota_l
+        int ok = tid < 256 && keep && (kept_before + s_scan2[tid] - 1 < quota);        // maxTracks = quota_l
         if (ok) {
             ok = x >= kPatchRadius && y >= kPatchRadius && x < G.w - kPatchRadius && y < G.h - kPatchRadius;
             if (ok && valid_mask) {
@@ -740,12 +742,12 @@ __global__ __launch_bounds__(256) void k_select(const PyrGeom *g, const uint32_t
                 ok = mx >= 0 && my >= 0 && mx < W0 && my < H0 && valid_mask[(uint64_t)my * W0 + mx] != 0;
             }
         }
-        s_scan[tid] = ok;
+        if (tid < 256) s_scan[tid] = ok;
         __syncthreads();
         for (int off = 1; off < 256; off <<= 1) {
-            const int v = tid >= off ? s_scan[tid - off] : 0;
+            const int v = (tid >= off && tid < 256) ? s_scan[tid - off] : 0;
             __syncthreads();
-            s_scan[tid] += v;
+            if (tid < 256) s_scan[tid] += v;
             __syncthreads();
         }
         const int run = s_run;
@@ -1347,12 +1349,14 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_ftile_tab, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
-    if (o->cfg.min_distance > 0.f)
-        hipLaunchKernelGGL(k_select<true>, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
-                           o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
-    else
-        hipLaunchKernelGGL(k_select<false>, dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask,
-                           o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+    const bool few = n_frames * G.levels <= 64;                     // a frame or a handful: one block per level is the whole launch -- give it 1024 threads
+    if (o->cfg.min_distance > 0.f) {
+        if (few) hipLaunchKernelGGL((k_select<true, 1024>), dim3(G.levels, n_frames), dim3(1024), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+        else hipLaunchKernelGGL((k_select<true, 256>), dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+    } else {
+        if (few) hipLaunchKernelGGL((k_select<false, 1024>), dim3(G.levels, n_frames), dim3(1024), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+        else hipLaunchKernelGGL((k_select<false, 256>), dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+    }
     MS_KERNEL_CHECK(c, "k_select");
     MS_STAGE_MARK();
     hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
