@@ -609,12 +609,13 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
     __shared__ uint32_t s_key[kMaxQuota];
     __shared__ int s_hist[256];
     __shared__ int s_cnt, s_digit, s_k, s_run, s_kept, s_open;
-    __shared__ int s_scan[256], s_scan2[256];
+    __shared__ int s_w1[4], s_w2[4];
     __shared__ uint8_t s_state[SPACED ? kMaxQuota : 1];          // 0 undecided, 1 kept, 2 rejected
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom &G = g->L[l];
     const uint32_t *keys = cand + (uint64_t)f * g->cand_stride + G.cand_off;
-    const int n = min(cand_count[f * g->levels + l], G.cand_cap);
+    const int n = min(cand_count[f * g->levels + l], G.cand_cap), n4 = n >> 2;
+    const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);          // (every level's list starts 16-byte aligned: cand_cap is a multiple of 4)
     const int quota = G.quota, min_dist = G.min_dist;
     const bool spaced = SPACED && min_dist >= 2;
     const int want = spaced ? min(4 * quota, kMaxQuota) : quota;      // how many of the strongest corners are sorted
@@ -625,15 +626,31 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += NTH) {
-                const uint32_t k = keys[i];
-                if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
+            // one block walks a level's list, and a block's memory parallelism is what its waves keep in flight: 16-byte loads, two per thread (a
+            // dword per lane and trip moved ~20 GB/s: 14 us per pass over a 720p frame's level 0)
+            for (int i = tid; i < n4; i += 2 * NTH) {
+                const uint4 q0 = keys4[i], q1 = i + NTH < n4 ? keys4[i + NTH] : uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const int lim = i + NTH < n4 ? 8 : 4;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < lim && (kk[u] & mask) == prefix) atomicAdd(&s_hist[(kk[u] >> shift) & 255], 1);
             }
+            for (int i = 4 * n4 + tid; i < n; i += NTH) { const uint32_t k = keys[i]; if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1); }
             __syncthreads();
-            if (tid == 0) {
-                int k = s_k, d = 0;
-                while (d < 255 && s_hist[d] < k) { k -= s_hist[d]; ++d; }
-                s_digit = d; s_k = k;
+            // the digit of the k-th smallest key: the first bin whose running count reaches k.  (One thread walking the 256 bins was ~10 us per pass --
+            // a chain of dependent LDS reads -- and four passes of it were most of a single frame's 44 us in this kernel.)
+            {
+                const int kk = s_k;
+                int h = tid < 256 ? s_hist[tid] : 0, c = h;                  // inclusive running count over the bins: wave scan, then the waves' totals
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(c, off, 64); if ((tid & 63) >= off) c += v; }
+                if ((tid & 63) == 63 && tid < 256) s_w1[tid >> 6] = c;
+                __syncthreads();
+                if (tid < 256) {
+                    for (int w = 0; w < (tid >> 6); ++w) c += s_w1[w];
+                    const bool last = tid == 255;                            // (k never exceeds the total: the last bin takes what is left, like the walk did)
+                    if ((c >= kk || last) && c - h < kk) { s_digit = tid; s_k = kk - (c - h); }
+                }
             }
             __syncthreads();
             prefix |= (uint32_t)s_digit << shift;
@@ -645,16 +662,25 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (want > 0)
-        for (int i = tid; i < n; i += NTH) {
-            const uint32_t k = keys[i];
-            if (k <= kth) { const int p = atomicAdd(&s_cnt, 1); if (p < kMaxQuota) s_key[p] = k; }
+    {
+        for (int i = tid; i < n4; i += 2 * NTH) {
+            const uint4 q0 = keys4[i], q1 = i + NTH < n4 ? keys4[i + NTH] : uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const int lim = i + NTH < n4 ? 8 : 4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < lim && kk[u] <= kth) { const int p = atomicAdd(&s_cnt, 1); if (p < kMaxQuota) s_key[p] = kk[u]; }
         }
+        for (int i = 4 * n4 + tid; i < n; i += NTH) { const uint32_t k = keys[i]; if (k <= kth) { const int p = atomicAdd(&s_cnt, 1); if (p < kMaxQuota) s_key[p] = k; } }
+    }
     __syncthreads();
     const int m = min(s_cnt, kMaxQuota);
     int np2 = 1;
     while (np2 < m) np2 <<= 1;
     for (int i = m + tid; i < np2; i += NTH) s_key[i] = 0xFFFFFFFFu;
     __syncthreads();
+    // bitonic sort.  A compare-exchange distance below 64 keeps both partners inside one wave's 64 consecutive elements (of every NTH-strided round), so
+    // those steps only need the wave's own LDS order; the block meets after the steps at distance >= 64 and before the next stage starts with one
+    // (45 steps for 512 keys, 6 block barriers instead of 45: a single frame's level is ONE block, and its barriers were most of its time)
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += NTH) {
@@ -665,8 +691,10 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
                     if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
                 }
             }
-            __syncthreads();
+            if (j >= 64 || (j == 1 && k >= 64)) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         }
+    __syncthreads();
     // minimum-distance walk as a fixed point
     if constexpr (SPACED) if (spaced) {
         __shared__ int16_t s_x[kMaxQuota], s_y[kMaxQuota], s_next[kMaxQuota];
@@ -716,6 +744,8 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
     if (tid == 0) { s_run = 0; s_kept = 0; }
     __syncthreads();
     const int W0 = g->width, H0 = g->height;
+    // (the two prefix sums per chunk are over 0 / 1 flags: a ballot and two popcounts per wave, one barrier each for the waves' totals)
+    const int wv = tid >> 6, ln = tid & 63;
     for (int base = 0; base < m; base += 256) {                  // chunks of 256 (threads beyond 256 only keep the barriers company)
         const int i = base + tid;
         int x = 0, y = 0, sc = 0, keep = 0;
@@ -725,16 +755,13 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
             y = idx / G.w; x = idx - y * G.w; sc = 255 - (int)(k >> 24);
             keep = spaced ? (s_state[i] == 1) : 1;
         }
-        if (tid < 256) s_scan2[tid] = keep;
+        const unsigned long long bk = __ballot(keep != 0);
+        if (ln == 0 && wv < 4) s_w1[wv] = __popcll(bk);
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const int v = (tid >= off && tid < 256) ? s_scan2[tid - off] : 0;
-            __syncthreads();
-            if (tid < 256) s_scan2[tid] += v;
-            __syncthreads();
-        }
-        const int kept_before = s_kept;
-        int ok = tid < 256 && keep && (kept_before + s_scan2[tid] - 1 < quota);        // maxTracks = quota_l
+        int incl = __popcll(bk & ((2ull << ln) - 1ull)), kept_chunk = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wv) incl += s_w1[w]; kept_chunk += s_w1[w]; }
+        const int kept_before = s_kept, run = s_run;
+        int ok = tid < 256 && keep && (kept_before + incl - 1 < quota);        // maxTracks = quota_l
         if (ok) {
             ok = x >= kPatchRadius && y >= kPatchRadius && x < G.w - kPatchRadius && y < G.h - kPatchRadius;
             if (ok && valid_mask) {
@@ -742,21 +769,17 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
                 ok = mx >= 0 && my >= 0 && mx < W0 && my < H0 && valid_mask[(uint64_t)my * W0 + mx] != 0;
             }
         }
-        if (tid < 256) s_scan[tid] = ok;
+        const unsigned long long bo = __ballot(ok != 0);
+        if (ln == 0 && wv < 4) s_w2[wv] = __popcll(bo);
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const int v = (tid >= off && tid < 256) ? s_scan[tid - off] : 0;
-            __syncthreads();
-            if (tid < 256) s_scan[tid] += v;
-            __syncthreads();
-        }
-        const int run = s_run;
+        int incl2 = __popcll(bo & ((2ull << ln) - 1ull)), out_chunk = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wv) incl2 += s_w2[w]; out_chunk += s_w2[w]; }
         if (ok) {
-            const uint64_t slot = (uint64_t)f * g->det_stride + G.det_base + run + s_scan[tid] - 1;
+            const uint64_t slot = (uint64_t)f * g->det_stride + G.det_base + run + incl2 - 1;
             det_x[slot] = (int16_t)x; det_y[slot] = (int16_t)y; det_score[slot] = (uint8_t)sc;
         }
-        __syncthreads();
-        if (tid == 255) { s_run = run + s_scan[255]; s_kept = kept_before + s_scan2[255]; }
+        __syncthreads();                                         // everyone has read s_run / s_kept / the waves' totals
+        if (tid == 0) { s_run = run + out_chunk; s_kept = kept_before + kept_chunk; }
         __syncthreads();
     }
     if (tid == 0) det_count[f * g->levels + l] = s_run;
@@ -1131,7 +1154,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
         L.det_base = det_base; det_base += quota[l];
         L.img_off = off; off += (uint64_t)L.pitch * L.h;
         L.blur_off = off; off += (uint64_t)L.pitch * L.h;
-        L.cand_cap = ((w[l] + 1) / 2) * ((h[l] + 1) / 2) + 256;   // strict 3x3 maxima: <= one per 2x2 block
+        L.cand_cap = (int32_t)ms_align_up((size_t)(((w[l] + 1) / 2) * ((h[l] + 1) / 2) + 256), 4);   // strict 3x3 maxima: <= one per 2x2 block; a multiple of 4 so that every level's list starts 16-byte aligned (k_select reads it as uint4)
         L.cand_off = coff; coff += L.cand_cap;
         L.btiles_x = ms_div_up(w[l], kBlurSeg); L.btile_base = bt; bt += L.btiles_x * ms_div_up(h[l], 4 * kBlurRows);
         L.ftiles_x = ms_div_up(w[l], kFastSeg); L.ftile_base = ft; ft += L.ftiles_x * ms_div_up(h[l], kFastRows);
