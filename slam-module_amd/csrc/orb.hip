@@ -602,7 +602,7 @@ constexpr int kGridCells = 8192;
 // NTH: threads per block.  256 for a batch (thousands of blocks); 1024 when only a few frames are in flight -- a level's candidates are then walked by ONE block
 // five times (four radix passes and the gather), and a single 720p frame's level 0 has tens of thousands of them: 54 us of a frame's 143 us with 256 threads.
 template <bool SPACED, int NTH>   // SPACED: some level has a minimum keypoint distance (uses 66 KB more LDS for the grid)
-__global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t *__restrict__ cand, const int32_t *__restrict__ cand_count,
+__global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t *__restrict__ cand, int32_t *__restrict__ cand_count,
                                                 const uint8_t *__restrict__ valid_mask,
                                                 int16_t *__restrict__ det_x, int16_t *__restrict__ det_y, uint8_t *__restrict__ det_score,
                                                 int32_t *__restrict__ det_count) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(NTH) void k_select(const PyrGeom *g, const uint32_t
         if (tid == 0) { s_run = run + out_chunk; s_kept = kept_before + kept_chunk; }
         __syncthreads();
     }
-    if (tid == 0) det_count[f * g->levels + l] = s_run;
+    if (tid == 0) { det_count[f * g->levels + l] = s_run; cand_count[f * g->levels + l] = 0; }      // the list is consumed: k_fast of the next extract appends from zero (no memset launch per call)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1348,7 +1348,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         MS_HIP(c, hipMemcpyAsync(o->d_n_tracks, n_tracks, (size_t)n_frames * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (track_id) MS_HIP(c, hipMemcpyAsync(o->d_track_id, track_id, (size_t)n_frames * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
-    MS_HIP(c, hipMemsetAsync(o->d_cand_count, 0, (size_t)n_frames * G.levels * sizeof(int32_t), st));
+    // (d_cand_count is zero here: allocated zeroed, and k_select puts every counter it has consumed back to zero)
     int stage = 0;
 #define MS_STAGE_MARK() do { if (o->profiling) MS_HIP(c, hipEventRecord(o->ev[stage++], st)); } while (0)
     MS_STAGE_MARK();
@@ -1382,10 +1382,12 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     }
     MS_KERNEL_CHECK(c, "k_select");
     MS_STAGE_MARK();
-    hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
-                       (have_tracks && track_id) ? o->d_track_id : nullptr, have_tracks ? o->d_n_tracks : nullptr, o->d_mask,
-                       o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
-    MS_KERNEL_CHECK(c, "k_tracks");
+    if (o->cfg.max_tracks > 0) {                                    // (an extractor built without tracker features: d_trk_count stays at its initial zero)
+        hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
+                           (have_tracks && track_id) ? o->d_track_id : nullptr, have_tracks ? o->d_n_tracks : nullptr, o->d_mask,
+                           o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
+        MS_KERNEL_CHECK(c, "k_tracks");
+    }
     MS_STAGE_MARK();
     hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
