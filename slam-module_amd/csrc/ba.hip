@@ -743,19 +743,29 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
                 }
                 atomicAdd(&P.bp[6 * fs + a2], v);
             }
-            for (int it = tid; it < kn * 144; it += NT) {                         // Hpp[fs][ft] += Js^T (W Jt)
-                const int ke = it / 144, r = it - 144 * ke, st = r / 36, en = r - 36 * st, a2 = en / 6, b3 = en - 6 * a2, k = k0 + ke;
+            // Hpp[fs][ft] += Js^T (W Jt): a thread per (edge, side pair, column b3) forms the column (W Jt)[:, b3] once and the six entries of the block's column
+            // from it -- every entry with the operation order of the scalar loop (a thread per ENTRY recomputed the column for each of the six: 68 k cycles)
+            for (int it = tid; it < kn * 24; it += NT) {
+                const int ke = it / 24, r = it - 24 * ke, st = r / 6, b3 = r - 6 * st, k = k0 + ke;
                 const int fs = P.pidx[(st >> 1) ? P.edge_j[k] : P.edge_i[k]], ft = P.pidx[(st & 1) ? P.edge_j[k] : P.edge_i[k]];
                 if (fs < 0 || ft < 0) continue;
                 const MS_LDS double *d = eb + ke * ES, *Js = d + 6 + 36 * (st >> 1), *Jt = d + 6 + 36 * (st & 1);
                 const double *W = P.edge_info + 36 * (size_t)k;
-                double v = 0;
+                double m[6];
+#pragma unroll
                 for (int r2 = 0; r2 < 6; ++r2) {
-                    double m = 0;                                                 // (W Jt)[r2][b3]
-                    for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * Jt[6 * c2 + b3];
-                    v += Js[6 * r2 + a2] * m;
+                    double mm = 0;                                                // (W Jt)[r2][b3]
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; ++c2) mm += W[6 * r2 + c2] * Jt[6 * c2 + b3];
+                    m[r2] = mm;
                 }
-                atomicAdd(&P.Hpp[(size_t)(6 * fs + a2) * n6 + 6 * ft + b3], v);
+#pragma unroll
+                for (int a2 = 0; a2 < 6; ++a2) {
+                    double v = 0;
+#pragma unroll
+                    for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + a2] * m[r2];
+                    atomicAdd(&P.Hpp[(size_t)(6 * fs + a2) * n6 + 6 * ft + b3], v);
+                }
             }
             __syncthreads();
         }
