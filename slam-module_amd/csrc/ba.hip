@@ -75,7 +75,7 @@ struct BaProb {
     const int32_t *obs_pose, *obs_point;
     const double *obs_uv, *obs_info;
     const int32_t *pt_start, *pt_obs;        // observations grouped by point
-    const int32_t *fstart, *fobs;            // observations grouped by FREE pose index
+    const int32_t *fstart, *fobs;            // observations grouped by FREE pose index; behind them, fobs[fstart[np_free] .. n_obs), those of the fixed poses
     const int32_t *free2pose;                // free index -> pose vertex
     // Schur work list: pairs (a,b) of observations of one free point with free poses fb <= fa, sorted by (fa,fb),
     // cut into chunks of CH items of the same pose pair (padding = -1); segments = runs of chunks of one pair
@@ -565,8 +565,39 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             }
         }
     }
+    // One workgroup per window (a chip-filling batch) with a point table that fits the LDS (9 doubles per point: 2000 points = 141 KB): the per-point walk below is
+    // dropped -- the per-pose pass visits every observation of a free pose anyway (lanes = the observations of ONE pose: all different points), so it adds the
+    // point's Hll / bl terms into the table with ds_add_f64 while it is there; the observations of FIXED poses get a sweep of their own.  The two walks evaluated
+    // every observation twice: 260 k + 340 k cycles of a 760 k-cycle linearisation.
+    const bool one_pass = T_ == 1 && !obs_par && P.fused && 9 * (size_t)P.n_point + 64 <= kLdsBytes / 8;
+    MS_LDS double *ptab1 = (MS_LDS double *)lds_;
+    if (one_pass) {
+        for (int i = tid; i < 9 * P.n_point; i += NT) ptab1[i] = 0;
+        __syncthreads();
+        for (int ix = P.fstart[P.np_free] + tid; ix < P.n_obs; ix += NT) {      // observations whose pose is fixed (the tail of fobs): point terms only
+            const int o = P.fobs[ix], pi = P.obs_pose[o], l = P.obs_point[o];
+            if (P.point_fixed && P.point_fixed[l]) continue;
+            double pose[7], X[3], uv[2];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) pose[q] = P.pose[7 * (size_t)pi + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) X[q] = P.point[3 * (size_t)l + q];
+            uv[0] = P.obs_uv[2 * (size_t)o]; uv[1] = P.obs_uv[2 * (size_t)o + 1];
+            double e[2], Jp[12], Jl[6];
+            proj_edge<true>(pose, X, uv, e, Jp, Jl);
+            const double info = P.obs_info[o], chi2 = info * (e[0] * e[0] + e[1] * e[1]);
+            double r, w;
+            huber(chi2, P.huber, r, w);
+            const double wi = w * info;
+            MS_LDS double *t = ptab1 + 9 * l;
+            lds_addd(t + 0, wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3])); lds_addd(t + 1, wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4])); lds_addd(t + 2, wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]));
+            lds_addd(t + 3, wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4])); lds_addd(t + 4, wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5])); lds_addd(t + 5, wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]));
+#pragma unroll
+            for (int a = 0; a < 3; ++a) lds_addd(t + 6 + a, -(Jl[a] * e[0] + Jl[3 + a] * e[1]) * wi);
+        }
+    }
     // per point: Hll, bl, Hpl
-    for (int l = obs_par ? P.n_point : gts; l < P.n_point; l += GT) {
+    for (int l = (obs_par || one_pass) ? P.n_point : gts; l < P.n_point; l += GT) {
         const bool lfree = !(P.point_fixed && P.point_fixed[l]);
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const double X[3] = {P.point[3 * (size_t)l], P.point[3 * (size_t)l + 1], P.point[3 * (size_t)l + 2]};
@@ -647,6 +678,13 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
 #pragma unroll
                 for (int b = a; b < 6; ++b) A[k++] += wi * (Jp[a] * Jp[b] + Jp[6 + a] * Jp[6 + b]);
             }
+            if (one_pass && cur.o >= 0 && !(P.point_fixed && P.point_fixed[cur.l])) {
+                MS_LDS double *t = ptab1 + 9 * cur.l;
+                lds_addd(t + 0, wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3])); lds_addd(t + 1, wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4])); lds_addd(t + 2, wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]));
+                lds_addd(t + 3, wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4])); lds_addd(t + 4, wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5])); lds_addd(t + 5, wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]));
+#pragma unroll
+                for (int a = 0; a < 3; ++a) lds_addd(t + 6 + a, -(Jl[a] * e[0] + Jl[3 + a] * e[1]) * wi);
+            }
             cur = nxt; o1 = o2; l1 = l2;
         }
 #pragma unroll
@@ -666,6 +704,13 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         }
     }
     LINP(3);
+    if (one_pass) {                                                // the point table leaves the LDS before the SE3 edges take it over
+        __syncthreads();
+        for (int i = tid; i < 9 * P.n_point; i += NT) {
+            const int l = i / 9, c = i - 9 * l;
+            if (c < 6) P.Hll[6 * (size_t)l + c] = ptab1[i]; else P.bl[3 * (size_t)l + c - 6] = ptab1[i];
+        }
+    }
     if (T_ == 1) team_sync(P);
     // EdgeSE3Expmap edges (odometry chain, loop closures, orientation prior).  One workgroup: in rounds of 128, a LANE per edge evaluates it (error, both
     // 6x6 Jacobians; the edges of a round run side by side instead of one after another) and parks the result in LDS, then the
@@ -2420,6 +2465,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int f = 0; f < R.np_free; ++f) R.fstart[f + 1] += R.fstart[f];
         R.fobs.resize(R.fstart[R.np_free]);
         { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
+        for (int o = 0; o < Q.n_obs; ++o) if (R.pidx[Q.obs_pose[o]] < 0) R.fobs.push_back(o);      // behind them: the observations of FIXED poses (fobs[fstart[np_free] .. n_obs))
         // envelope of the reduced camera matrix at pose level: the first free pose each free pose is coupled with (a shared point or a
         // pose-pose edge), and the free observations of every free point, sorted by free pose (flat arrays: the fused Schur pass is built from them)
         std::vector<int> first(R.np_free);
