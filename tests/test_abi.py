@@ -26,6 +26,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in L.ms_version()
 
 
+def test_native_c5_driver_is_built_on_the_c_abi_only():
+    """tools/c5_native.cpp (bench.py --c5-native): built next to the library, exports its two entry points, and names no symbol outside the C ABI."""
+    path = os.path.join(ROOT, "slam-module_amd", "lib", "libc5native.so")
+    assert os.path.exists(path), "make -C slam-module_amd/csrc builds it"
+    L = ctypes.CDLL(path)
+    assert hasattr(L, "c5_prepare") and hasattr(L, "c5_go")
+    src = open(os.path.join(ROOT, "tools", "c5_native.cpp")).read()
+    assert '#include "mi355slam.h"' in src and "hip" not in src.lower().replace("mi355slam", "") and "oracle" not in src
+
+
 def test_host_geometry_equals_oracle(oracle):
     import mi355slam
     for levels, f, w, h, k in [(8, 1.2, 1280, 720, 2000), (8, 1.2, 640, 480, 2000), (5, 1.5, 333, 222, 777), (1, 1.2, 100, 100, 50), (12, 1.1, 1920, 1080, 5000)]:
