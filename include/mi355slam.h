@@ -336,7 +336,9 @@ typedef struct {
 
 typedef struct ms_ba ms_ba;
 
-/* Upload `n` independent problems (different sizes allowed) and build their index structures. */
+/* Upload `n` independent problems (different sizes allowed) and build their index structures.  The handle's device memory is ONE block;
+ * ms_ba_destroy hands it back to the context (up to four blocks are kept), and the next ms_ba_create on that context takes a kept block
+ * that is large enough instead of allocating: a window per keyframe (create, solve, download, destroy) allocates nothing after warm-up. */
 int ms_ba_create(ms_ctx *ctx, const ms_ba_problem *problems, int n, ms_ba **out);
 void ms_ba_destroy(ms_ba *ba);
 /* Run the full LM schedule of every problem from its initial estimates, one workgroup per problem,
