@@ -303,3 +303,13 @@ def test_envelope_with_loop_closure_and_scattered_covisibility(oracle, ctx):
         ba = mi355slam.BundleAdjuster(ctx, [p, p], max_iters=8); ba.set_team(team); ba.solve()
         _check(p, ba.download(0), want); _check(p, ba.download(1), want)
         ba.close()
+
+
+def test_randomised_windows_fuzz_tool():
+    """tools/ba_fuzz.py on 120 random windows (2..70 keyframes, ragged visibility, fixed poses and points, outliers, loop closures, pose-only cases;
+    alone / batched / on teams of 2, 5, 16): residuals within 1e-5 of the oracle's, LM trajectory equal unless the solve had converged."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ba_fuzz.py"), "120", "2024"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
