@@ -307,7 +307,7 @@ def test_envelope_with_loop_closure_and_scattered_covisibility(oracle, ctx):
 
 def test_randomised_windows_fuzz_tool():
     """tools/ba_fuzz.py on 120 random windows (2..70 keyframes, ragged visibility, fixed poses and points, outliers, loop closures, pose-only cases;
-    alone / batched / on teams of 2, 5, 16): residuals within 1e-5 of the oracle's, LM trajectory equal unless the solve had converged."""
+    alone / batched / on teams of 2, 5, 16): residuals within 1e-7 of the oracle's (the tool's own bar; the contract is 1e-5), LM trajectory equal unless the solve had converged."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ba_fuzz.py"), "120", "2024"], capture_output=True, text=True, timeout=300)

@@ -1,5 +1,5 @@
 """Differential fuzz of the bundle adjuster against the CPU oracle: N random windows (2..70 keyframes, ragged visibility, fixed poses and
-points, outliers, loop-closure edges, pose-only cases), solved alone / in a batch / on teams; residuals within 1e-5, LM trajectory equal.
+points, outliers, loop-closure edges, pose-only cases), solved alone / in a batch / on teams; residuals within 1e-7 (north_star: 1e-5; observed 2e-10 over 8000 windows), LM trajectory equal.
 usage: python tools/ba_fuzz.py [N] [seed]"""
 import os, sys
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,6 +38,7 @@ def random_problem():
 
 
 bad = done = 0
+worst = 0.0
 while done < N:
     probs = [random_problem() for _ in range(int(rng.integers(1, 5)))]
     iters = int(rng.integers(1, 9)); team = int(rng.choice([0, 1, 2, 5, 16]))
@@ -46,7 +47,8 @@ while done < N:
     for p, w, i in zip(probs, want, range(len(probs))):
         g = ba.download(i)
         rg, rw = ba_synth.residuals_fast(p, g["pose"], g["point"]), ba_synth.residuals_fast(p, w["pose"], w["point"])
-        ok = np.abs(rg - rw).max() < 1e-5 and abs(g["stats"]["chi2_final"] - w["stats"]["chi2_final"]) <= 1e-7 * abs(w["stats"]["chi2_final"]) + 1e-8
+        worst = max(worst, float(np.abs(rg - rw).max()))
+        ok = np.abs(rg - rw).max() < 1e-7 and abs(g["stats"]["chi2_final"] - w["stats"]["chi2_final"]) <= 1e-7 * abs(w["stats"]["chi2_final"]) + 1e-8
         # the LM trajectory (iterations, trials, stop reason) must be the oracle's, except once the solve has converged and the gain ratio is
         # rounding noise (then a trial or an iteration more or less is taken at the same estimate): same answer to 1e-8
         same_path = (g["stats"]["iters"], g["stats"]["trials"], g["stats"]["stop"]) == (w["stats"]["iters"], w["stats"]["trials"], w["stats"]["stop"])
@@ -58,5 +60,5 @@ while done < N:
                                    dres=float(np.abs(rg - rw).max()), stats=(g["stats"]["iters"], g["stats"]["trials"], w["stats"]["iters"], w["stats"]["trials"]),
                                    chi2=(g["stats"]["chi2_final"], w["stats"]["chi2_final"])), flush=True)
     ba.close()
-print("ba fuzz: %d windows, %d mismatches" % (done, bad))
+print("ba fuzz: %d windows, %d mismatches; largest residual difference to the oracle %.2e (the fuzz fails above 1e-7; north_star's tolerance is 1e-5)" % (done, bad, worst))
 sys.exit(1 if bad else 0)
