@@ -46,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-greedy", action="store_true", help="skip the M1 / M2 greedy matcher leg")
+    ap.add_argument("--only-greedy", action="store_true", help="M1 / M2 greedy matcher leg only (profiling runs): prints its object as the line")
     ap.add_argument("--no-extra", action="store_true", help="skip the sparse-corner input and the PCIe-inclusive legs")
     ap.add_argument("--only-headline", action="store_true", help="C2+C3 leg only (profiling runs)")
     ap.add_argument("--only-ba", action="store_true", help="local-BA leg only (profiling runs): prints its object as the line")
@@ -59,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--master-port", type=int, default=0)
     a = ap.parse_args(argv)
     if a.only_headline:
-        a.no_ba = a.no_c5 = a.no_extra = a.no_cpu_baseline = True
+        a.no_ba = a.no_c5 = a.no_extra = a.no_cpu_baseline = a.no_greedy = True
     return a
 
 
@@ -361,6 +363,12 @@ def run_gpu(R, args):
             print(json.dumps(res), flush=True)
         ctx.close()
         return
+    if args.only_greedy:
+        res = bench_greedy(R, ctx, args)
+        if R.rank == 0:
+            print(json.dumps(res), flush=True)
+        ctx.close()
+        return
     frames_np = synth.synth_sequences(BATCH, W, H, 1000 + N_SEQ * R.rank)
     hl = Headline(R, ctx, frames_np)
 
@@ -442,6 +450,9 @@ def run_gpu(R, args):
     # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 distinct windows per launch, device-resident ----
     if not args.no_ba:
         leg("local_ba", lambda: bench_ba(R, ctx, args))
+    # ---- the reference's own matchers M1 / M2 on a new keyframe's pairs ----
+    if not args.no_greedy:
+        leg("greedy_match", lambda: bench_greedy(R, ctx, args))
     # ---- C5: 8 independent sequences, sequence s on GPU s mod N, frame by frame ----
     if not args.no_c5:
         leg("c5", lambda: bench_c5(R, args))
@@ -613,6 +624,80 @@ def bench_ba(R, ctx, args):
     if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_ba(probs[:32])
     ba.close(); one.close()
+    return res
+
+
+def cpu_baseline_greedy(wl):
+    """The oracle's M1 / M2 (plain C restatement of keyframe_matcher.cpp:50-293) on the same keyframe pairs: 1 thread and all cores."""
+    mso = _oracle()
+    cores = host_cores()
+    k0, sf = wl["kfs"][0], wl["scale_factors"]
+    pairs = list(range(1, wl["n_adj"] + 1))
+
+    def m1(i):
+        k = wl["kfs"][i]
+        return mso.match_loop_closure(k0["desc"], k0["angle"], k0["has_mp"], k0["node"], k["desc"], k["angle"], k["has_mp"], k["node"], wl["lowe_ratio"], True)
+
+    def m2(i):
+        k = wl["kfs"][i]
+        return mso.match_triangulation(k0["desc"], k0["angle"], k0["octave"], k0["bearing"], 1 - k0["has_mp"], k0["node"],
+                                       k["desc"], k["angle"], k["bearing"], 1 - k["has_mp"], k["node"], wl["E"][i - 1], sf, wl["thr_deg"], True)
+    out = {"kind": "port", "unit": "ms per keyframe pair", "cores_all": cores,
+           "sample": "the leg's %d keyframe pairs x 10 repetitions, oracle/libmso.so (gcc -O2, scalar; includes building the two CSR node tables per call)" % len(pairs)}
+    for name, fn in (("loop_closure", m1), ("triangulation", m2)):
+        fn(1)
+        r1 = _pool_rate(fn, pairs * 10, 1)
+        rall = _pool_rate(fn, pairs * 10 * max(cores // 4, 1), cores)
+        out[name] = {"ms_per_pair_1_thread": round(1e3 / r1, 4), "ms_per_pair_all_cores": round(1e3 / rall, 4)}
+    return out
+
+
+def bench_greedy(R, ctx, args):
+    """M1 matchForLoopClosures / M2 matchForTriangulationDBoW (keyframe_matcher.cpp:50-293) as the mapper calls them: one new keyframe against
+    each of its adjacent keyframes (mapper_helpers.cpp:280-293).  ms per pair for a call with ONE pair and for a call with all 20."""
+    import ctypes as C
+    import numpy as np
+    import mi355slam
+    import greedy_workload
+    wl = greedy_workload.build(ctx, mi355slam, n_adj=20, seed=3000 + R.rank)
+    kfs, n_adj = wl["kfs"], wl["n_adj"]
+    L = mi355slam.lib()
+    res = {"workload": "1 new 720p keyframe vs its %d adjacent keyframes (shift 6 px / 3 px per keyframe), %.0f keypoints and %.0f vocabulary nodes per keyframe "
+                       "(k=10, L=6 synthetic vocabulary, levelsUp 4, ms_bow_transform), usable masks at 50 %%, Lowe ratio %.2f, epipolar threshold %.1f deg"
+                       % (n_adj, wl["keypoints_per_kf"], wl["nodes_per_kf"], wl["lowe_ratio"], wl["thr_deg"]), "unit": "ms per keyframe pair"}
+    dE, dsf = ctx.upload(wl["E"].reshape(-1, 9)), ctx.upload(np.asarray(wl["scale_factors"], np.float32))
+    for name, tri in (("loop_closure", False), ("triangulation", True)):
+        fr = [mi355slam.FrameOnDevice(ctx, k["desc"], k["angle"], (1 - k["has_mp"]) if tri else k["has_mp"], k["node"],
+                                      octave=k["octave"] if tri else None, bearing=k["bearing"] if tri else None) for k in kfs]
+        outs = [ctx.alloc(4 * fr[0].n + 16) for _ in range(n_adj)]
+        nm = ctx.alloc(4 * n_adj)
+        A1 = (mi355slam.MatchFrame * n_adj)(*[fr[0].struct] * n_adj)
+        A2 = (mi355slam.MatchFrame * n_adj)(*[f.struct for f in fr[1:]])
+        ptrs = (C.c_void_p * n_adj)(*[o.ptr for o in outs])
+
+        def call(n):
+            if tri:
+                ctx.check(L.ms_match_triangulation(ctx._h, A1, A2, n, mi355slam._vp(dE), mi355slam._vp(dsf), C.c_float(wl["thr_deg"]), 1, ptrs, mi355slam._vp(nm)), "ms_match_triangulation")
+            else:
+                ctx.check(L.ms_match_loop_closure(ctx._h, A1, A2, n, C.c_float(wl["lowe_ratio"]), 1, ptrs, mi355slam._vp(nm)), "ms_match_loop_closure")
+        leg = {}
+        for n, reps in ((1, 20), (n_adj, 10)):
+            call(n); ctx.sync()
+            ctx.event_mark(6)
+            for _ in range(reps):
+                call(n)
+            ctx.event_mark(7)
+            ctx.sync()
+            dev_ms = ctx.event_elapsed_ms(6, 7) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call(n); ctx.sync()                               # what a sequential caller sees: launch + wait
+            wall_ms = (time.perf_counter() - t0) / reps * 1e3
+            leg["batch_%d" % n] = {"ms_per_call_device": round(dev_ms, 4), "ms_per_call_host_synchronous": round(wall_ms, 4), "ms_per_pair": round(dev_ms / n, 4)}
+        leg["matches_per_pair"] = round(float(nm.download(np.int32, (n_adj,)).mean()), 1)
+        res[name] = leg
+    if R.rank == 0 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_greedy(wl)
     return res
 
 

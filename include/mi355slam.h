@@ -292,6 +292,12 @@ typedef struct {
 int ms_match_loop_closure(ms_ctx *ctx, const ms_match_frame *pairs1, const ms_match_frame *pairs2, int n_pairs,
                           float lowe_ratio, int check_orientation, int32_t *const *matched, int32_t *n_matches);
 
+/* Execution path of the two greedy matchers: 0 (default) = one wavefront per shared vocabulary node, all nodes and pairs side by side
+ * (valid because a DBoW2 FeatureVector names each keypoint in exactly one node, so the greedy order only matters inside a node; a pair
+ * whose node lists break that property is detected on the device and redone sequentially); 1 = one wavefront per pair walking the
+ * nodes in order.  Both give the reference's result bit for bit. */
+int ms_match_set_path(ms_ctx *ctx, int path);
+
 /* matchForTriangulationDBoW (keyframe_matcher.hpp:53, keyframe_matcher.cpp:160-293).
  * E12 [n_pairs*9] device, row-major essential matrices (create_E_21, essential_solver.cc:157-162);
  * scale_factors [levels] device; residual_deg_thr = epipolarCheckThresholdDegrees. */

@@ -284,12 +284,16 @@ def bow_assemble(word, weight, node):
 
 
 def make_bow(bucket_of_kp):
-    """CSR over ascending node ids; keypoints of a node in ascending keypoint index (DBoW2 insertion order)."""
-    bucket_of_kp = np.asarray(bucket_of_kp, np.int32)
-    order = np.argsort(bucket_of_kp, kind="stable").astype(np.int32)
-    ids, counts = np.unique(bucket_of_kp, return_counts=True)
-    start = np.zeros(len(ids) + 1, np.int32)
-    start[1:] = np.cumsum(counts)
+    """CSR over ascending node ids; keypoints of a node in ascending keypoint index (DBoW2 insertion order).
+    A tuple (node_id, node_start, kp_idx) is taken as the CSR itself (tests with hand-made node lists)."""
+    if isinstance(bucket_of_kp, tuple):
+        ids, start, order = [np.ascontiguousarray(a, np.int32) for a in bucket_of_kp]
+    else:
+        bucket_of_kp = np.asarray(bucket_of_kp, np.int32)
+        order = np.argsort(bucket_of_kp, kind="stable").astype(np.int32)
+        ids, counts = np.unique(bucket_of_kp, return_counts=True)
+        start = np.zeros(len(ids) + 1, np.int32)
+        start[1:] = np.cumsum(counts)
     keep = dict(node_id=np.ascontiguousarray(ids, np.int32), node_start=start, kp_idx=order)
     b = Bow(len(ids), _p(keep["node_id"], i32p), _p(keep["node_start"], i32p), _p(keep["kp_idx"], i32p))
     return b, keep

@@ -15,6 +15,7 @@
 #include "ms_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -409,6 +410,7 @@ struct GreedyArgs {
     const float *scale_factors;   // M2
     float lowe_ratio, residual_deg_thr;
     int check_orientation;
+    const int32_t *redo;          // sequential kernel only: when set, pair p runs only if redo[32 p + 31] != 0 (the node-parallel pass gave it up)
 };
 
 __device__ __forceinline__ int angle_bin(float a1, float a2) {   // match_angle_checker.h:72-83
@@ -438,6 +440,7 @@ template <bool TRIANGULATION>
 __global__ __launch_bounds__(64) void k_match_greedy(GreedyArgs A) {
     __shared__ uint32_t s_used[1024];          // bitset over kf2 keypoints (n2 <= 32768)
     const int p = blockIdx.x, lane = threadIdx.x;
+    if (A.redo && A.redo[32 * p + 31] == 0) return;
     const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
     int32_t *matched = A.matched[p];
     for (int i = lane; i < F1.n; i += 64) matched[i] = -1;
@@ -531,6 +534,209 @@ __global__ __launch_bounds__(64) void k_match_greedy(GreedyArgs A) {
         num -= removed;
     }
     if (lane == 0) A.n_matches[p] = num;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same two matchers, node-parallel.  A DBoW2 FeatureVector names every keypoint in exactly one node
+// (TemplatedVocabulary::transform calls addFeature once per feature), so the targets a query can consume are
+// the targets of its own node: the greedy order matters only INSIDE a node, and the nodes of a pair can run
+// side by side.  One wavefront per (pair, node of kf1):
+//   * the node's kf2 candidates live in the lanes' registers (descriptor, angle, bearing, "consumed" flag;
+//     positions >= 64 are re-read from memory with their flags in an LDS bitset),
+//   * the node's kf1 queries are fetched 64 at a time, one per lane, and handed to the wave one after the other
+//     with v_readlane -- the walk has no dependent memory access per query any more (the one-wave-per-pair
+//     kernel above spent ~1 us per query in three of them),
+//   * matches go to the pair's rotation histogram / counter with integer atomics (order-free, deterministic).
+// k_greedy_finish then applies the histogram per pair.  Inputs that break the FeatureVector property (a keypoint
+// listed in two shared nodes) are detected with per-keypoint counters and the pair is redone by the sequential
+// kernel, so the result is the reference's for ANY input.
+struct GreedyScratch {
+    int32_t *own1, *own2;           // [n_pairs][stride]: node lists naming the keypoint (shared nodes only)
+    int32_t stride1, stride2;
+    int32_t *hist;                  // [n_pairs][32]: 30 rotation bins, [30] matches, [31] redo flag
+};
+
+__global__ __launch_bounds__(256) void k_greedy_init(GreedyArgs A, GreedyScratch S) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n1 = A.f1[p].n, n2 = A.f2[p].n;
+    if (i < n1) { A.matched[p][i] = -1; S.own1[(size_t)p * S.stride1 + i] = 0; }
+    if (i < n2) S.own2[(size_t)p * S.stride2 + i] = 0;
+    if (i < 32) S.hist[32 * p + i] = 0;
+}
+
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double rl_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <bool TRIANGULATION>
+__global__ __launch_bounds__(64) void k_greedy_nodes(GreedyArgs A, GreedyScratch S) {
+    __shared__ uint32_t s_used[1024];            // consumed flags of node positions >= 64 (a node holds <= 32768 candidates)
+    const int p = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
+    const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
+    if (a >= F1.bow.n_nodes) return;
+    const int ida = F1.bow.node_id[a];
+    int lo = 0, hi = F2.bow.n_nodes;
+    while (lo < hi) {                            // the ordered-map merge of keyframe_matcher.cpp:70-147, per node
+        const int mid = (lo + hi) >> 1;
+        if (F2.bow.node_id[mid] < ida) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= F2.bow.n_nodes || F2.bow.node_id[lo] != ida) return;
+    const int s1 = F1.bow.node_start[a], e1 = F1.bow.node_start[a + 1];
+    const int s2 = F2.bow.node_start[lo], n2 = F2.bow.node_start[lo + 1] - s2;
+    if (n2 <= 0 || e1 <= s1) return;
+    int32_t *own1 = S.own1 + (size_t)p * S.stride1, *own2 = S.own2 + (size_t)p * S.stride2, *hist = S.hist + 32 * p;
+    int32_t *matched = A.matched[p];
+    const uint4 *D1 = reinterpret_cast<const uint4 *>(F1.desc), *D2 = reinterpret_cast<const uint4 *>(F2.desc);
+    bool bad = false;                            // a keypoint named twice, or an index outside the keyframe
+    if (n2 > 32768) bad = true;
+    for (int r = 64 + lane; r < n2; r += 64) {
+        const int i2 = F2.bow.kp_idx[s2 + r];
+        if ((unsigned)i2 >= (unsigned)F2.n || atomicAdd(&own2[i2], 1) != 0) bad = true;
+    }
+    // candidates 0..63 of the node: one per lane, for the whole walk
+    int i2v = lane < n2 ? F2.bow.kp_idx[s2 + lane] : -1;
+    bool t_ok = false;
+    if (lane < n2) {
+        if ((unsigned)i2v >= (unsigned)F2.n || atomicAdd(&own2[i2v], 1) != 0) bad = true;
+        else t_ok = F2.usable[i2v] != 0;
+    }
+    uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
+    float ang2v = 0.f;
+    double b2v[3] = {0, 0, 0};
+    if (t_ok) {
+        ta = D2[2 * i2v]; tb = D2[2 * i2v + 1];
+        if (A.check_orientation) ang2v = F2.angle[i2v];
+        if (TRIANGULATION) { b2v[0] = F2.bearing[3 * (size_t)i2v]; b2v[1] = F2.bearing[3 * (size_t)i2v + 1]; b2v[2] = F2.bearing[3 * (size_t)i2v + 2]; }
+    }
+    if (n2 > 64) {
+        for (int w = lane; w < (min(n2, 32768) + 31) >> 5; w += 64) s_used[w] = 0;
+        __syncthreads();
+    }
+    double E[9];
+    if (TRIANGULATION) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = A.E12[9 * (size_t)p + k];
+    }
+    bool used0 = false;
+    int num = 0;
+    for (int q0 = s1; q0 < e1 && !__any(bad); q0 += 64) {
+        const int i1v = q0 + lane < e1 ? F1.bow.kp_idx[q0 + lane] : -1;
+        bool q_ok = false;
+        if (q0 + lane < e1) {
+            if ((unsigned)i1v >= (unsigned)F1.n || atomicAdd(&own1[i1v], 1) != 0) bad = true;
+            else q_ok = F1.usable[i1v] != 0;
+        }
+        uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+        float ang1v = 0.f, sc1v = 0.f;
+        double b1v[3] = {0, 0, 0};
+        if (q_ok) {
+            qa = D1[2 * i1v]; qb = D1[2 * i1v + 1];
+            if (A.check_orientation) ang1v = F1.angle[i1v];
+            if (TRIANGULATION) {
+                b1v[0] = F1.bearing[3 * (size_t)i1v]; b1v[1] = F1.bearing[3 * (size_t)i1v + 1]; b1v[2] = F1.bearing[3 * (size_t)i1v + 2];
+                sc1v = A.scale_factors[F1.octave[i1v]];
+            }
+        }
+        if (__any(bad)) break;
+        uint64_t qmask = __ballot(q_ok);
+        while (qmask) {                                                       // the node's queries in list order (:76 / :200)
+            const int k = __builtin_ctzll(qmask);
+            qmask &= qmask - 1;
+            const uint32_t qr[8] = {rl_u(qa.x, k), rl_u(qa.y, k), rl_u(qa.z, k), rl_u(qa.w, k), rl_u(qb.x, k), rl_u(qb.y, k), rl_u(qb.z, k), rl_u(qb.w, k)};
+            double b1[3] = {0, 0, 0};
+            float sc1 = 0.f;
+            if (TRIANGULATION) { b1[0] = rl_d(b1v[0], k); b1[1] = rl_d(b1v[1], k); b1[2] = rl_d(b1v[2], k); sc1 = rl_f(sc1v, k); }
+            uint32_t best = kNone, second = kNone;
+            auto score = [&](uint32_t pos, const uint4 &da, const uint4 &db, const double *bb) {
+                const uint32_t d = hamming8(qr, da, db);
+                if (TRIANGULATION) {
+                    if (d > MS_HAMMING_THR_LOW) return;                                           // :231
+                    if (!epipolar_ok(b1, bb, E, sc1, A.residual_deg_thr)) return;                 // :237-239
+                    best = min(best, (d << 20) | (0xFFFFFu - pos));                               // ties: LAST wins
+                } else {
+                    best2_push(best, second, (d << 20) | pos);                                    // ties: FIRST wins
+                }
+            };
+            if (t_ok && !used0) score((uint32_t)lane, ta, tb, b2v);
+            for (int r0 = 64; r0 < n2; r0 += 64) {
+                const int r = r0 + lane;
+                if (r >= n2) continue;
+                const int i2 = F2.bow.kp_idx[s2 + r];
+                if (!F2.usable[i2] || ((s_used[r >> 5] >> (r & 31)) & 1u)) continue;
+                double bb[3] = {0, 0, 0};
+                if (TRIANGULATION) { bb[0] = F2.bearing[3 * (size_t)i2]; bb[1] = F2.bearing[3 * (size_t)i2 + 1]; bb[2] = F2.bearing[3 * (size_t)i2 + 2]; }
+                score((uint32_t)r, D2[2 * i2], D2[2 * i2 + 1], bb);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t ob = __shfl_xor(best, off, 64);
+                if (TRIANGULATION) best = min(best, ob);
+                else {
+                    const uint32_t os = __shfl_xor(second, off, 64);
+                    const uint32_t l2 = min(best, ob), h2 = max(best, ob);
+                    second = min(min(second, os), h2);
+                    best = l2;
+                }
+            }
+            if (best == kNone) continue;
+            const uint32_t bd = best >> 20;
+            const uint32_t pos = TRIANGULATION ? 0xFFFFFu - (best & 0xFFFFFu) : (best & 0xFFFFFu);
+            if (!TRIANGULATION) {
+                const uint32_t sd = second == kNone ? (uint32_t)MS_HAMMING_MAX : second >> 20;
+                if (MS_HAMMING_THR_LOW < bd) continue;                                            // :115
+                if (__fmul_rn(A.lowe_ratio, (float)sd) < (float)bd) continue;                     // :120
+            }
+            const int i1 = (int)rl_u((uint32_t)i1v, k);
+            const int bi = pos < 64 ? (int)rl_u((uint32_t)i2v, (int)pos) : F2.bow.kp_idx[s2 + (int)pos];
+            if (lane == 0) matched[i1] = bi;                                                      // :126 / :250
+            if (pos < 64) { if (lane == (int)pos) used0 = true; }                                 // :128 / :249
+            else {
+                if (lane == 0) s_used[pos >> 5] |= 1u << (pos & 31);
+                __syncthreads();
+            }
+            ++num;
+            if (A.check_orientation) {
+                const float a1 = rl_f(ang1v, k), a2 = pos < 64 ? rl_f(ang2v, (int)pos) : F2.angle[bi];
+                const int bin = angle_bin(a1, a2);
+                if (lane == 0) atomicAdd(&hist[bin], 1);
+            }
+        }
+    }
+    if (__any(bad)) { if (lane == 0) hist[31] = 1; return; }
+    if (lane == 0 && num) atomicAdd(&hist[30], num);
+}
+
+__global__ __launch_bounds__(256) void k_greedy_finish(GreedyArgs A, GreedyScratch S) {
+    __shared__ int s_removed;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int32_t *hist = S.hist + 32 * p;
+    if (hist[31]) return;                                                     // the sequential kernel redoes this pair
+    const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
+    int32_t *matched = A.matched[p];
+    if (tid == 0) s_removed = 0;
+    __syncthreads();
+    if (A.check_orientation) {
+        int v0 = -1, v1 = -1, v2 = -1;                                        // top-3 bins by (size desc, bin asc), match_angle_checker.h:108-134
+        for (int rep = 0; rep < 3; ++rep) {
+            int bb = -1, bc = -1;
+            for (int k = 0; k < 30; ++k)
+                if (k != v0 && k != v1 && hist[k] > bc) { bc = hist[k]; bb = k; }
+            if (rep == 0) v0 = bb; else if (rep == 1) v1 = bb; else v2 = bb;
+        }
+        int removed = 0;
+        for (int i = tid; i < F1.n; i += 256) {
+            const int m = matched[i];
+            if (m >= 0) {
+                const int bin = angle_bin(F1.angle[i], F2.angle[m]);
+                if (bin != v0 && bin != v1 && bin != v2) { matched[i] = -1; ++removed; }
+            }
+        }
+        if (removed) atomicAdd(&s_removed, removed);
+        __syncthreads();
+    }
+    if (tid == 0) A.n_matches[p] = hist[30] - s_removed;
 }
 
 }  // namespace
@@ -680,29 +886,57 @@ static int launch_greedy(ms_ctx *c, bool tri, const ms_match_frame *p1, const ms
                          int32_t *const *matched, int32_t *n_matches) {
     if (!c || !p1 || !p2 || !matched || !n_matches || n_pairs < 0) return MS_ERR_INVALID;
     if (n_pairs == 0) return MS_OK;
+    if (n_pairs > 65535) return ms_fail(c, MS_ERR_CAPACITY, "greedy matcher: %d pairs in one call (max 65535)", n_pairs);
+    int max_n1 = 0, max_n2 = 0, max_nodes = 0;
     for (int p = 0; p < n_pairs; ++p) {
         if (p2[p].n > 32768 || p1[p].n < 0 || p2[p].n < 0) return ms_fail(c, MS_ERR_CAPACITY, "greedy matcher: kf2 has %d keypoints (max 32768)", p2[p].n);
         if (reinterpret_cast<uintptr_t>(p1[p].desc) % 16 || reinterpret_cast<uintptr_t>(p2[p].desc) % 16)
             return ms_fail(c, MS_ERR_INVALID, "greedy matcher: descriptors must be 16-byte aligned");
+        if (p1[p].bow.n_nodes < 0 || p2[p].bow.n_nodes < 0) return ms_fail(c, MS_ERR_INVALID, "greedy matcher: negative node count");
+        max_n1 = std::max(max_n1, p1[p].n); max_n2 = std::max(max_n2, p2[p].n); max_nodes = std::max(max_nodes, p1[p].bow.n_nodes);
     }
     MS_HIP(c, hipSetDevice(c->device));
+    // one argument table, one copy: [kf1 structs][kf2 structs][output pointers], then the device-only part of the scratch
     const size_t fb = sizeof(ms_match_frame) * (size_t)n_pairs, mb = sizeof(int32_t *) * (size_t)n_pairs;
+    const size_t tab = ms_align_up(2 * fb + mb, 256), hb = ms_align_up(sizeof(int32_t) * 32 * (size_t)n_pairs, 256);
+    const size_t o1 = ms_align_up(sizeof(int32_t) * (size_t)n_pairs * std::max(max_n1, 1), 256), o2 = ms_align_up(sizeof(int32_t) * (size_t)n_pairs * std::max(max_n2, 1), 256);
+    const bool node_parallel = c->greedy_path == 0;
     void *scr = nullptr;
-    int rc = ms_scratch(c, 2 * fb + mb + 64, &scr);
+    int rc = ms_scratch(c, tab + (node_parallel ? hb + o1 + o2 : 0), &scr);
     if (rc != MS_OK) return rc;
     char *base = static_cast<char *>(scr);
-    MS_HIP(c, hipMemcpyAsync(base, p1, fb, hipMemcpyHostToDevice, c->stream));
-    MS_HIP(c, hipMemcpyAsync(base + fb, p2, fb, hipMemcpyHostToDevice, c->stream));
-    MS_HIP(c, hipMemcpyAsync(base + 2 * fb, matched, mb, hipMemcpyHostToDevice, c->stream));
+    std::vector<char> host(2 * fb + mb);
+    std::memcpy(host.data(), p1, fb); std::memcpy(host.data() + fb, p2, fb); std::memcpy(host.data() + 2 * fb, matched, mb);
+    MS_HIP(c, hipMemcpyAsync(base, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));     // pageable source: staged before the call returns
     GreedyArgs A{};
     A.f1 = reinterpret_cast<const ms_match_frame *>(base);
     A.f2 = reinterpret_cast<const ms_match_frame *>(base + fb);
     A.matched = reinterpret_cast<int32_t *const *>(base + 2 * fb);
     A.n_matches = n_matches; A.E12 = E12; A.scale_factors = sf; A.lowe_ratio = ratio; A.residual_deg_thr = thr_deg;
     A.check_orientation = check_orientation;
+    if (node_parallel) {
+        GreedyScratch S{};
+        S.hist = reinterpret_cast<int32_t *>(base + tab);
+        S.own1 = reinterpret_cast<int32_t *>(base + tab + hb);
+        S.own2 = reinterpret_cast<int32_t *>(base + tab + hb + o1);
+        S.stride1 = std::max(max_n1, 1); S.stride2 = std::max(max_n2, 1);
+        hipLaunchKernelGGL(k_greedy_init, dim3(std::max(ms_div_up(std::max(max_n1, max_n2), 256), 1), n_pairs), dim3(256), 0, c->stream, A, S);
+        if (max_nodes > 0) {
+            if (tri) hipLaunchKernelGGL(k_greedy_nodes<true>, dim3(max_nodes, n_pairs), dim3(64), 0, c->stream, A, S);
+            else hipLaunchKernelGGL(k_greedy_nodes<false>, dim3(max_nodes, n_pairs), dim3(64), 0, c->stream, A, S);
+        }
+        hipLaunchKernelGGL(k_greedy_finish, dim3(n_pairs), dim3(256), 0, c->stream, A, S);
+        A.redo = S.hist;                                   // pairs the node pass gave up (a keypoint in two shared nodes): exact sequential walk
+    }
     if (tri) hipLaunchKernelGGL(k_match_greedy<true>, dim3(n_pairs), dim3(64), 0, c->stream, A);
     else hipLaunchKernelGGL(k_match_greedy<false>, dim3(n_pairs), dim3(64), 0, c->stream, A);
     MS_KERNEL_CHECK(c, "k_match_greedy");
+    return MS_OK;
+}
+
+int ms_match_set_path(ms_ctx *c, int path) {
+    if (!c || path < 0 || path > 1) return MS_ERR_INVALID;
+    c->greedy_path = path;
     return MS_OK;
 }
 

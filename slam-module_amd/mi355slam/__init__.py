@@ -113,6 +113,10 @@ class Context:
         """0 = automatic (matrix-core kernel for unmasked searches), 1 = popcount kernel for everything."""
         self.check(lib().ms_hamming_set_path(self._h, int(path)), "ms_hamming_set_path")
 
+    def set_match_path(self, path):
+        """0 = node-parallel greedy matchers (default), 1 = one sequential wavefront per keyframe pair."""
+        self.check(lib().ms_match_set_path(self._h, int(path)), "ms_match_set_path")
+
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
 
@@ -469,13 +473,18 @@ def angle_check(delta, ids):
 class FrameOnDevice:
     """Uploads one keyframe's matcher inputs and builds the ms_match_frame struct."""
 
-    def __init__(self, ctx, desc, angle, usable, bucket, octave=None, bearing=None):
-        bucket = np.asarray(bucket, np.int32)
-        order = np.argsort(bucket, kind="stable").astype(np.int32)
-        ids, counts = np.unique(bucket, return_counts=True)
-        start = np.zeros(len(ids) + 1, np.int32)
-        start[1:] = np.cumsum(counts)
-        self.n = len(bucket)
+    def __init__(self, ctx, desc, angle, usable, bucket, octave=None, bearing=None, csr=None):
+        """bucket: vocabulary node of every keypoint (the CSR is built like DBoW2 fills a FeatureVector: nodes ascending, keypoints of a
+        node in index order); csr = (node_id, node_start, kp_idx) overrides it with explicit node lists (tests)."""
+        if csr is None:
+            bucket = np.asarray(bucket, np.int32)
+            order = np.argsort(bucket, kind="stable").astype(np.int32)
+            ids, counts = np.unique(bucket, return_counts=True)
+            start = np.zeros(len(ids) + 1, np.int32)
+            start[1:] = np.cumsum(counts)
+        else:
+            ids, start, order = [np.ascontiguousarray(a, np.int32) for a in csr]
+        self.n = len(np.asarray(usable))
         self.bufs = dict(desc=ctx.upload(np.asarray(desc, np.uint32).reshape(-1, 8)), angle=ctx.upload(np.asarray(angle, np.float32)),
                          usable=ctx.upload(np.asarray(usable, np.uint8)), node_id=ctx.upload(ids.astype(np.int32)),
                          node_start=ctx.upload(start), kp_idx=ctx.upload(order))

@@ -167,6 +167,74 @@ def test_match_triangulation_exact_greedy(oracle, ctx):
         assert counts[i] == wn and np.array_equal(matched[i], wm), i
 
 
+def test_greedy_matchers_node_parallel_equals_sequential_walk(oracle, ctx):
+    """Both execution paths of M1 / M2 (ms_match_set_path) against the oracle: nodes of 1..600 candidates (registers + LDS bitset),
+    query lists longer than a wave, keyframes with nodes the other one lacks, empty keyframes."""
+    import mi355slam
+    rng = np.random.default_rng(77)
+    sf = oracle.scale_factors(8, 1.2)
+    shapes = [(2000, 2000, 100), (900, 1300, 3), (700, 650, 1), (130, 90, 40), (64, 64, 1), (65, 129, 2), (5, 0, 3), (0, 7, 2)]
+    f1m, f2m, f1t, f2t, Es, want_m, want_t = [], [], [], [], [], [], []
+    for seed, (n1, n2, nb) in enumerate(shapes):
+        q, t, b1, b2, a1, a2, u1, u2 = _frames(900 + seed, max(n1, 1), max(n2, 1), nb)
+        q, t, b1, b2, a1, a2, u1, u2 = q[:n1], t[:n2], b1[:n1], b2[:n2], a1[:n1], a2[:n2], u1[:n1], u2[:n2]
+        if seed == 2:
+            q &= 0x7; t &= 0x7                                         # ties everywhere: first / last minimum decide
+        if seed == 3:
+            b2 = b2 + 1000 * (b2 % 3 == 0)                             # a third of kf2's nodes do not exist in kf1
+        be1 = rng.normal(size=(n1, 3)); be1 /= np.linalg.norm(be1, axis=1, keepdims=True) if n1 else 1
+        be2 = be1[rng.integers(0, max(n1, 1), n2)] + 0.01 * rng.normal(size=(n2, 3)) if n1 else rng.normal(size=(n2, 3))
+        if n2: be2 /= np.linalg.norm(be2, axis=1, keepdims=True)
+        o1 = rng.integers(0, 8, n1).astype(np.int32)
+        E = oracle.create_E21(_rot(rng), rng.normal(size=3), _rot(rng), rng.normal(size=3))
+        f1m.append(mi355slam.FrameOnDevice(ctx, q.reshape(-1, 8), a1, u1, b1)); f2m.append(mi355slam.FrameOnDevice(ctx, t.reshape(-1, 8), a2, u2, b2))
+        f1t.append(mi355slam.FrameOnDevice(ctx, q.reshape(-1, 8), a1, u1, b1, octave=o1, bearing=be1)); f2t.append(mi355slam.FrameOnDevice(ctx, t.reshape(-1, 8), a2, u2, b2, bearing=be2))
+        Es.append(E)
+        want_m.append(oracle.match_loop_closure(q, a1, u1, b1, t, a2, u2, b2, 0.75, True))
+        want_t.append(oracle.match_triangulation(q, a1, o1, be1, u1, b1, t, a2, be2, u2, b2, E, sf, 25.0, True))
+    assert want_m[1][0] > 50 and want_t[1][0] > 20 and want_m[2][0] > 20
+    try:
+        for path in (0, 1):
+            ctx.set_match_path(path)
+            counts, matched = mi355slam.match_loop_closure(ctx, f1m, f2m, 0.75, True)
+            for i, (wn, wm) in enumerate(want_m):
+                assert counts[i] == wn and np.array_equal(matched[i], wm), ("loop closure", path, i)
+            counts, matched = mi355slam.match_triangulation(ctx, f1t, f2t, np.stack(Es), sf, 25.0, True)
+            for i, (wn, wm) in enumerate(want_t):
+                assert counts[i] == wn and np.array_equal(matched[i], wm), ("triangulation", path, i)
+    finally:
+        ctx.set_match_path(0)
+
+
+def test_greedy_matchers_keypoint_listed_in_two_nodes_falls_back_to_the_exact_walk(oracle, ctx):
+    """A DBoW2 FeatureVector never names a keypoint twice; node lists that do make the result depend on the order of the NODES, which
+    only the sequential walk reproduces -- the node-parallel pass must notice and hand the pair over (the pair next to it stays parallel)."""
+    import mi355slam
+    q, t, b1, b2, a1, a2, u1, u2 = _frames(4242, 400, 420, 6)
+    q &= 0x3; t &= 0x3                    # low-entropy descriptors + ratio 1.0 below: every query takes some free target, so consumption decides
+
+    def csr(b, extra):
+        order = np.argsort(b, kind="stable").astype(np.int32)
+        ids, counts = np.unique(b, return_counts=True)
+        lists = [list(order[np.cumsum(counts)[i] - counts[i]:np.cumsum(counts)[i]]) for i in range(len(ids))]
+        for node, kp in extra:
+            lists[node].insert(0, kp)                 # in front: a free copy would win every tie
+        start = np.zeros(len(ids) + 1, np.int32); start[1:] = np.cumsum([len(l) for l in lists])
+        return ids.astype(np.int32), start, np.concatenate(lists).astype(np.int32)
+    # kf2: the keypoints of node 0 are also offered in node 3 (a consumed target comes back as a candidate); kf1: one query listed twice
+    c2 = csr(b2, [(3, int(k)) for k in np.flatnonzero(b2 == 0)[:25]])
+    c1 = csr(b1, [(4, int(np.flatnonzero(b1 == 1)[0]))])
+    wn, wm = oracle.match_loop_closure(q, a1, u1, c1, t, a2, u2, c2, 1.0, True)
+    wn0, wm0 = oracle.match_loop_closure(q, a1, u1, b1, t, a2, u2, b2, 1.0, True)
+    fa, fb = mi355slam.FrameOnDevice(ctx, q, a1, u1, None, csr=c1), mi355slam.FrameOnDevice(ctx, t, a2, u2, None, csr=c2)
+    ga, gb = mi355slam.FrameOnDevice(ctx, q, a1, u1, b1), mi355slam.FrameOnDevice(ctx, t, a2, u2, b2)
+    counts, matched = mi355slam.match_loop_closure(ctx, [ga, fa, ga], [gb, fb, gb], 1.0, True)
+    assert counts[1] == wn and np.array_equal(matched[1], wm)
+    for i in (0, 2):
+        assert counts[i] == wn0 and np.array_equal(matched[i], wm0)
+    assert wn > 20
+
+
 def test_hamming_candidates_projection_core(oracle, ctx):
     """Scoring core of searchByProjection / replaceDuplication: each map point against its own radius-query candidates."""
     import mi355slam
