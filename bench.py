@@ -53,12 +53,14 @@ def parse_args(argv=None):
     ap.add_argument("--only-ba", action="store_true", help="local-BA leg only (profiling runs): prints its object as the line")
     ap.add_argument("--ba-batch", type=int, default=256)
     ap.add_argument("--ba-steps", type=int, default=3)
-    ap.add_argument("--c5-frames", type=int, default=40, help="frames per sequence in the C5 leg")
+    ap.add_argument("--c5-frames", type=int, default=320, help="frames per sequence in the C5 leg")
+    ap.add_argument("--c5-distinct", type=int, default=40, help="distinct images per sequence (walked forwards and backwards)")
     ap.add_argument("--c5-keyframe-every", type=int, default=5)
     ap.add_argument("--c5-native", action="store_true", help="drive the C5 sequences from C++ threads (tools/c5_native.cpp) instead of Python threads")
     ap.add_argument("--plumbing", action="store_true", help="no GPU work: launcher / rendezvous / aggregation only (gloo)")
     ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="with --plumbing: this rank exits with code 3 (launcher test)")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--launcher-timeout", type=int, default=1500, help="wall-clock limit of the N-rank launcher in seconds: past it every rank is stopped")
     a = ap.parse_args(argv)
     if a.only_headline:
         a.no_ba = a.no_c5 = a.no_extra = a.no_cpu_baseline = a.no_greedy = True
@@ -66,46 +68,94 @@ def parse_args(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------ launcher
+def _child_setup():
+    """In the child, before exec of the interpreter: die with the launcher (PR_SET_PDEATHSIG), whatever kills it."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+    except Exception:
+        pass
+
+
 def launch(args, argv):
-    """Parent of an N-rank run: no GPU call, no torch import.  One child per GPU; rank 0's stdout carries the JSON line."""
+    """Parent of an N-rank run: no GPU call, no torch import.  One child per GPU, each in a session of its own (so the whole rank, helper threads and
+    all, can be signalled as a group) and bound to the launcher's life (PDEATHSIG); rank 0's stdout carries the JSON line, every rank's stderr is kept
+    and its tail shown when the run fails.  SIGTERM / SIGINT to the launcher and the wall-clock deadline end every rank."""
+    import signal
     import socket
+    import tempfile
     port = args.master_port
     if not port:
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        errs.append(tempfile.TemporaryFile())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True, preexec_fn=_child_setup,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)                      # the rank's own session = its process group
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def reap(grace):
+        stop_all(signal.SIGTERM)
+        t_end = time.time() + grace
+        for p in procs:
+            try:
+                p.wait(max(t_end - time.time(), 0.1))
+            except subprocess.TimeoutExpired:
+                pass
+        stop_all(signal.SIGKILL)
+        for p in procs:
+            p.wait()
+    stopped = []
+
+    def on_signal(signum, _frame):
+        stopped.append(signum)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()))      # drain rank 0's pipe while the ranks run
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)      # drain rank 0's pipe while the ranks run
     reader.start()
-    codes = [None] * len(procs)
-    while any(c is None for c in codes):
-        for i, p in enumerate(procs):
-            if codes[i] is None:
-                codes[i] = p.poll()
+    deadline = time.time() + args.launcher_timeout
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
         if any(c not in (None, 0) for c in codes):            # one rank failed: the others would wait for it in a barrier forever
-            for i, p in enumerate(procs):
-                if codes[i] is None:
-                    p.terminate()
-            for i, p in enumerate(procs):
-                if codes[i] is None:
-                    try:
-                        codes[i] = p.wait(20)
-                    except subprocess.TimeoutExpired:
-                        p.kill(); codes[i] = p.wait()
+            why = "a rank failed"
+        elif stopped:
+            why = "launcher received signal %d" % stopped[0]
+        elif time.time() > deadline:
+            why = "launcher deadline of %d s passed" % args.launcher_timeout
+        if why:
+            reap(20)
             break
         time.sleep(0.05)
-    reader.join()
+    for sg, h in old.items():
+        signal.signal(sg, h)
+    codes = [p.wait() for p in procs]
+    reader.join(5)
     out0 = (chunks[0] if chunks else b"").decode()
     line = None
     for ln in out0.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-    if any(c != 0 for c in codes) or line is None:
-        sys.stderr.write("bench.py launcher: rank exit codes %s%s\n" % (codes, "" if line else "; rank 0 printed no result line"))
+    if why or any(c != 0 for c in codes) or line is None:
+        sys.stderr.write("bench.py launcher: %srank exit codes %s%s\n" % ((why + "; ") if why else "", codes, "" if line else "; rank 0 printed no result line"))
+        for r, f in enumerate(errs):
+            if codes[r] != 0 or line is None:
+                f.seek(0)
+                tail = f.read().decode(errors="replace").splitlines()[-15:]
+                if tail:
+                    sys.stderr.write("---- rank %d stderr (last lines) ----\n%s\n" % (r, "\n".join(tail)))
         if line:
             sys.stderr.write("rank 0 said: %s\n" % line)
         return 1
@@ -191,6 +241,7 @@ class Rank:
         import torch                                   # plumbing: device memory for the inputs + torch.distributed
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self.deferred = []                             # rank 0: (object, fn) -- CPU baselines, run after every GPU leg and after the process group is gone
         self.device = "cpu" if args.plumbing else "cuda"
         if not args.plumbing:
             torch.cuda.set_device(self.local_rank)
@@ -223,7 +274,7 @@ class Rank:
         return [float(o.item()) for o in outs]
 
     def close(self):
-        if self.world > 1:
+        if self.world > 1 and self.dist.is_initialized():
             self.dist.destroy_process_group()
 
 
@@ -262,8 +313,9 @@ class Headline:
         import mi355slam
         torch = R.torch
         self.R, self.ctx, self.ms = R, ctx, mi355slam
+        self.h, self.w = frames_np.shape[1:]
         self.frames = torch.from_numpy(frames_np).cuda()        # inputs resident in HBM before any timed region
-        self.ex = mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=BATCH)
+        self.ex = mi355slam.OrbExtractor(ctx, self.w, self.h, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=BATCH)
         cap = self.cap = self.ex.capacity
         self.view = None
         self.pair_q = torch.arange(BATCH, dtype=torch.int32, device="cuda")
@@ -285,7 +337,7 @@ class Headline:
 
     def step(self, images=None, mark=False):
         if images is None:
-            self.ex.extract(self.frames.data_ptr(), n_frames=BATCH, frame_stride=W * H, row_stride=W)
+            self.ex.extract(self.frames.data_ptr(), n_frames=BATCH, frame_stride=self.w * self.h, row_stride=self.w)
         else:
             self.ex.extract(images)                             # host frames: the H2D copies are part of the call
         if self.view is None:
@@ -321,6 +373,10 @@ class Headline:
         avg["hamming"] = match_ms / steps
         return dt, avg
 
+    def close(self):
+        self.ex.close()
+        del self.frames, self.best_idx, self.best_dist, self.second_dist, self.match
+
     def counts(self):
         import numpy as np
         n_kp = np.frombuffer(ctx_download(self.ctx, self.view.count, 4 * BATCH), dtype=np.int32)
@@ -328,12 +384,12 @@ class Headline:
         return n_kp, n_match
 
 
-def kernel_table(avg_ms, n_kp):
+def kernel_table(avg_ms, n_kp, w=W, h=H):
     """Per kernel: ms per launch and algorithmic GB/s (bytes per frame from SURVEY 8d / DESIGN.md 5, x 256 frames per launch)."""
     import numpy as np
     import mi355slam
-    ws, hs = mi355slam.level_sizes(LEVELS, SCALE, W, H)
-    P = int((ws.astype(np.int64) * hs).sum()); N0 = W * H; K = float(n_kp.mean())
+    ws, hs = mi355slam.level_sizes(LEVELS, SCALE, w, h)
+    P = int((ws.astype(np.int64) * hs).sum()); N0 = w * h; K = float(n_kp.mean())
     alg = {"resize": (P - int(ws[-1]) * int(hs[-1])) + (P - N0),      # read levels 0..n-2, write levels 1..n-1
            "blur": 0,                                            # the blurred pyramid is not materialised any more (k_describe blurs its own patches); the stage slot stays
            "fast": P, "select": 4 * K, "tracks": 0, "describe": 1821 * K, "hamming": 32 * 2 * K + 8 * K}
@@ -359,15 +415,13 @@ def run_gpu(R, args):
     if args.only_ba:
         args.no_cpu_baseline = True
         res = bench_ba(R, ctx, args)
-        if R.rank == 0:
-            print(json.dumps(res), flush=True)
         ctx.close()
+        finish(R, args, res)
         return
     if args.only_greedy:
         res = bench_greedy(R, ctx, args)
-        if R.rank == 0:
-            print(json.dumps(res), flush=True)
         ctx.close()
+        finish(R, args, res)
         return
     frames_np = synth.synth_sequences(BATCH, W, H, 1000 + N_SEQ * R.rank)
     hl = Headline(R, ctx, frames_np)
@@ -403,7 +457,11 @@ def run_gpu(R, args):
                 "traffic_source": (PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, tools/profile_set.sh; not measured in this run)") if pmc else None,
                 # the front-end kernels are bound by VALU issue (VOP3 / packed forms issue once per ~4 cycles per SIMD, profiles/r01_e_valu_issue_rates.txt)
                 "valu_insts": valu, "valu_issue_frac": round(valu / 1024 * 4 / 2.4e9 / (avg_ms[dom] * 1e-3), 3) if valu else None,
-                "whole_step_alg_GBs": round((4 * P + 1821 * K + 72 * K) * BATCH * args.steps / dt / 1e9, 1)}
+                # bytes the step has in its contract NOW: the blurred pyramid is no longer written or read (k_describe blurs its own patches), so
+                # input N0 + levels written (P - N0) + levels read for detection P = 2P, + 1821 K (patches, outputs) + 72 K (match pair);
+                # the SURVEY 8d contract figure (4P + ..., with the blur round trip) is kept beside it
+                "whole_step_alg_GBs": round((2 * P + 1821 * K + 72 * K) * BATCH * args.steps / dt / 1e9, 1),
+                "contract_alg_GBs": round((4 * P + 1821 * K + 72 * K) * BATCH * args.steps / dt / 1e9, 1)}
     out = base_line(R, args, value, dt)
     out["config"] = {"workload": "C2+C3: ORB extract 1280x720, 8 levels x1.2, 2000 kpts/frame, FAST thr 20, batch 256 synthetic frames/GPU, "
                                  "+ Hamming brute-force best2 + ratio 0.75 of each frame vs the previous (256 pairs, <=2000x2000)",
@@ -445,8 +503,25 @@ def run_gpu(R, args):
             # PCIe-inclusive: frames start in pinned HOST memory, keypoints + descriptors end in host memory
             hl.set_frames(frames_np)
             return pcie_inclusive(R, hl, frames_np, max(min(args.steps // 4, 12), 2))
+        def vga_leg():
+            # north_star: "synthetic VGA/720p frames" -- the same step on 256 frames of 640x480 (same quotas, 2000 keypoints)
+            vga_np = synth.synth_sequences(BATCH, 640, 480, 1000 + N_SEQ * R.rank)
+            hv = Headline(R, ctx, vga_np)
+            vdt, vavg = hv.timed(max(args.steps // 2, 1), 2)
+            v_total, vdt_max = R.aggregate(BATCH * max(args.steps // 2, 1), vdt)
+            vkp, vmatch = hv.counts()
+            vk, valg, vP, vK = kernel_table(vavg, vkp, 640, 480)
+            hv.close()
+            return {"value": round(v_total / vdt_max, 1), "unit": "frames/s", "ms_per_step": round(vdt / max(args.steps // 2, 1) * 1e3, 3),
+                    "workload": "the C2+C3 step on 256 synthetic 640x480 frames per GPU (P = %d pyramid pixels per frame)" % vP,
+                    "keypoints_per_frame": round(vK, 1), "ratio_matches_per_frame": round(vmatch / BATCH, 1),
+                    "whole_step_alg_GBs": round((2 * vP + 1821 * vK + 72 * vK) * BATCH * max(args.steps // 2, 1) / vdt / 1e9, 1),
+                    "contract_alg_GBs": round((4 * vP + 1821 * vK + 72 * vK) * BATCH * max(args.steps // 2, 1) / vdt / 1e9, 1), "kernels": vk}
         leg("sparse_input", sparse_leg)
+        leg("vga", vga_leg)
         leg("value_pcie_inclusive", pcie_leg)
+        hl.close()
+        leg("c3", lambda: bench_c3(R, ctx, args))
     # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 distinct windows per launch, device-resident ----
     if not args.no_ba:
         leg("local_ba", lambda: bench_ba(R, ctx, args))
@@ -458,11 +533,23 @@ def run_gpu(R, args):
         leg("c5", lambda: bench_c5(R, args))
     if failed:
         out["failed_legs"] = failed
-    if R.rank == 0:
-        if R.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_frames(frames_np)
-        print(json.dumps(out), flush=True)
     ctx.close()
+    finish(R, args, out, [(out, lambda: cpu_baseline_frames(frames_np))] if not args.no_cpu_baseline else [])
+
+
+def finish(R, args, out, first=()):
+    """Every GPU leg is done: the ranks meet once more and take the process group down; then rank 0 -- alone, the other ranks have nothing left to do --
+    times the CPU baselines (at every N, on this rank's host cores) and prints the line."""
+    R.barrier()
+    R.close()
+    if R.rank != 0:
+        return
+    for obj, fn in list(first) + R.deferred:
+        try:
+            obj["cpu_baseline"] = fn()
+        except Exception as e:                                      # noqa: BLE001 -- reported in the line
+            obj["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    print(json.dumps(out), flush=True)
 
 
 def pcie_inclusive(R, hl, frames_np, steps):
@@ -610,6 +697,7 @@ def bench_ba(R, ctx, args):
     for i in range(n_new):
         b = mi355slam.BundleAdjuster(ctx, [probs[i % len(probs)]], max_iters=10); b.solve(); b.download(0); b.close()
     new_window_ms = (time.perf_counter() - t1) / n_new * 1e3
+    two_stage = bench_ba_two_stage(R, ctx, args, probs)
     alg_bytes_per_launch = 6.61e6 * trials * args.ba_batch    # 6.61 MB per LM iteration (= per damped solve) at C4
     achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     pmc = pmc_of("k_ba_lm")
@@ -617,14 +705,195 @@ def bench_ba(R, ctx, args):
            "unit": "solves/s", "windows_per_launch": args.ba_batch, "distinct_windows": len(probs), "ms_per_launch": round(kernel_ms, 3),
            "lm_iterations": round(iters, 2), "lm_trials": round(trials, 2),
            "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
-           "new_window_ms": round(new_window_ms, 3), "dtype": "f64",
+           "new_window_ms": round(new_window_ms, 3), "dtype": "f64", "two_stage": two_stage,
            "roofline": {"kernel": "k_ba_lm", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
                         "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes of this build over the 256-window launch, tools/pmc_ba.sh)") if pmc else None}}
-    if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_ba(probs[:32])
+    if R.rank == 0 and not args.no_cpu_baseline:
+        R.deferred.append((res, lambda: cpu_baseline_ba(probs[:32])))
     ba.close(); one.close()
     return res
+
+
+def two_stage_problems(p, cur):
+    """The reference's localBundleAdjust schedule on one window (bundle_adjuster.cpp:245-373): stage 1 frees only the current keyframe (+ all points),
+    stage 2 frees every keyframe and adds the orientation prior Omega = diag((100 r)^2 I3, 0) against a fixed copy of the stage-1 pose."""
+    import numpy as np
+    n = len(p["pose"])
+    s1 = dict(p); s1["pose_fixed"] = np.ones(n, np.uint8); s1["pose_fixed"][cur] = 0
+    s2 = dict(p); s2["pose"] = np.vstack([p["pose"], p["pose"][cur:cur + 1]])
+    s2["pose_fixed"] = np.concatenate([np.zeros(n, np.uint8), [1]]).astype(np.uint8)
+    Wm = np.zeros((6, 6)); Wm[:3, :3] = np.eye(3) * (100 * 100.0) ** 2
+    s2["edge_i"] = np.concatenate([p["edge_i"], [n]]).astype(np.int32); s2["edge_j"] = np.concatenate([p["edge_j"], [cur]]).astype(np.int32)
+    s2["edge_meas"] = np.vstack([p["edge_meas"], [[0, 0, 0, 1, 0, 0, 0]]]); s2["edge_info"] = np.vstack([p["edge_info"], Wm.reshape(1, 36)])
+    return s1, s2
+
+
+def bench_ba_two_stage(R, ctx, args, probs):
+    """C4 under the reference's two-stage schedule, iterations = int(1 + sqrt(50)) = 8 per stage (bundle_adjuster.cpp:156,322-373): both handles built once,
+    stage 1 -> ms_ba_copy_state -> stage 2 chained on the device."""
+    import numpy as np
+    import mi355slam
+    iters = int(1 + np.sqrt(50.0))
+    cur = len(probs[0]["pose"]) - 1                           # the newest keyframe of the window
+    st = [two_stage_problems(p, cur) for p in probs]
+    b1 = mi355slam.BundleAdjuster(ctx, [a for a, _ in st], max_iters=iters)
+    b2 = mi355slam.BundleAdjuster(ctx, [b for _, b in st], max_iters=iters)
+    extra = np.full(len(probs), cur, np.int32)
+
+    def run():
+        b1.solve(); b2.copy_state_from(b1, extra); b2.solve()
+    run(); ctx.sync()
+    ctx.event_mark(10); b1.solve(); ctx.event_mark(11); b2.copy_state_from(b1, extra); b2.solve(); ctx.event_mark(12)
+    s1_ms, s2_ms = ctx.event_elapsed_ms(10, 11), ctx.event_elapsed_ms(11, 12)
+    R.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.ba_steps):
+        run()
+    ctx.sync()
+    R.barrier()
+    dt = time.perf_counter() - t0
+    total, dt = R.aggregate(len(probs) * args.ba_steps, dt)
+    r1, r2 = b1.download(0)["stats"], b2.download(0)["stats"]
+    # one window, the way the mapper pays for it: both creates + stage 1 + copy + stage 2 + one download + destroys
+    s1, s2 = st[0]
+    o1 = mi355slam.BundleAdjuster(ctx, [s1], max_iters=iters); o2 = mi355slam.BundleAdjuster(ctx, [s2], max_iters=iters)
+    o1.solve(); o2.copy_state_from(o1, extra[:1]); o2.solve(); ctx.sync()
+    ctx.event_mark(10); o1.solve(); o2.copy_state_from(o1, extra[:1]); o2.solve(); ctx.event_mark(11)
+    one_ms = ctx.event_elapsed_ms(10, 11)
+    o1.close(); o2.close()
+    t1 = time.perf_counter()
+    n_new = 6
+    for i in range(n_new):
+        a, b = st[i % len(st)]
+        h1 = mi355slam.BundleAdjuster(ctx, [a], max_iters=iters); h2 = mi355slam.BundleAdjuster(ctx, [b], max_iters=iters)
+        h1.solve(); h2.copy_state_from(h1, extra[:1]); h2.solve(); h2.download(0); h1.close(); h2.close()
+    new_ms = (time.perf_counter() - t1) / n_new * 1e3
+    b1.close(); b2.close()
+    return {"schedule": "stage 1: current keyframe + all points free, %d iterations; stage 2: every keyframe free + orientation prior edge, %d iterations (bundle_adjuster.cpp:156,322-373)" % (iters, iters),
+            "value": round(total / dt, 1), "unit": "two-stage solves/s", "windows_per_launch": len(probs),
+            "stage1_ms_per_launch": round(s1_ms, 3), "stage2_ms_per_launch": round(s2_ms, 3),
+            "stage1_iterations_trials": [r1["iters"], r1["trials"]], "stage2_iterations_trials": [r2["iters"], r2["trials"]],
+            "chi2": [round(r1["chi2_init"], 1), round(r1["chi2_final"], 1), round(r2["chi2_final"], 1)],
+            "single_window_ms": round(one_ms, 3), "new_window_ms": round(new_ms, 3)}
+
+
+def bench_c3(R, ctx, args, n_pairs=1000, nq=2000, nt=2000, n_inlier=1400, flip=0.08, buckets=100):
+    """BASELINE config 3 on its own workload: 1000 pairs of 2000 x 2000 descriptors -- target rows 0..1399 are rows of the query set,
+    permuted, each bit flipped with probability 0.08 (mean distance ~20), the other 600 random; policy = M1 core (best / second, best <= 50,
+    0.75 second >= best).  Timed: the unmasked search on the matrix cores and on the popcount kernel, the 100-bucket masked variant, the ratio
+    test, and the greedy-unique variant (matchForLoopClosures' consumption of targets, keyframe_matcher.cpp:98-100,:128) with one bucket and with
+    100.  Descriptors are generated on the device with torch (plumbing); same recipe as tools/synth.py synth_descriptor_pair."""
+    import ctypes as C
+    import numpy as np
+    import mi355slam
+    torch = R.torch
+    L, vp = mi355slam.lib(), mi355slam._vp
+    g = torch.Generator(device="cuda"); g.manual_seed(4242 + R.rank)
+    rbits = lambda *shape: torch.randint(-2 ** 31, 2 ** 31, shape, dtype=torch.int64, device="cuda", generator=g).to(torch.int32)
+    q = rbits(n_pairs, nq, 8)
+    t = torch.empty(n_pairs, nt, 8, dtype=torch.int32, device="cuda")
+    perm = torch.argsort(torch.rand(n_pairs, nq, device="cuda", generator=g), dim=1)[:, :n_inlier]
+    w32 = (torch.ones(32, dtype=torch.int64, device="cuda") << torch.arange(32, device="cuda")).view(1, 1, 1, 32)
+    for p0 in range(0, n_pairs, 50):
+        sl = slice(p0, min(p0 + 50, n_pairs))
+        src = torch.gather(q[sl], 1, perm[sl].unsqueeze(-1).expand(-1, -1, 8))
+        fl = ((torch.rand(src.shape[0], n_inlier, 8, 32, device="cuda", generator=g) < flip).to(torch.int64) * w32).sum(-1).to(torch.int32)
+        t[sl, :n_inlier] = src ^ fl
+    t[:, n_inlier:] = rbits(n_pairs, nt - n_inlier, 8)
+    # vocabulary nodes for the bucketed variants: a target that is a noisy copy of a query sits in the query's node (what a vocabulary does most of the time)
+    qb = torch.randint(0, buckets, (n_pairs, nq), dtype=torch.int32, device="cuda", generator=g)
+    tb = torch.randint(0, buckets, (n_pairs, nt), dtype=torch.int32, device="cuda", generator=g)
+    tb[:, :n_inlier] = torch.gather(qb, 1, perm)
+    bi = torch.empty(n_pairs * nq, dtype=torch.int32, device="cuda"); bd = torch.empty(n_pairs * nq, dtype=torch.int16, device="cuda")
+    sd = torch.empty_like(bd); match = torch.empty_like(bi)
+    torch.cuda.synchronize()
+
+    def best2(masked):
+        ctx.check(L.ms_hamming_best2(ctx._h, vp(q.data_ptr()), nq, vp(t.data_ptr()), nt, n_pairs, vp(qb.data_ptr()) if masked else None, vp(tb.data_ptr()) if masked else None, None,
+                                     vp(bi.data_ptr()), vp(bd.data_ptr()), vp(sd.data_ptr())), "ms_hamming_best2")
+
+    def ratio():
+        mi355slam.ratio_test_device(ctx, bi.data_ptr(), bd.data_ptr(), sd.data_ptr(), n_pairs * nq, LOWE_RATIO, 50, match.data_ptr())
+
+    def timed(fn, reps=3):
+        fn(); ctx.sync()
+        ctx.event_mark(8)
+        for _ in range(reps):
+            fn()
+        ctx.event_mark(9)
+        return ctx.event_elapsed_ms(8, 9) / reps
+    ops = 2.0 * 256 * nq * nt * n_pairs                       # one multiply-add per descriptor bit and (query, target)
+    res = {"workload": "%d pairs x %d x %d descriptors per GPU, %d inliers at bit-flip probability %.2f, Lowe ratio %.2f, max distance 50" % (n_pairs, nq, nt, n_inlier, flip, LOWE_RATIO),
+           "alg_bytes_per_pair": 32 * (nq + nt) + 8 * nq, "unit": "pairs/s"}
+    ms = timed(lambda: best2(False))
+    ratio(); ctx.sync()
+    res["ratio_matches_per_pair"] = round(float((match >= 0).sum().item()) / n_pairs, 1)
+    res["matrix_core_search"] = {"ms_per_launch": round(ms, 3), "pairs_per_s": round(n_pairs / ms * 1e3, 1), "alg_GBs": round((32 * (nq + nt) + 8 * nq) * n_pairs / ms / 1e6, 1),
+                                 "roofline": {"bound": "mfma", "achieved": round(ops / ms / 1e9, 1), "peak": 5000.0, "unit": "Top/s (i8)", "frac": round(ops / ms / 1e9 / 5000.0, 4)}}
+    ctx.set_hamming_path(1)
+    try:
+        ms = timed(lambda: best2(False))
+    finally:
+        ctx.set_hamming_path(0)
+    # v_xor + v_bcnt per descriptor word and pair: 16 lane-operations per pair against the chip's 1024 SIMDs x 16 lanes x 2.4 GHz (SURVEY 8d)
+    res["popcount_search"] = {"ms_per_launch": round(ms, 3), "pairs_per_s": round(n_pairs / ms * 1e3, 1),
+                              "valu_lane_ops_frac": round(16.0 * nq * nt * n_pairs / (ms * 1e-3) / (1024 * 64 * 2.4e9 / 4), 3)}
+    ms = timed(lambda: best2(True))
+    res["masked_%d_buckets" % buckets] = {"ms_per_launch": round(ms, 3), "pairs_per_s": round(n_pairs / ms * 1e3, 1)}
+    res["ratio_test_ms"] = round(timed(ratio), 4)
+    # greedy-unique variant: M1 with every keypoint usable, no rotation histogram
+    ones = torch.ones(max(nq, nt), dtype=torch.uint8, device="cuda")
+    outs = torch.empty(n_pairs, nq, dtype=torch.int32, device="cuda"); nm = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    ptrs = (C.c_void_p * n_pairs)(*[outs.data_ptr() + 4 * nq * p for p in range(n_pairs)])
+    iota = torch.arange(max(nq, nt), dtype=torch.int32, device="cuda")
+    node1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st_q1 = torch.tensor([0, nq], dtype=torch.int32, device="cuda"); st_t1 = torch.tensor([0, nt], dtype=torch.int32, device="cuda")
+    nodeB = torch.arange(buckets, dtype=torch.int32, device="cuda")
+
+    def csr(b):                                                # per pair: keypoints of a node in index order (stable sort), node_start by counting
+        order = torch.argsort(b, dim=1, stable=True).to(torch.int32).contiguous()
+        cnt = torch.zeros(b.shape[0], buckets, dtype=torch.int64, device="cuda").scatter_add_(1, b.to(torch.int64), torch.ones_like(b, dtype=torch.int64))
+        start = torch.zeros(b.shape[0], buckets + 1, dtype=torch.int32, device="cuda"); start[:, 1:] = torch.cumsum(cnt, 1).to(torch.int32)
+        return order, start.contiguous()
+    oq, sq = csr(qb); ot, st = csr(tb)
+    torch.cuda.synchronize()
+
+    def frames(bucketed):
+        F1, F2 = (mi355slam.MatchFrame * n_pairs)(), (mi355slam.MatchFrame * n_pairs)()
+        for p in range(n_pairs):
+            b1 = mi355slam.Bow(buckets, nodeB.data_ptr(), sq.data_ptr() + 4 * (buckets + 1) * p, oq.data_ptr() + 4 * nq * p) if bucketed else mi355slam.Bow(1, node1.data_ptr(), st_q1.data_ptr(), iota.data_ptr())
+            b2 = mi355slam.Bow(buckets, nodeB.data_ptr(), st.data_ptr() + 4 * (buckets + 1) * p, ot.data_ptr() + 4 * nt * p) if bucketed else mi355slam.Bow(1, node1.data_ptr(), st_t1.data_ptr(), iota.data_ptr())
+            F1[p] = mi355slam.MatchFrame(nq, q.data_ptr() + 32 * nq * p, 0, 0, 0, ones.data_ptr(), b1)
+            F2[p] = mi355slam.MatchFrame(nt, t.data_ptr() + 32 * nt * p, 0, 0, 0, ones.data_ptr(), b2)
+        return F1, F2
+    for name, bucketed in (("greedy_unique_single_bucket", False), ("greedy_unique_%d_buckets" % buckets, True)):
+        F1, F2 = frames(bucketed)
+        ms = timed(lambda: ctx.check(L.ms_match_loop_closure(ctx._h, F1, F2, n_pairs, C.c_float(LOWE_RATIO), 0, ptrs, vp(nm.data_ptr())), "ms_match_loop_closure"), reps=2)
+        res[name] = {"ms_per_launch": round(ms, 3), "pairs_per_s": round(n_pairs / ms * 1e3, 1), "matches_per_pair": round(float(nm.sum().item()) / n_pairs, 1)}
+        ms1 = timed(lambda: ctx.check(L.ms_match_loop_closure(ctx._h, F1, F2, 1, C.c_float(LOWE_RATIO), 0, ptrs, vp(nm.data_ptr())), "ms_match_loop_closure"), reps=3)
+        res[name]["one_pair_ms"] = round(ms1, 4)
+    if R.rank == 0 and not args.no_cpu_baseline:
+        host = [x[:4].cpu().numpy().view(np.uint32) for x in (q, t)] + [x[:4].cpu().numpy() for x in (qb, tb)]
+        R.deferred.append((res, lambda: cpu_baseline_c3(host, buckets)))
+    return res
+
+
+def cpu_baseline_c3(host, buckets):
+    """The oracle on 4 of the leg's pairs, 1 thread: the brute-force best / second search, its 100-bucket form, and M1's greedy walk with one bucket and with 100."""
+    mso = _oracle()
+    import numpy as np
+    q, t, qb, tb = host
+    n = len(q)
+    ones_q, ones_t, zq, zt = np.ones(q.shape[1], np.uint8), np.ones(t.shape[1], np.uint8), np.zeros(q.shape[1], np.float32), np.zeros(t.shape[1], np.float32)
+    legs = {"search": lambda i: mso.hamming_best2(q[i], t[i]),
+            "masked_%d_buckets" % buckets: lambda i: mso.hamming_best2(q[i], t[i], q_bucket=qb[i], t_bucket=tb[i]),
+            "greedy_unique_single_bucket": lambda i: mso.match_loop_closure(q[i], zq, ones_q, np.zeros(q.shape[1], np.int32), t[i], zt, ones_t, np.zeros(t.shape[1], np.int32), LOWE_RATIO, False),
+            "greedy_unique_%d_buckets" % buckets: lambda i: mso.match_loop_closure(q[i], zq, ones_q, qb[i], t[i], zt, ones_t, tb[i], LOWE_RATIO, False)}
+    out = {"kind": "port", "cores": 1, "unit": "pairs/s", "sample": "%d of the leg's pairs, oracle/libmso.so (gcc -O2, scalar), 1 thread" % n}
+    for name, fn in legs.items():
+        out[name] = round(_pool_rate(fn, list(range(n)), 1), 2)
+    return out
 
 
 def cpu_baseline_greedy(wl):
@@ -697,8 +966,16 @@ def bench_greedy(R, ctx, args):
         leg["matches_per_pair"] = round(float(nm.download(np.int32, (n_adj,)).mean()), 1)
         res[name] = leg
     if R.rank == 0 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_greedy(wl)
+        R.deferred.append((res, lambda: cpu_baseline_greedy(wl)))
     return res
+
+
+def image_of(i, n_distinct):
+    """Frame i of a sequence that walks n_distinct images forwards and backwards (0, 1, .., n-1, n-2, .., 1, 0, 1, ..): consecutive frames always overlap."""
+    if n_distinct < 2:
+        return 0
+    j = i % (2 * n_distinct - 2)
+    return j if j < n_distinct else 2 * n_distinct - 2 - j
 
 
 class SequenceRunner(threading.Thread):
@@ -706,9 +983,10 @@ class SequenceRunner(threading.Thread):
     previous frame -> ratio test; on every k-th frame (a keyframe) one local BA of a NEW C4-shaped window (create + solve + download).
     Own context (stream) and handles; nothing is batched across frames."""
 
-    def __init__(self, device, seq_id, frames_np, windows, kf_every, start_evt, on_frame=None):
+    def __init__(self, device, seq_id, frames_np, windows, kf_every, start_evt, on_frame=None, n_total=None):
         super().__init__()
         self.device, self.seq_id, self.frames_np, self.windows, self.kf_every, self.start_evt = device, seq_id, frames_np, windows, kf_every, start_evt
+        self.n_total = n_total or len(frames_np)                 # frames of the sequence: the images are walked forwards and backwards (image_of)
         self.on_frame = on_frame                                 # tests only: called after every frame with the device results (synchronises)
         self.frames_done = self.ba_done = self.matches = 0
         self.error = None
@@ -719,7 +997,7 @@ class SequenceRunner(threading.Thread):
         try:
             import mi355slam
             ctx = mi355slam.Context(self.device)
-            n = len(self.frames_np)
+            n, nd = self.n_total, len(self.frames_np)
             buf = ctx.upload(self.frames_np)
             ex = [mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=1) for _ in range(2)]
             cap = ex[0].capacity
@@ -728,7 +1006,7 @@ class SequenceRunner(threading.Thread):
 
             def frame(i, count):
                 e = ex[i & 1]
-                e.extract(buf.ptr + i * W * H, n_frames=1, frame_stride=W * H, row_stride=W)
+                e.extract(buf.ptr + image_of(i, nd) * W * H, n_frames=1, frame_stride=W * H, row_stride=W)
                 if views[i & 1] is None:
                     views[i & 1] = e.device_view()
                 if i:
@@ -770,12 +1048,12 @@ def bench_c5(R, args):
     import synth
     from mi355slam import shard
     mine = [s for s in range(N_SEQ) if shard.sequence_of(s, R.world) == R.rank]
-    F = args.c5_frames
+    F, FD = args.c5_frames, min(args.c5_distinct, args.c5_frames)
     import numpy as np
     seq_frames, seq_windows = [], []
     for s in mine:
-        g = synth.SequenceSynth(W, H, 2000 + s, 2 * (F - 1), F - 1)
-        seq_frames.append(np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(F)])))
+        g = synth.SequenceSynth(W, H, 2000 + s, 2 * (FD - 1), FD - 1)
+        seq_frames.append(np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(FD)])))
         seq_windows.append([] if args.no_ba else [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + 16 * s + k) for k in range(4)])
     native = _c5_native_lib() if args.c5_native else None
     if native is not None and mine:
@@ -788,7 +1066,7 @@ def bench_c5(R, args):
         warr = (mi355slam.BaProblemC * max(len(structs), 1))(*structs)
         fptr = (C.c_void_p * len(mine))(*[f.ctypes.data for f in seq_frames])
         native.c5_prepare.restype = C.c_void_p
-        job = native.c5_prepare(R.local_rank, len(mine), F, W, H, fptr, warr, len(structs), args.c5_keyframe_every, LEVELS, C.c_float(SCALE), MAX_KPTS, FAST_THR, C.c_float(LOWE_RATIO))
+        job = native.c5_prepare(R.local_rank, len(mine), F, FD, W, H, fptr, warr, len(structs), args.c5_keyframe_every, LEVELS, C.c_float(SCALE), MAX_KPTS, FAST_THR, C.c_float(LOWE_RATIO))
         if not job:
             raise RuntimeError("c5_prepare failed")
         secs, seq_s = C.c_double(), (C.c_double * len(mine))()
@@ -805,7 +1083,7 @@ def bench_c5(R, args):
         del keep
     else:
         start = threading.Event()
-        runners = [SequenceRunner(R.local_rank, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start) for k, s in enumerate(mine)]
+        runners = [SequenceRunner(R.local_rank, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start, n_total=F) for k, s in enumerate(mine)]
         for r in runners:
             r.start()
         for r in runners:
@@ -823,8 +1101,8 @@ def bench_c5(R, args):
         frames_mine, ba_mine, matches, driver = sum(r.frames_done for r in runners), sum(r.ba_done for r in runners), [r.matches for r in runners], "python threads (SequenceRunner)"
     frames_total, dt_max = R.aggregate(frames_mine, dt)
     ba_total, _ = R.aggregate(ba_mine, dt)
-    return {"workload": "8 independent 720p sequences x %d frames; per frame extract -> match vs previous -> ratio test; every %d-th frame a local BA of a new "
-                        "C4 window (create + solve + download); sequence s on GPU s mod N, one host thread + context per sequence" % (F, args.c5_keyframe_every),
+    return {"workload": "8 independent 720p sequences x %d frames (%d distinct images each, walked forwards and backwards); per frame extract -> match vs previous -> ratio test; "
+                        "every %d-th frame a local BA of a new C4 window (create + solve + download); sequence s on GPU s mod N, one host thread + context per sequence" % (F, FD, args.c5_keyframe_every),
             "driver": driver,
             "scaling": "strong (8 sequences in total)", "frames_per_s": round(frames_total / dt_max, 1), "ba_per_s": round(ba_total / dt_max, 1),
             "seconds": round(dt_max, 4), "per_gpu": [round(v, 1) for v in R.gather(frames_mine / dt)],

@@ -295,7 +295,8 @@ int ms_match_loop_closure(ms_ctx *ctx, const ms_match_frame *pairs1, const ms_ma
 /* Execution path of the two greedy matchers: 0 (default) = one wavefront per shared vocabulary node, all nodes and pairs side by side
  * (valid because a DBoW2 FeatureVector names each keypoint in exactly one node, so the greedy order only matters inside a node; a pair
  * whose node lists break that property is detected on the device and redone sequentially); 1 = one wavefront per pair walking the
- * nodes in order.  Both give the reference's result bit for bit. */
+ * nodes in order; 2 = as 0, but ONE workgroup walks the whole work list of large nodes (a test setting: it makes a workgroup reuse its
+ * staging memory across nodes).  All give the reference's result bit for bit. */
 int ms_match_set_path(ms_ctx *ctx, int path);
 
 /* matchForTriangulationDBoW (keyframe_matcher.hpp:53, keyframe_matcher.cpp:160-293).
@@ -362,6 +363,13 @@ int ms_ba_set_team(ms_ba *ba, int workgroups_per_problem);
  * and a densely coupled map by many).  Has no effect on smaller systems. */
 int ms_ba_set_factor_team(ms_ba *ba, int workgroups);
 int ms_ba_solve(ms_ba *ba);
+/* Chains two solves on the device: the state `src`'s last solve left (poses, points) becomes the INITIAL state of `dst`'s problems --
+ * the step between stage 1 and stage 2 of localBundleAdjust (bundle_adjuster.cpp:335-373: same vertices, every keyframe unfixed, one more
+ * edge against a fixed copy of the just-optimised pose) without a download / upload in between.  Both handles hold the same number of
+ * problems on the same context; problem i of dst has the points of problem i of src and at least its poses; each pose dst has beyond
+ * them takes the value of src's pose extra_pose_src[i] (HOST array, one entry per problem; may be NULL when the pose counts agree).
+ * Asynchronous on the context stream, ordered after src's solve. */
+int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src);
 /* Team launches (more than one workgroup per problem) synchronise their workgroups with spin barriers, which need every workgroup
  * of the launch resident: problems x team <= CUs is enforced per launch, and the team launches of one process are admitted per device
  * so that their workgroups together fit the CUs (a launch waits, on the device, for as many older ones of other contexts as it takes),

@@ -2298,6 +2298,18 @@ __global__ void k_ba_team_reset(const BaProb *probs, int n, int gave_up) {
     if (i < n) { probs[i].bar[0] = 0; probs[i].bar[32] = 0; probs[i].flag[1] = gave_up; }
 }
 
+// the solved state of src's problems becomes the initial state of dst's (ms_ba_copy_state); poses dst has beyond src's take src's pose extra[p]
+__global__ __launch_bounds__(256) void k_ba_copy_state(const BaProb *dst, const BaProb *src, const int32_t *extra) {
+    const BaProb &D = dst[blockIdx.x], &S = src[blockIdx.x];
+    double *pose0 = const_cast<double *>(D.pose0), *point0 = const_cast<double *>(D.point0);
+    const int ex = extra ? extra[blockIdx.x] : 0;
+    for (int i = threadIdx.x; i < 7 * D.n_pose; i += 256) {
+        const int k = i / 7, from = k < S.n_pose ? k : ex;
+        pose0[i] = S.pose[7 * (size_t)from + (i - 7 * k)];
+    }
+    for (int i = threadIdx.x; i < 3 * D.n_point; i += 256) point0[i] = S.point[i];
+}
+
 // grid = problems x team workgroups; workgroup b works on problem b / team
 __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -3051,6 +3063,31 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
     if (pose) MS_HIP(c, hipMemcpy(pose, H.pose, 7 * (size_t)H.n_pose * sizeof(double), hipMemcpyDeviceToHost));
     if (point && H.n_point) MS_HIP(c, hipMemcpy(point, H.point, 3 * (size_t)H.n_point * sizeof(double), hipMemcpyDeviceToHost));
     if (chi2_per_obs && H.n_obs) MS_HIP(c, hipMemcpy(chi2_per_obs, H.chi2_obs, (size_t)H.n_obs * sizeof(double), hipMemcpyDeviceToHost));
+    return MS_OK;
+}
+
+int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src) {
+    if (!dst || !src || dst == src || dst->ctx != src->ctx || dst->n != src->n) return MS_ERR_INVALID;
+    ms_ctx *c = dst->ctx;
+    bool need_extra = false;
+    for (int i = 0; i < dst->n; ++i) {
+        const BaProb &D = dst->host[(size_t)i], &S = src->host[(size_t)i];
+        if (D.n_point != S.n_point || D.n_pose < S.n_pose) return ms_fail(c, MS_ERR_INVALID, "ms_ba_copy_state: problem %d: %d / %d poses, %d / %d points", i, D.n_pose, S.n_pose, D.n_point, S.n_point);
+        if (D.n_pose > S.n_pose) {
+            need_extra = true;
+            if (!extra_pose_src || extra_pose_src[i] < 0 || extra_pose_src[i] >= S.n_pose) return ms_fail(c, MS_ERR_INVALID, "ms_ba_copy_state: problem %d has %d poses more than its source and no valid pose to copy them from", i, D.n_pose - S.n_pose);
+        }
+    }
+    MS_HIP(c, hipSetDevice(c->device));
+    int32_t *d_extra = nullptr;
+    if (need_extra) {
+        void *scr = nullptr;
+        MS_TRY_BA(ms_scratch(c, sizeof(int32_t) * (size_t)dst->n, &scr));
+        d_extra = static_cast<int32_t *>(scr);
+        MS_HIP(c, hipMemcpyAsync(d_extra, extra_pose_src, sizeof(int32_t) * (size_t)dst->n, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_ba_copy_state, dim3(dst->n), dim3(256), 0, c->stream, dst->d_probs, src->d_probs, d_extra);
+    MS_KERNEL_CHECK(c, "k_ba_copy_state");
     return MS_OK;
 }
 

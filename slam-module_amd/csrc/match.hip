@@ -541,19 +541,20 @@ __global__ __launch_bounds__(64) void k_match_greedy(GreedyArgs A) {
 // (TemplatedVocabulary::transform calls addFeature once per feature), so the targets a query can consume are
 // the targets of its own node: the greedy order matters only INSIDE a node, and the nodes of a pair can run
 // side by side.  One wavefront per (pair, node of kf1):
-//   * the node's kf2 candidates live in the lanes' registers (descriptor, angle, bearing, "consumed" flag;
-//     positions >= 64 are re-read from memory with their flags in an LDS bitset),
+//   * the node's kf2 candidates live in the lanes' registers (descriptor, bearing, "free" flag; up to four per lane -- nodes with more
+//     than 256 candidates go to k_greedy_big_nodes below),
 //   * the node's kf1 queries are fetched 64 at a time, one per lane, and handed to the wave one after the other
 //     with v_readlane -- the walk has no dependent memory access per query any more (the one-wave-per-pair
 //     kernel above spent ~1 us per query in three of them),
-//   * matches go to the pair's rotation histogram / counter with integer atomics (order-free, deterministic).
-// k_greedy_finish then applies the histogram per pair.  Inputs that break the FeatureVector property (a keypoint
+//   * a node adds its number of matches to the pair's counter (integer atomic: order-free, deterministic).
+// k_greedy_finish then builds the pair's rotation histogram from the matches and applies it.  Inputs that break the FeatureVector property (a keypoint
 // listed in two shared nodes) are detected with per-keypoint counters and the pair is redone by the sequential
 // kernel, so the result is the reference's for ANY input.
 struct GreedyScratch {
     int32_t *own1, *own2;           // [n_pairs][stride]: node lists naming the keypoint (shared nodes only)
     int32_t stride1, stride2;
-    int32_t *hist;                  // [n_pairs][32]: 30 rotation bins, [30] matches, [31] redo flag
+    int32_t *hist;                  // [n_pairs][32]: [30] matches, [31] redo flag (the rest unused)
+    int32_t *big;                   // [0] nodes with more than 64 candidates found by k_greedy_nodes, [1] cursor of k_greedy_big_nodes, then int4 {pair, node of kf1, node of kf2, -} each
 };
 
 __global__ __launch_bounds__(256) void k_greedy_init(GreedyArgs A, GreedyScratch S) {
@@ -562,6 +563,7 @@ __global__ __launch_bounds__(256) void k_greedy_init(GreedyArgs A, GreedyScratch
     if (i < n1) { A.matched[p][i] = -1; S.own1[(size_t)p * S.stride1 + i] = 0; }
     if (i < n2) S.own2[(size_t)p * S.stride2 + i] = 0;
     if (i < 32) S.hist[32 * p + i] = 0;
+    if (p == 0 && i < 2) S.big[i] = 0;
 }
 
 __device__ __forceinline__ uint32_t rl_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -570,9 +572,38 @@ __device__ __forceinline__ double rl_d(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+constexpr int kGreedyCpl = 4;            // candidates per lane in k_greedy_nodes: nodes of up to 256 candidates stay in one wave's registers
+
+// Wave-wide reductions on the DPP network (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): 6 steps of
+// 1-2 register moves instead of 6 x ds_bpermute round trips through the LDS crossbar.  The result is read from lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_none(uint32_t v) {               // lanes the control gives no source keep kNone (the identity of min)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)kNone, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void best2_step(uint32_t &best, uint32_t &second) {
+    const uint32_t ob = dpp_or_none<CTRL, ROW_MASK>(best), os = dpp_or_none<CTRL, ROW_MASK>(second);
+    const uint32_t l2 = min(best, ob), h2 = max(best, ob);
+    second = min(min(second, os), h2);
+    best = l2;
+}
+__device__ __forceinline__ void wave_best2(uint32_t &best, uint32_t &second) {      // every source lane enters each lane's result once: no key is counted twice
+    best2_step<0x111, 0xF>(best, second);          // row_shr:1
+    best2_step<0x112, 0xF>(best, second);          // row_shr:2
+    best2_step<0x114, 0xF>(best, second);          // row_shr:4
+    best2_step<0x118, 0xF>(best, second);          // row_shr:8   -> lane 15 of a row holds the row
+    best2_step<0x142, 0xA>(best, second);          // row_bcast:15 into rows 1 and 3
+    best2_step<0x143, 0xC>(best, second);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
+    best = rl_u(best, 63); second = rl_u(second, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_or_none<0x111, 0xF>(v)); v = min(v, dpp_or_none<0x112, 0xF>(v)); v = min(v, dpp_or_none<0x114, 0xF>(v));
+    v = min(v, dpp_or_none<0x118, 0xF>(v)); v = min(v, dpp_or_none<0x142, 0xA>(v)); v = min(v, dpp_or_none<0x143, 0xC>(v));
+    return rl_u(v, 63);
+}
+
 template <bool TRIANGULATION>
 __global__ __launch_bounds__(64) void k_greedy_nodes(GreedyArgs A, GreedyScratch S) {
-    __shared__ uint32_t s_used[1024];            // consumed flags of node positions >= 64 (a node holds <= 32768 candidates)
     const int p = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
     const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
     if (a >= F1.bow.n_nodes) return;
@@ -586,40 +617,39 @@ __global__ __launch_bounds__(64) void k_greedy_nodes(GreedyArgs A, GreedyScratch
     const int s1 = F1.bow.node_start[a], e1 = F1.bow.node_start[a + 1];
     const int s2 = F2.bow.node_start[lo], n2 = F2.bow.node_start[lo + 1] - s2;
     if (n2 <= 0 || e1 <= s1) return;
+    if (n2 > 64 * kGreedyCpl) {                  // more candidates than the lanes' registers hold: onto the work list of k_greedy_big_nodes
+        if (lane == 0) { const int w = atomicAdd(&S.big[0], 1); reinterpret_cast<int4 *>(S.big + 4)[w] = make_int4(p, a, lo, 0); }
+        return;
+    }
     int32_t *own1 = S.own1 + (size_t)p * S.stride1, *own2 = S.own2 + (size_t)p * S.stride2, *hist = S.hist + 32 * p;
     int32_t *matched = A.matched[p];
     const uint4 *D1 = reinterpret_cast<const uint4 *>(F1.desc), *D2 = reinterpret_cast<const uint4 *>(F2.desc);
     bool bad = false;                            // a keypoint named twice, or an index outside the keyframe
-    if (n2 > 32768) bad = true;
-    for (int r = 64 + lane; r < n2; r += 64) {
-        const int i2 = F2.bow.kp_idx[s2 + r];
-        if ((unsigned)i2 >= (unsigned)F2.n || atomicAdd(&own2[i2], 1) != 0) bad = true;
-    }
-    // candidates 0..63 of the node: one per lane, for the whole walk
-    int i2v = lane < n2 ? F2.bow.kp_idx[s2 + lane] : -1;
-    bool t_ok = false;
-    if (lane < n2) {
-        if ((unsigned)i2v >= (unsigned)F2.n || atomicAdd(&own2[i2v], 1) != 0) bad = true;
-        else t_ok = F2.usable[i2v] != 0;
-    }
-    uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
-    float ang2v = 0.f;
-    double b2v[3] = {0, 0, 0};
-    if (t_ok) {
-        ta = D2[2 * i2v]; tb = D2[2 * i2v + 1];
-        if (A.check_orientation) ang2v = F2.angle[i2v];
-        if (TRIANGULATION) { b2v[0] = F2.bearing[3 * (size_t)i2v]; b2v[1] = F2.bearing[3 * (size_t)i2v + 1]; b2v[2] = F2.bearing[3 * (size_t)i2v + 2]; }
-    }
-    if (n2 > 64) {
-        for (int w = lane; w < (min(n2, 32768) + 31) >> 5; w += 64) s_used[w] = 0;
-        __syncthreads();
+    // the node's candidates: position 64 c + lane in slot c of this lane, for the whole walk; bit c of `free` = usable and not consumed yet
+    int i2v[kGreedyCpl];
+    uint4 ta[kGreedyCpl], tb[kGreedyCpl];
+    double b2v[kGreedyCpl][3];
+    uint32_t free = 0;
+#pragma unroll
+    for (int c = 0; c < kGreedyCpl; ++c) {
+        const int r = 64 * c + lane;
+        i2v[c] = -1; ta[c] = make_uint4(0, 0, 0, 0); tb[c] = ta[c]; b2v[c][0] = b2v[c][1] = b2v[c][2] = 0;
+        if (64 * c >= n2) continue;              // uniform: small nodes pay for one slot
+        if (r < n2) {
+            i2v[c] = F2.bow.kp_idx[s2 + r];
+            if ((unsigned)i2v[c] >= (unsigned)F2.n || atomicAdd(&own2[i2v[c]], 1) != 0) bad = true;
+            else if (F2.usable[i2v[c]]) {
+                free |= 1u << c;
+                ta[c] = D2[2 * i2v[c]]; tb[c] = D2[2 * i2v[c] + 1];
+                if (TRIANGULATION) { b2v[c][0] = F2.bearing[3 * (size_t)i2v[c]]; b2v[c][1] = F2.bearing[3 * (size_t)i2v[c] + 1]; b2v[c][2] = F2.bearing[3 * (size_t)i2v[c] + 2]; }
+            }
+        }
     }
     double E[9];
     if (TRIANGULATION) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) E[k] = A.E12[9 * (size_t)p + k];
     }
-    bool used0 = false;
     int num = 0;
     for (int q0 = s1; q0 < e1 && !__any(bad); q0 += 64) {
         const int i1v = q0 + lane < e1 ? F1.bow.kp_idx[q0 + lane] : -1;
@@ -629,11 +659,10 @@ __global__ __launch_bounds__(64) void k_greedy_nodes(GreedyArgs A, GreedyScratch
             else q_ok = F1.usable[i1v] != 0;
         }
         uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-        float ang1v = 0.f, sc1v = 0.f;
+        float sc1v = 0.f;
         double b1v[3] = {0, 0, 0};
         if (q_ok) {
             qa = D1[2 * i1v]; qb = D1[2 * i1v + 1];
-            if (A.check_orientation) ang1v = F1.angle[i1v];
             if (TRIANGULATION) {
                 b1v[0] = F1.bearing[3 * (size_t)i1v]; b1v[1] = F1.bearing[3 * (size_t)i1v + 1]; b1v[2] = F1.bearing[3 * (size_t)i1v + 2];
                 sc1v = A.scale_factors[F1.octave[i1v]];
@@ -649,37 +678,20 @@ __global__ __launch_bounds__(64) void k_greedy_nodes(GreedyArgs A, GreedyScratch
             float sc1 = 0.f;
             if (TRIANGULATION) { b1[0] = rl_d(b1v[0], k); b1[1] = rl_d(b1v[1], k); b1[2] = rl_d(b1v[2], k); sc1 = rl_f(sc1v, k); }
             uint32_t best = kNone, second = kNone;
-            auto score = [&](uint32_t pos, const uint4 &da, const uint4 &db, const double *bb) {
-                const uint32_t d = hamming8(qr, da, db);
+#pragma unroll
+            for (int c = 0; c < kGreedyCpl; ++c) {
+                if (64 * c >= n2) continue;
+                if (!((free >> c) & 1u)) continue;
+                const uint32_t d = hamming8(qr, ta[c], tb[c]), pos = (uint32_t)(64 * c + lane);
                 if (TRIANGULATION) {
-                    if (d > MS_HAMMING_THR_LOW) return;                                           // :231
-                    if (!epipolar_ok(b1, bb, E, sc1, A.residual_deg_thr)) return;                 // :237-239
+                    if (d > MS_HAMMING_THR_LOW) continue;                                         // :231
+                    if (!epipolar_ok(b1, b2v[c], E, sc1, A.residual_deg_thr)) continue;           // :237-239
                     best = min(best, (d << 20) | (0xFFFFFu - pos));                               // ties: LAST wins
                 } else {
                     best2_push(best, second, (d << 20) | pos);                                    // ties: FIRST wins
                 }
-            };
-            if (t_ok && !used0) score((uint32_t)lane, ta, tb, b2v);
-            for (int r0 = 64; r0 < n2; r0 += 64) {
-                const int r = r0 + lane;
-                if (r >= n2) continue;
-                const int i2 = F2.bow.kp_idx[s2 + r];
-                if (!F2.usable[i2] || ((s_used[r >> 5] >> (r & 31)) & 1u)) continue;
-                double bb[3] = {0, 0, 0};
-                if (TRIANGULATION) { bb[0] = F2.bearing[3 * (size_t)i2]; bb[1] = F2.bearing[3 * (size_t)i2 + 1]; bb[2] = F2.bearing[3 * (size_t)i2 + 2]; }
-                score((uint32_t)r, D2[2 * i2], D2[2 * i2 + 1], bb);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t ob = __shfl_xor(best, off, 64);
-                if (TRIANGULATION) best = min(best, ob);
-                else {
-                    const uint32_t os = __shfl_xor(second, off, 64);
-                    const uint32_t l2 = min(best, ob), h2 = max(best, ob);
-                    second = min(min(second, os), h2);
-                    best = l2;
-                }
-            }
+            if (TRIANGULATION) best = wave_min_u32(best); else wave_best2(best, second);
             if (best == kNone) continue;
             const uint32_t bd = best >> 20;
             const uint32_t pos = TRIANGULATION ? 0xFFFFFu - (best & 0xFFFFFu) : (best & 0xFFFFFu);
@@ -689,54 +701,218 @@ __global__ __launch_bounds__(64) void k_greedy_nodes(GreedyArgs A, GreedyScratch
                 if (__fmul_rn(A.lowe_ratio, (float)sd) < (float)bd) continue;                     // :120
             }
             const int i1 = (int)rl_u((uint32_t)i1v, k);
-            const int bi = pos < 64 ? (int)rl_u((uint32_t)i2v, (int)pos) : F2.bow.kp_idx[s2 + (int)pos];
+            const int pc = (int)(pos >> 6), pl = (int)(pos & 63u);
+            int bi = 0;
+#pragma unroll
+            for (int c = 0; c < kGreedyCpl; ++c) if (c == pc) bi = (int)rl_u((uint32_t)i2v[c], pl);
             if (lane == 0) matched[i1] = bi;                                                      // :126 / :250
-            if (pos < 64) { if (lane == (int)pos) used0 = true; }                                 // :128 / :249
-            else {
-                if (lane == 0) s_used[pos >> 5] |= 1u << (pos & 31);
-                __syncthreads();
-            }
+            if (lane == pl) free &= ~(1u << pc);                                                  // :128 / :249
             ++num;
-            if (A.check_orientation) {
-                const float a1 = rl_f(ang1v, k), a2 = pos < 64 ? rl_f(ang2v, (int)pos) : F2.angle[bi];
-                const int bin = angle_bin(a1, a2);
-                if (lane == 0) atomicAdd(&hist[bin], 1);
-            }
         }
     }
     if (__any(bad)) { if (lane == 0) hist[31] = 1; return; }
     if (lane == 0 && num) atomicAdd(&hist[30], num);
 }
 
+// Nodes with more than 256 candidates (coarse vocabularies; one node = plain brute force): a 256-thread workgroup per node.  The candidates'
+// descriptors and keypoint indices are staged in LDS once (the first kBigCap of them; a longer list is read from memory behind that), every
+// thread owns the candidates at positions tid, tid + 256, ... and keeps their "consumed" flags in registers (a candidate without the usable flag
+// starts consumed).  Queries are staged 64 at a time; for each one the four waves score their candidates, reduce (best, second) per wave, meet
+// once (one barrier per query, the partial results double-buffered) and every thread merges the four partials to the same decision.
+constexpr int kBigCap = 2048;
+template <bool TRIANGULATION>
+__global__ __launch_bounds__(256) void k_greedy_big_nodes(GreedyArgs A, GreedyScratch S) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_big[];
+    uint4 *s_cd = reinterpret_cast<uint4 *>(s_big);                            // [kBigCap][2] candidate descriptors
+    int32_t *s_ci = reinterpret_cast<int32_t *>(s_cd + 2 * kBigCap);           // [kBigCap] keypoint index of the candidate
+    uint4 *s_q = reinterpret_cast<uint4 *>(s_ci + kBigCap);                    // [64][2] query descriptors of the current chunk
+    double *s_qb = reinterpret_cast<double *>(s_q + 128);                      // [64][3] query bearings (M2)
+    int32_t *s_qi = reinterpret_cast<int32_t *>(s_qb + 192);                   // [64] keypoint index
+    float *s_qs = reinterpret_cast<float *>(s_qi + 64);                        // [64] scale factor of the query's octave (M2)
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(s_qs + 64);                // [2][4][2] per-wave (best, second), double-buffered
+    __shared__ unsigned long long s_qmask;
+    __shared__ int s_bad, s_work;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (;;) {                                                                   // work list: every workgroup leaves once the cursor has passed the count
+    __syncthreads();
+    if (tid == 0) s_work = atomicAdd(&S.big[1], 1);
+    __syncthreads();
+    if (s_work >= S.big[0]) return;
+    const int4 item = reinterpret_cast<const int4 *>(S.big + 4)[s_work];
+    const int p = item.x, a = item.y, lo = item.z;
+    const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
+    const int s1 = F1.bow.node_start[a], e1 = F1.bow.node_start[a + 1];
+    const int s2 = F2.bow.node_start[lo], n2 = F2.bow.node_start[lo + 1] - s2;
+    int32_t *own1 = S.own1 + (size_t)p * S.stride1, *own2 = S.own2 + (size_t)p * S.stride2, *hist = S.hist + 32 * p;
+    int32_t *matched = A.matched[p];
+    const uint4 *D1 = reinterpret_cast<const uint4 *>(F1.desc), *D2 = reinterpret_cast<const uint4 *>(F2.desc);
+    if (tid == 0) s_bad = n2 > 32768 ? 1 : 0;
+    __syncthreads();
+    // stage the candidates; this thread's consumed flags: bit j of used[j >> 6] <-> position tid + 256 j
+    unsigned long long used0 = 0, used1 = 0;                                   // (two scalars: an indexed pair would live in scratch memory)
+    for (int r = tid, j = 0; r < min(n2, 32768); r += 256, ++j) {
+        const int i2 = F2.bow.kp_idx[s2 + r];
+        bool ok = true;
+        if ((unsigned)i2 >= (unsigned)F2.n || atomicAdd(&own2[i2], 1) != 0) { s_bad = 1; ok = false; }
+        else ok = F2.usable[i2] != 0;
+        if (!ok) { if (j < 64) used0 |= 1ull << j; else used1 |= 1ull << (j - 64); }
+        if (r < kBigCap) {
+            s_ci[r] = i2;
+            if (ok) { s_cd[2 * r] = D2[2 * i2]; s_cd[2 * r + 1] = D2[2 * i2 + 1]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kBigCap / 256; ++j) if (tid + 256 * j >= n2) used0 |= 1ull << j;      // slots behind the end of the list are never free
+    double E[9];
+    if (TRIANGULATION) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = A.E12[9 * (size_t)p + k];
+    }
+    __syncthreads();
+    int num = 0, it = 0;
+    for (int q0 = s1; q0 < e1 && !s_bad; q0 += 64) {
+        __syncthreads();                                                       // the previous chunk's queries are no longer read
+        if (wave == 0) {                                                       // stage up to 64 queries
+            const int i1 = q0 + lane < e1 ? F1.bow.kp_idx[q0 + lane] : -1;
+            bool q_ok = false;
+            if (q0 + lane < e1) {
+                if ((unsigned)i1 >= (unsigned)F1.n || atomicAdd(&own1[i1], 1) != 0) s_bad = 1;
+                else q_ok = F1.usable[i1] != 0;
+            }
+            if (q_ok) {
+                s_q[2 * lane] = D1[2 * i1]; s_q[2 * lane + 1] = D1[2 * i1 + 1];
+                s_qi[lane] = i1;
+                if (TRIANGULATION) {
+                    s_qb[3 * lane] = F1.bearing[3 * (size_t)i1]; s_qb[3 * lane + 1] = F1.bearing[3 * (size_t)i1 + 1]; s_qb[3 * lane + 2] = F1.bearing[3 * (size_t)i1 + 2];
+                    s_qs[lane] = A.scale_factors[F1.octave[i1]];
+                }
+            }
+            const unsigned long long m = __ballot(q_ok);
+            if (lane == 0) s_qmask = m;
+        }
+        __syncthreads();
+        if (s_bad) break;
+        unsigned long long qmask = s_qmask;
+        while (qmask) {
+            const int k = __builtin_ctzll(qmask);
+            qmask &= qmask - 1;
+            const uint4 qa = s_q[2 * k], qb = s_q[2 * k + 1];
+            const uint32_t qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            double b1[3] = {0, 0, 0};
+            float sc1 = 0.f;
+            if (TRIANGULATION) { b1[0] = s_qb[3 * k]; b1[1] = s_qb[3 * k + 1]; b1[2] = s_qb[3 * k + 2]; sc1 = s_qs[k]; }
+            uint32_t best = kNone, second = kNone;
+            auto score = [&](int r, int i2, const uint4 &da, const uint4 &db) {
+                const uint32_t d = hamming8(qr, da, db);
+                if (TRIANGULATION) {
+                    if (d > MS_HAMMING_THR_LOW) return;                                             // :231
+                    if (i2 < 0) i2 = s_ci[r];
+                    const double bb[3] = {F2.bearing[3 * (size_t)i2], F2.bearing[3 * (size_t)i2 + 1], F2.bearing[3 * (size_t)i2 + 2]};
+                    if (!epipolar_ok(b1, bb, E, sc1, A.residual_deg_thr)) return;                   // :237-239
+                    best = min(best, (d << 20) | (0xFFFFFu - (uint32_t)r));                         // ties: LAST wins
+                } else {
+                    best2_push(best, second, (d << 20) | (uint32_t)r);                              // ties: FIRST wins
+                }
+            };
+            {   // the staged candidates: all of this thread's LDS reads are issued before the first distance (fixed trip count, free slots only)
+                const uint32_t lowfree = ~(uint32_t)used0;
+                uint4 da[kBigCap / 256], db[kBigCap / 256];
+#pragma unroll
+                for (int j = 0; j < kBigCap / 256; ++j)
+                    if ((lowfree >> j) & 1u) { da[j] = s_cd[2 * (tid + 256 * j)]; db[j] = s_cd[2 * (tid + 256 * j) + 1]; }
+#pragma unroll
+                for (int j = 0; j < kBigCap / 256; ++j)
+                    if ((lowfree >> j) & 1u) score(tid + 256 * j, -1, da[j], db[j]);
+            }
+            for (int r = tid + kBigCap, j = kBigCap / 256; r < n2; r += 256, ++j) {                 // a list longer than the LDS holds: from memory
+                if (((j < 64 ? used0 : used1) >> (j & 63)) & 1ull) continue;
+                const int i2 = F2.bow.kp_idx[s2 + r];
+                score(r, i2, D2[2 * i2], D2[2 * i2 + 1]);
+            }
+            if (TRIANGULATION) best = wave_min_u32(best); else wave_best2(best, second);
+            uint32_t *part = s_part + 8 * (it & 1);
+            ++it;
+            if (lane == 0) { part[2 * wave] = best; part[2 * wave + 1] = second; }
+            __syncthreads();
+            best = part[0]; second = part[1];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const uint32_t ob = part[2 * w], os = part[2 * w + 1];
+                const uint32_t l2 = min(best, ob), h2 = max(best, ob);
+                second = min(min(second, os), h2);
+                best = l2;
+            }
+            if (best == kNone) continue;
+            const uint32_t bd = best >> 20;
+            const uint32_t pos = TRIANGULATION ? 0xFFFFFu - (best & 0xFFFFFu) : (best & 0xFFFFFu);
+            if (!TRIANGULATION) {
+                const uint32_t sd = second == kNone ? (uint32_t)MS_HAMMING_MAX : second >> 20;
+                if (MS_HAMMING_THR_LOW < bd) continue;                                              // :115
+                if (__fmul_rn(A.lowe_ratio, (float)sd) < (float)bd) continue;                       // :120
+            }
+            if ((int)(pos & 255u) == tid) { const int j = (int)(pos >> 8); if (j < 64) used0 |= 1ull << j; else used1 |= 1ull << (j - 64); }   // :128 / :249
+            ++num;
+            if (tid == 0) matched[s_qi[k]] = pos < (uint32_t)kBigCap ? s_ci[pos] : F2.bow.kp_idx[s2 + (int)pos];    // :126 / :250
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { if (s_bad) hist[31] = 1; else if (num) atomicAdd(&hist[30], num); }
+  }
+}
+constexpr size_t kBigLds = sizeof(uint4) * 2 * kBigCap + 4 * kBigCap + sizeof(uint4) * 128 + sizeof(double) * 192 + 4 * 64 * 2 + 4 * 16;     // 76 KB: two workgroups per CU
+
 __global__ __launch_bounds__(256) void k_greedy_finish(GreedyArgs A, GreedyScratch S) {
-    __shared__ int s_removed;
+    // rotation consistency (match_angle_checker.h:60-134) over the pair's matches: the histogram is built here, from the matches the node passes left
+    // (the bins do not depend on the order the matches were found in), then everything outside the three fullest bins is un-matched (:149-155 / :272-277)
+    __shared__ int s_hist[30], s_removed;
     const int p = blockIdx.x, tid = threadIdx.x;
-    const int32_t *hist = S.hist + 32 * p;
-    if (hist[31]) return;                                                     // the sequential kernel redoes this pair
+    const int32_t *cnt = S.hist + 32 * p;
+    if (cnt[31]) return;                                                      // the sequential kernel redoes this pair
     const ms_match_frame F1 = A.f1[p], F2 = A.f2[p];
     int32_t *matched = A.matched[p];
+    if (tid < 30) s_hist[tid] = 0;
     if (tid == 0) s_removed = 0;
     __syncthreads();
     if (A.check_orientation) {
+        int8_t bins[8];                                                       // this thread's first 8 matches keep their bin; beyond (n1 > 2048) it is recomputed
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bins[j] = -1;
+        for (int i = tid, j = 0; i < F1.n; i += 256, ++j) {
+            const int m = matched[i];
+            if (m < 0) continue;
+            const int bin = angle_bin(F1.angle[i], F2.angle[m]);
+            atomicAdd(&s_hist[bin], 1);
+            if (j < 8) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) if (jj == j) bins[jj] = (int8_t)bin;
+            }
+        }
+        __syncthreads();
         int v0 = -1, v1 = -1, v2 = -1;                                        // top-3 bins by (size desc, bin asc), match_angle_checker.h:108-134
         for (int rep = 0; rep < 3; ++rep) {
             int bb = -1, bc = -1;
             for (int k = 0; k < 30; ++k)
-                if (k != v0 && k != v1 && hist[k] > bc) { bc = hist[k]; bb = k; }
+                if (k != v0 && k != v1 && s_hist[k] > bc) { bc = s_hist[k]; bb = k; }
             if (rep == 0) v0 = bb; else if (rep == 1) v1 = bb; else v2 = bb;
         }
         int removed = 0;
-        for (int i = tid; i < F1.n; i += 256) {
-            const int m = matched[i];
-            if (m >= 0) {
-                const int bin = angle_bin(F1.angle[i], F2.angle[m]);
-                if (bin != v0 && bin != v1 && bin != v2) { matched[i] = -1; ++removed; }
+        for (int i = tid, j = 0; i < F1.n; i += 256, ++j) {
+            int bin = -1;
+            if (j < 8) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) if (jj == j) bin = bins[jj];
+                if (bin < 0) continue;
+            } else {
+                const int m = matched[i];
+                if (m < 0) continue;
+                bin = angle_bin(F1.angle[i], F2.angle[m]);
             }
+            if (bin != v0 && bin != v1 && bin != v2) { matched[i] = -1; ++removed; }
         }
         if (removed) atomicAdd(&s_removed, removed);
         __syncthreads();
     }
-    if (tid == 0) A.n_matches[p] = hist[30] - s_removed;
+    if (tid == 0) A.n_matches[p] = cnt[30] - s_removed;
 }
 
 }  // namespace
@@ -900,9 +1076,10 @@ static int launch_greedy(ms_ctx *c, bool tri, const ms_match_frame *p1, const ms
     const size_t fb = sizeof(ms_match_frame) * (size_t)n_pairs, mb = sizeof(int32_t *) * (size_t)n_pairs;
     const size_t tab = ms_align_up(2 * fb + mb, 256), hb = ms_align_up(sizeof(int32_t) * 32 * (size_t)n_pairs, 256);
     const size_t o1 = ms_align_up(sizeof(int32_t) * (size_t)n_pairs * std::max(max_n1, 1), 256), o2 = ms_align_up(sizeof(int32_t) * (size_t)n_pairs * std::max(max_n2, 1), 256);
-    const bool node_parallel = c->greedy_path == 0;
+    const bool node_parallel = c->greedy_path != 1;
+    const size_t bl = ms_align_up(16 * ((size_t)n_pairs * std::max(max_nodes, 1) + 1), 256);
     void *scr = nullptr;
-    int rc = ms_scratch(c, tab + (node_parallel ? hb + o1 + o2 : 0), &scr);
+    int rc = ms_scratch(c, tab + (node_parallel ? hb + o1 + o2 + bl : 0), &scr);
     if (rc != MS_OK) return rc;
     char *base = static_cast<char *>(scr);
     std::vector<char> host(2 * fb + mb);
@@ -919,11 +1096,25 @@ static int launch_greedy(ms_ctx *c, bool tri, const ms_match_frame *p1, const ms
         S.hist = reinterpret_cast<int32_t *>(base + tab);
         S.own1 = reinterpret_cast<int32_t *>(base + tab + hb);
         S.own2 = reinterpret_cast<int32_t *>(base + tab + hb + o1);
+        S.big = reinterpret_cast<int32_t *>(base + tab + hb + o1 + o2);
         S.stride1 = std::max(max_n1, 1); S.stride2 = std::max(max_n2, 1);
         hipLaunchKernelGGL(k_greedy_init, dim3(std::max(ms_div_up(std::max(max_n1, max_n2), 256), 1), n_pairs), dim3(256), 0, c->stream, A, S);
         if (max_nodes > 0) {
             if (tri) hipLaunchKernelGGL(k_greedy_nodes<true>, dim3(max_nodes, n_pairs), dim3(64), 0, c->stream, A, S);
             else hipLaunchKernelGGL(k_greedy_nodes<false>, dim3(max_nodes, n_pairs), dim3(64), 0, c->stream, A, S);
+            // a node can only hold more than 256 of kf2's keypoints if kf2 has that many
+            if (max_n2 > 64 * kGreedyCpl) {
+                bool *attr_done = c->greedy_attr_done;
+                if (!attr_done[tri]) {
+                    if (tri) MS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy_big_nodes<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLds));
+                    else MS_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy_big_nodes<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLds));
+                    attr_done[tri] = true;
+                }
+                // as many workgroups as are resident at once (two per CU at 76 KB of LDS each); they share the work list, and all leave at once when it is empty
+                const int wgs = c->greedy_path == 2 ? 1 : (int)std::min<size_t>((size_t)n_pairs * max_nodes, (size_t)std::max(c->n_cu, 1) * 2);
+                if (tri) hipLaunchKernelGGL(k_greedy_big_nodes<true>, dim3(wgs), dim3(256), kBigLds, c->stream, A, S);
+                else hipLaunchKernelGGL(k_greedy_big_nodes<false>, dim3(wgs), dim3(256), kBigLds, c->stream, A, S);
+            }
         }
         hipLaunchKernelGGL(k_greedy_finish, dim3(n_pairs), dim3(256), 0, c->stream, A, S);
         A.redo = S.hist;                                   // pairs the node pass gave up (a keypoint in two shared nodes): exact sequential walk
@@ -935,7 +1126,7 @@ static int launch_greedy(ms_ctx *c, bool tri, const ms_match_frame *p1, const ms
 }
 
 int ms_match_set_path(ms_ctx *c, int path) {
-    if (!c || path < 0 || path > 1) return MS_ERR_INVALID;
+    if (!c || path < 0 || path > 2) return MS_ERR_INVALID;
     c->greedy_path = path;
     return MS_OK;
 }

@@ -17,6 +17,7 @@ struct ms_ctx {
     void *scratch = nullptr;      // growable device scratch for small per-call argument tables
     size_t scratch_bytes = 0;
     int hamming_path = 0;         // 0 = automatic (matrix-core kernel for unmasked searches), 1 = popcount kernel for everything (ms_hamming_set_path)
+    bool greedy_attr_done[2] = {false, false};   // dynamic-LDS attribute of k_greedy_big_nodes<false/true> set on this context's device
     int greedy_path = 0;          // 0 = node-parallel greedy matchers (sequential redo of pairs that need it), 1 = one wave per pair, sequential (ms_match_set_path)
     // device blocks of destroyed bundle-adjustment handles, kept for the next ms_ba_create on this context: a window per keyframe then allocates nothing after
     // warm-up (hipFree synchronises the whole device -- with one sequence per context that stalled every other sequence's stream once per keyframe)

@@ -111,15 +111,17 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
     std::vector<std::uint8_t> fixed(w.poses.size(), 1);
     fixed[w.currentKeyframe] = 0;
     ms_ba_problem p1 = detail::as_problem(w, fixed, nullptr, iterations);
-    ctx.check(ms_ba_solve_host(ctx.get(), &p1, w.poses[0].data(), w.points.empty() ? nullptr : w.points[0].data(), chi2.data(), &out.stage1), "ms_ba_solve_host");
-    out.ran = true;
     if (!neighbourhoodStage) {                                                 // "Skip neighbordhood BA" (:326-332)
+        ctx.check(ms_ba_solve_host(ctx.get(), &p1, w.poses[0].data(), w.points.empty() ? nullptr : w.points[0].data(), chi2.data(), &out.stage1), "ms_ba_solve_host");
+        out.ran = true;
         if (workspace) workspace->baStats.update(BaStats::Ba::NEIGHBOR);
         return out;
     }
-    // stage 2: unfix every keyframe (:335-337); soft orientation prior against the stage-1 pose (:341-370)
+    // stage 2: unfix every keyframe (:335-337); soft orientation prior against the stage-1 pose (:341-370).  Its graph differs from stage 1's only in
+    // the fixed flags, one more (fixed) vertex and one more edge, none of which depends on stage 1's result: both handles are built up front and the
+    // stage-1 state moves to stage 2 on the device (ms_ba_copy_state) -- one download per window instead of two downloads and an upload
     BaWindow w2 = w;
-    w2.poses.push_back(w.poses[w.currentKeyframe]);                            // conv.custom(0): fixed copy of the just-optimised pose
+    w2.poses.push_back(w.poses[w.currentKeyframe]);                            // conv.custom(0): fixed copy of the just-optimised pose (value set on the device)
     std::vector<std::uint8_t> fixed2(w2.poses.size(), 0);
     fixed2.back() = 1;
     const double r = 100 * parameters.odometryPriorStrengthRotation;          // :364
@@ -130,7 +132,16 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
     w2.edgeMeas.push_back({0, 0, 0, 1, 0, 0, 0});                              // identity measurement (:357)
     w2.edgeInfo.push_back(info);
     ms_ba_problem p2 = detail::as_problem(w2, fixed2, nullptr, iterations);
-    ctx.check(ms_ba_solve_host(ctx.get(), &p2, w2.poses[0].data(), w2.points.empty() ? nullptr : w2.points[0].data(), chi2.data(), &out.stage2), "ms_ba_solve_host");
+    struct Handle { ms_ba *h = nullptr; ~Handle() { ms_ba_destroy(h); } } b1, b2;
+    ctx.check(ms_ba_create(ctx.get(), &p1, 1, &b1.h), "ms_ba_create");
+    ctx.check(ms_ba_create(ctx.get(), &p2, 1, &b2.h), "ms_ba_create");
+    ctx.check(ms_ba_solve(b1.h), "ms_ba_solve");
+    const std::int32_t cur = w.currentKeyframe;
+    ctx.check(ms_ba_copy_state(b2.h, b1.h, &cur), "ms_ba_copy_state");
+    ctx.check(ms_ba_solve(b2.h), "ms_ba_solve");
+    ctx.check(ms_ba_download(b1.h, 0, nullptr, nullptr, nullptr, &out.stage1), "ms_ba_download");      // a failed stage 1 stops here, the window untouched
+    out.ran = true;
+    ctx.check(ms_ba_download(b2.h, 0, w2.poses[0].data(), w2.points.empty() ? nullptr : w2.points[0].data(), chi2.data(), &out.stage2), "ms_ba_download");
     for (std::size_t i = 0; i < w.poses.size(); ++i) w.poses[i] = w2.poses[i];    // applyBundleAdjustResults (:114-137)
     w.points = w2.points;
     out.outlier.resize(chi2.size());

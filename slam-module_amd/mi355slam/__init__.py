@@ -579,6 +579,11 @@ class BundleAdjuster:
     def solve(self):
         self.ctx.check(lib().ms_ba_solve(self._h), "ms_ba_solve")
 
+    def copy_state_from(self, src, extra_pose_src=None):
+        """The state src's last solve left becomes this handle's initial state (ms_ba_copy_state)."""
+        ex = None if extra_pose_src is None else np.ascontiguousarray(extra_pose_src, np.int32)
+        self.ctx.check(lib().ms_ba_copy_state(self._h, src._h, _vp(ex)), "ms_ba_copy_state")
+
     def team_fallbacks(self):
         return lib().ms_ba_team_fallbacks(self._h)
 

@@ -75,10 +75,10 @@ def test_bench_and_tools_touch_the_oracle_only_as_the_cpu_baseline():
     assert body.index("import mso") < body.index("def host_cores")                   # the one import sits inside _oracle()
     callers = [ln for ln in src.splitlines() if "_oracle()" in ln and "def " not in ln]
     assert callers and all("mso = _oracle()" in ln for ln in callers)
-    for fn in ("cpu_baseline_frames", "cpu_baseline_ba", "cpu_baseline_greedy"):
+    for fn in ("cpu_baseline_frames", "cpu_baseline_ba", "cpu_baseline_greedy", "cpu_baseline_c3"):
         seg = src[src.index("def %s(" % fn):]
         assert "_oracle()" in seg[:seg.index("\ndef ", 5)]
-    assert len(callers) == 3
+    assert len(callers) == 4
     for rel in ("tools/synth.py", "tests/ba_synth.py"):
         txt = open(os.path.join(ROOT, rel)).read()
         assert "import mso" not in txt and "libmso" not in txt

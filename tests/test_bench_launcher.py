@@ -64,3 +64,58 @@ def test_parent_imports_no_gpu_library():
     assert "import torch" not in head and "import mi355slam" not in head
     body = src[src.index("def launch("):src.index("# ------------------------------------------------------------------------------------------------------------------ CPU baseline")]
     assert "import torch" not in body and "import mi355slam" not in body and "os.exec" not in src
+
+
+def _long_launcher(*extra):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        e.pop(k, None)
+    # 30000 steps of 2-4 ms: the ranks would run for a minute or two if nothing stopped them
+    return subprocess.Popen([sys.executable, BENCH, "--plumbing", "--gpus", "2", "--steps", "30000", "--warmup", "0", *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+
+
+def _ranks_of(launcher, wait_s=60):
+    import time
+    import psutil
+    t_end = time.time() + wait_s
+    while time.time() < t_end:
+        kids = [c for c in psutil.Process(launcher.pid).children(recursive=True)]
+        if len(kids) >= 2:
+            return kids
+        time.sleep(0.1)
+    return []
+
+
+def _all_gone(procs, wait_s=40):
+    import psutil
+    gone, alive = psutil.wait_procs(procs, timeout=wait_s)
+    return not alive
+
+
+def test_launcher_deadline_stops_every_rank():
+    """a launcher that is past its wall-clock limit ends its ranks (own sessions, TERM then KILL) and says why."""
+    p = _long_launcher("--launcher-timeout", "4")
+    kids = _ranks_of(p)
+    assert len(kids) >= 2
+    out, err = p.communicate(timeout=120)
+    assert p.returncode != 0 and "deadline" in err and not [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert _all_gone(kids)
+
+
+def test_launcher_killed_or_terminated_takes_its_ranks_along():
+    import signal
+    import time
+    p = _long_launcher()
+    kids = _ranks_of(p)
+    assert len(kids) >= 2
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)                  # handled: ranks are stopped, exit code non-zero, the reason is printed
+    out, err = p.communicate(timeout=120)
+    assert p.returncode != 0 and "signal" in err
+    assert _all_gone(kids)
+    p = _long_launcher()
+    kids = _ranks_of(p)
+    assert len(kids) >= 2
+    p.kill()                                       # not handled by anything: PR_SET_PDEATHSIG ends the ranks
+    p.wait()
+    assert _all_gone(kids)

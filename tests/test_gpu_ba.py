@@ -75,6 +75,21 @@ def test_reference_two_stage_schedule(oracle, ctx):
     # the prior held the current keyframe's orientation (softly)
     dq = np.abs(np.abs(g2["pose"][cur, :4] @ g1["pose"][cur, :4]) - 1)
     assert dq < 1e-6
+    # the same schedule chained on the device (ms_ba_copy_state): the stage-2 handle is built from the INITIAL window (its values are
+    # placeholders), takes stage 1's state and the fixed copy of the current keyframe's pose on the device, and ends where the
+    # download / re-create route ended
+    s2c = stage2(dict(pose=p["pose"], point=p["point"]))
+    ba3 = mi355slam.BundleAdjuster(ctx, [s2c], max_iters=iters)
+    ba.solve(); ba3.copy_state_from(ba, [cur]); ba3.solve()
+    g3 = ba3.download(0)
+    _check(s2w, g3, w2)
+    assert np.abs(g3["pose"] - g2["pose"]).max() < 1e-9 and np.abs(g3["point"] - g2["point"]).max() < 1e-9
+    g1b = ba.download(0)                                              # stage 1 as it ran this time (its atomic sums differ in the last bits from run to run)
+    assert np.array_equal(g3["pose"][12], g1b["pose"][cur])           # the fixed extra vertex is that run's stage-1 pose, bit for bit
+    with pytest.raises(mi355slam.MsError):
+        ba3.copy_state_from(ba, None)                                   # one pose more than the source and nothing to fill it from
+    with pytest.raises(mi355slam.MsError):
+        ba.copy_state_from(ba3, None)                                   # fewer poses than the source
 
 
 def test_pose_only_and_fixed_points(oracle, ctx):

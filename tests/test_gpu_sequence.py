@@ -17,7 +17,7 @@ def test_eight_frame_sequence_matches_oracle(oracle):
     F = 8
     g = synth.SequenceSynth(bench.W, bench.H, 2003, 2 * (F - 1), F - 1)
     frames = np.stack([g.frame(2 * i, i) for i in range(F)])
-    windows = [ba_synth.make_problem_fast(20, 500, 8, seed=70 + k) for k in range(2)]
+    windows = [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + k) for k in range(2)]      # C4 windows, the ones bench_c5 solves
     ocfg = oracle.cfg(levels=bench.LEVELS, scale_factor=bench.SCALE, max_kpts=bench.MAX_KPTS, fast_threshold=bench.FAST_THR)
     want_kp = [oracle.orb_extract(ocfg, frames[i]) for i in range(F)]
     seen = {"frames": 0, "ba": 0, "matches": 0}
@@ -68,14 +68,14 @@ def test_native_driver_counts_what_the_python_driver_counts():
     import synth
     lib = bench._c5_native_lib()
     assert lib is not None, "slam-module_amd/lib/libc5native.so is missing (make -C slam-module_amd/csrc)"
-    F, S = 6, 2
+    F, S, TOTAL = 6, 2, 9                  # 9 frames over 6 images: 0 1 2 3 4 5 4 3 2 (both drivers walk back)
     seqs = []
     for s in range(S):
         g = synth.SequenceSynth(bench.W, bench.H, 2100 + s, 2 * (F - 1), F - 1)
         seqs.append(np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(F)])))
     windows = [ba_synth.make_problem_fast(20, 500, 8, seed=80 + k) for k in range(2)]
     start = threading.Event(); start.set()
-    runners = [bench.SequenceRunner(0, s, seqs[s], windows, 5, start) for s in range(S)]
+    runners = [bench.SequenceRunner(0, s, seqs[s], windows, 5, start, n_total=TOTAL) for s in range(S)]
     for r in runners:
         r.start()
     for r in runners:
@@ -86,7 +86,7 @@ def test_native_driver_counts_what_the_python_driver_counts():
     warr = (mi355slam.BaProblemC * len(structs))(*structs)
     fptr = (C.c_void_p * S)(*[f.ctypes.data for f in seqs])
     lib.c5_prepare.restype = C.c_void_p
-    job = lib.c5_prepare(0, S, F, bench.W, bench.H, fptr, warr, len(structs), 5, bench.LEVELS, C.c_float(bench.SCALE), bench.MAX_KPTS, bench.FAST_THR, C.c_float(bench.LOWE_RATIO))
+    job = lib.c5_prepare(0, S, TOTAL, F, bench.W, bench.H, fptr, warr, len(structs), 5, bench.LEVELS, C.c_float(bench.SCALE), bench.MAX_KPTS, bench.FAST_THR, C.c_float(bench.LOWE_RATIO))
     assert job
     secs, seq_s = C.c_double(), (C.c_double * S)()
     fd, bd, lm = (C.c_int32 * S)(), (C.c_int32 * S)(), (C.c_int32 * S)()
@@ -94,6 +94,6 @@ def test_native_driver_counts_what_the_python_driver_counts():
     rc = lib.c5_go(C.c_void_p(job), C.byref(secs), seq_s, fd, bd, lm, err, 512)
     assert rc == 0, err.value
     del keep
-    assert list(fd) == [r.frames_done for r in runners] == [F] * S
+    assert list(fd) == [r.frames_done for r in runners] == [TOTAL] * S
     assert list(bd) == [r.ba_done for r in runners] == [2] * S
     assert list(lm) == [r.matches for r in runners] and min(lm) > 500

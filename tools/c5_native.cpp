@@ -31,7 +31,7 @@ struct Seq {
         if (rc_ != MS_OK) { out.status = rc_; std::snprintf(out.err, sizeof(out.err), "%s: %s", #call, ctx ? ms_last_error(ctx) : "no context"); goto done; } \
     } while (0)
 
-void run_sequence(int device, const uint8_t *frames_host, int n_frames, int W, int H, const ms_ba_problem *windows, int n_windows, int kf_every,
+void run_sequence(int device, const uint8_t *frames_host, int n_frames, int n_distinct, int W, int H, const ms_ba_problem *windows, int n_windows, int kf_every,
                   const ms_orb_config &cfg, float ratio, Shared &sh, int n_seq, Seq &out) {
     ms_ctx *ctx = nullptr;
     ms_orb *ex[2] = {nullptr, nullptr};
@@ -43,9 +43,11 @@ void run_sequence(int device, const uint8_t *frames_host, int n_frames, int W, i
     int cap = 0;
     const size_t fbytes = (size_t)W * H;
     bool released = false;
+    // the sequence walks its n_distinct images forwards and backwards (0, 1, .., n-1, n-2, .., 1, 0, 1, ..): consecutive frames always overlap
+    auto image_of = [&](int i) { if (n_distinct < 2) return 0; const int j = i % (2 * n_distinct - 2); return j < n_distinct ? j : 2 * n_distinct - 2 - j; };
     auto frame = [&](int i, bool count) -> int {
         ms_orb *e = ex[i & 1];
-        int rc = ms_orb_extract(e, static_cast<const uint8_t *>(d_frames) + (size_t)i * fbytes, 1, 1, fbytes, (size_t)W, nullptr, nullptr, nullptr);
+        int rc = ms_orb_extract(e, static_cast<const uint8_t *>(d_frames) + (size_t)image_of(i) * fbytes, 1, 1, fbytes, (size_t)W, nullptr, nullptr, nullptr);
         if (rc != MS_OK) return rc;
         if (!have_view[i & 1]) { rc = ms_orb_device_view(e, &view[i & 1]); if (rc != MS_OK) return rc; have_view[i & 1] = true; }
         if (i) {
@@ -71,8 +73,8 @@ void run_sequence(int device, const uint8_t *frames_host, int n_frames, int W, i
         return MS_OK;
     };
     C5_CHECK(ms_ctx_create(device, &ctx));
-    C5_CHECK(ms_dev_alloc(ctx, fbytes * n_frames, &d_frames));
-    C5_CHECK(ms_dev_upload(ctx, d_frames, frames_host, fbytes * n_frames));
+    C5_CHECK(ms_dev_alloc(ctx, fbytes * n_distinct, &d_frames));
+    C5_CHECK(ms_dev_upload(ctx, d_frames, frames_host, fbytes * n_distinct));
     for (int k = 0; k < 2; ++k) C5_CHECK(ms_orb_create(ctx, &cfg, &ex[k]));
     cap = ms_orb_capacity(ex[0]);
     C5_CHECK(ms_dev_alloc(ctx, 4 * (size_t)cap + 16, &bi));
@@ -105,7 +107,7 @@ done:
 }  // namespace
 
 // c5_prepare starts the sequences' threads: each builds its context and handles, uploads its frames, runs two warm-up frames and waits.  frames: n_seq
-// pointers to n_frames * W * H bytes each (they and `windows` must stay valid until c5_go returns).  c5_go releases them together, joins them and fills
+// pointers to n_distinct * W * H bytes each (a sequence of n_frames frames walks them back and forth) (they and `windows` must stay valid until c5_go returns).  c5_go releases them together, joins them and fills
 // the per-sequence outputs (arrays of n_seq); *seconds_out = wall time from the release to the last sequence's end.  Returns MS_OK, or the first failing
 // sequence's status with its message in err (err_len bytes).  The job is freed by c5_go.
 struct C5Job {
@@ -115,16 +117,16 @@ struct C5Job {
     ms_orb_config cfg;
 };
 
-extern "C" void *c5_prepare(int device, int n_seq, int n_frames, int W, int H, const uint8_t *const *frames, const ms_ba_problem *windows, int n_windows, int kf_every,
+extern "C" void *c5_prepare(int device, int n_seq, int n_frames, int n_distinct, int W, int H, const uint8_t *const *frames, const ms_ba_problem *windows, int n_windows, int kf_every,
                             int levels, float scale_factor, int max_kpts, int fast_threshold, float lowe_ratio) {
-    if (n_seq < 1 || n_frames < 1 || !frames || kf_every < 1) return nullptr;
+    if (n_seq < 1 || n_frames < 1 || n_distinct < 1 || !frames || kf_every < 1) return nullptr;
     C5Job *J = new C5Job();
     std::memset(&J->cfg, 0, sizeof(J->cfg));
     J->cfg.width = W; J->cfg.height = H; J->cfg.levels = levels; J->cfg.scale_factor = scale_factor; J->cfg.max_kpts = max_kpts; J->cfg.lk_track_level = 0;
     J->cfg.fast_threshold = fast_threshold; J->cfg.max_tracks = 0; J->cfg.max_batch = 1; J->cfg.min_distance = 0;
     J->seqs.resize(n_seq);
     for (int s = 0; s < n_seq; ++s)
-        J->th.emplace_back(run_sequence, device, frames[s], n_frames, W, H, windows, n_windows, kf_every, std::cref(J->cfg), lowe_ratio, std::ref(J->sh), n_seq, std::ref(J->seqs[s]));
+        J->th.emplace_back(run_sequence, device, frames[s], n_frames, n_distinct, W, H, windows, n_windows, kf_every, std::cref(J->cfg), lowe_ratio, std::ref(J->sh), n_seq, std::ref(J->seqs[s]));
     while (J->sh.ready.load() < n_seq) std::this_thread::yield();
     return J;
 }
