@@ -399,9 +399,16 @@ def kernel_table(avg_ms, n_kp, w=W, h=H):
 
 
 def pmc_of(kernel):
-    """HBM bytes and instruction counts per launch from the committed PMC passes of this build (tools/profile_set.sh); None if absent."""
+    """HBM bytes and instruction counts per launch from the committed PMC passes (tools/profile_set.sh), or None: absent, or taken on OTHER kernel
+    sources than the ones in this tree (the summary carries the SHA-256 of slam-module_amd/csrc + include/; tools/build_id.py)."""
     try:
-        return json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"][kernel]
+        import build_id
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        k = d["kernels"][kernel]
+        sha = k.get("src_sha256") or d.get("src_sha256")
+        if sha != build_id.source_hash():
+            return {"stale": True}
+        return k
     except Exception:
         return None
 
@@ -450,11 +457,13 @@ def run_gpu(R, args):
     dom = max(avg_ms, key=avg_ms.get)
     achieved = alg[dom] * BATCH / (avg_ms[dom] * 1e-3) / 1e9
     pmc = pmc_of({"hamming": "k_hamming_mfma"}.get(dom, "k_" + dom))
-    traffic = pmc.get("hbm_bytes_per_step") if pmc else None
-    valu = pmc.get("SQ_INSTS_VALU_per_step") if pmc else None
+    stale = bool(pmc and pmc.get("stale"))
+    traffic = pmc.get("hbm_bytes_per_step") if pmc and not stale else None
+    valu = pmc.get("SQ_INSTS_VALU_per_step") if pmc and not stale else None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": (PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, tools/profile_set.sh; not measured in this run)") if pmc else None,
+                "traffic_source": ((PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these kernel sources, tools/profile_set.sh; not measured in this run)") if not stale
+                                   else (PMC_FILE + " was taken on other kernel sources than this tree's (src_sha256 differs): traffic withheld, re-run tools/profile_set.sh")) if pmc else None,
                 # the front-end kernels are bound by VALU issue (VOP3 / packed forms issue once per ~4 cycles per SIMD, profiles/r01_e_valu_issue_rates.txt)
                 "valu_insts": valu, "valu_issue_frac": round(valu / 1024 * 4 / 2.4e9 / (avg_ms[dom] * 1e-3), 3) if valu else None,
                 # bytes the step has in its contract NOW: the blurred pyramid is no longer written or read (k_describe blurs its own patches), so
@@ -707,8 +716,9 @@ def bench_ba(R, ctx, args):
            "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
            "new_window_ms": round(new_window_ms, 3), "dtype": "f64", "two_stage": two_stage,
            "roofline": {"kernel": "k_ba_lm", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                        "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
-                        "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes of this build over the 256-window launch, tools/pmc_ba.sh)") if pmc else None}}
+                        "traffic": pmc.get("hbm_bytes_per_launch") if pmc and not pmc.get("stale") else None,
+                        "traffic_source": ((PMC_FILE + " (rocprofv3 --pmc passes of these kernel sources over the 256-window launch, tools/pmc_ba.sh)") if not pmc.get("stale")
+                                           else (PMC_FILE + " was taken on other kernel sources than this tree's: traffic withheld")) if pmc else None}}
     if R.rank == 0 and not args.no_cpu_baseline:
         R.deferred.append((res, lambda: cpu_baseline_ba(probs[:32])))
     ba.close(); one.close()

@@ -53,6 +53,16 @@ void ms_ctx_destroy(ms_ctx *ctx);
 int ms_ctx_sync(ms_ctx *ctx);                 /* hipStreamSynchronize on the context stream */
 void *ms_ctx_stream(ms_ctx *ctx);             /* the hipStream_t, for event timing by the caller */
 const char *ms_last_error(const ms_ctx *ctx); /* never NULL; valid until the next call on ctx */
+
+/* Stage ranges in a profiler's marker trace (rocprofv3 --marker-trace): with on = 1 the entry points below bracket their work with roctx ranges named
+ * like the reference's own timers where it has them (mapper_helpers.cpp:1044 "poseBundleAdjust", :1080 "localBundleAdjust", :1193 "Bow index
+ * transform") and by stage elsewhere ("pyramid", "detect", "describe" inside ms_orb_extract; "match"; "ms_ba_create", "ms_ba_solve",
+ * "ms_ba_download" -- the host mirrors wrap those in "localBundleAdjust" / "poseBundleAdjust" / "globalBundleAdjust").  The ranges mark where
+ * the work is ENQUEUED on the calling thread.  Process-wide, off by default (also switched on by MS_TRACE_RANGES=1 in the environment); the roctx
+ * library is looked up at run time, MS_ERR_INVALID if there is none.  ms_trace_range_push / pop let a caller (the host mirrors do) add its own. */
+int ms_set_trace_ranges(int on);
+void ms_trace_range_push(const char *name);
+void ms_trace_range_pop(void);
 const char *ms_version(void);
 /* HIP-event timing on the context stream (bench.py measures the hot path with these). */
 int ms_timer_start(ms_ctx *ctx);
@@ -158,7 +168,12 @@ int ms_keypoints_unpack(const uint8_t *records, int n, float *x, float *y, float
 int ms_orb_set_profiling(ms_orb *orb, int enable);
 int ms_orb_stage_ms(ms_orb *orb, float *ms /* [MS_ORB_STAGES] */);
 /* ImagePyramid::getLevel / getBlurredLevel (image_pyramid.hpp:24-25): copy one level of one frame
- * of the last batch to host, tightly packed w*h bytes (debug / parity testing). */
+ * of the last batch to host, tightly packed w*h bytes (debug / parity testing).
+ * LIFETIME of device inputs: frames handed to ms_orb_extract in device memory (16-byte aligned base and strides) are used IN PLACE as
+ * level 0 -- they are not copied.  Level 0, and every BLURRED level (the blurred pyramid is produced on demand, by k_blur over the levels
+ * of the last batch), therefore read the caller's buffer at the time of THIS call: it must still hold the frames of the last
+ * ms_orb_extract, unchanged and not freed, until the next ms_orb_extract or until the caller stops asking for level 0 / blurred levels.
+ * Host inputs and unaligned device inputs are copied into the extractor's own memory and carry no such requirement. */
 int ms_orb_level_size(const ms_orb *orb, int level, int32_t *w, int32_t *h);
 int ms_orb_download_level(ms_orb *orb, int frame, int level, int blurred, uint8_t *dst_host);
 /* FeatureDetector::detect (feature_detector.cpp:20-28): per-level detector output of the last batch
@@ -196,7 +211,12 @@ int ms_hamming_best2_sets(ms_ctx *ctx, const uint32_t *q_pool, int q_stride, con
                           int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist);
 
 /* Accept rule of matchForLoopClosures without the greedy state (keyframe_matcher.cpp:115-122):
- * match[i] = best_idx if best <= 50 and ratio*second >= best, else -1.  Device pointers. */
+ * match[i] = best_idx if best <= max_dist and NOT (ratio * second < (float)best), else -1.  Device pointers.
+ * Arithmetic of the product: float32 (`lowe_ratio` is a float here, the product is one rounded float32 multiply).  The reference writes
+ * `parameters.loopClosureFeatureMatchLoweRatio * second_best_hamm_dist < static_cast<float>(best_hamm_dist)` (:120); the parameter's type lives in
+ * the parent project (not in the tree).  If it is a double there, the reference's product is exact in double and the two can differ for a ratio
+ * that float32 cannot represent, exactly at the boundary ratio * second == best (0.75, 0.5, 0.8125 ... are exact either way; 0.8 or 0.7 are not).
+ * The same holds for ms_match_loop_closure's lowe_ratio. */
 int ms_ratio_test(ms_ctx *ctx, const int32_t *best_idx, const uint16_t *best_dist, const uint16_t *second_dist,
                   int n, float lowe_ratio, int max_dist, int32_t *match);
 
@@ -344,8 +364,11 @@ typedef struct {
 typedef struct ms_ba ms_ba;
 
 /* Upload `n` independent problems (different sizes allowed) and build their index structures.  The handle's device memory is ONE block;
- * ms_ba_destroy hands it back to the context (up to four blocks are kept), and the next ms_ba_create on that context takes a kept block
- * that is large enough instead of allocating: a window per keyframe (create, solve, download, destroy) allocates nothing after warm-up. */
+ * ms_ba_destroy hands it back to the context (up to four blocks, 1 GiB in total: a block that would push the kept total past that --
+ * a global-BA sized handle -- is freed instead), and the next ms_ba_create on that context takes the smallest kept block that is large
+ * enough and at most 8 times the request instead of allocating: a window per keyframe (create, solve, download, destroy) allocates nothing
+ * after warm-up, and a small window never sits on a large block.  If the device is out of memory the kept blocks are freed and the
+ * allocation is tried once more.  Kept blocks are released by ms_ctx_destroy. */
 int ms_ba_create(ms_ctx *ctx, const ms_ba_problem *problems, int n, ms_ba **out);
 void ms_ba_destroy(ms_ba *ba);
 /* Run the full LM schedule of every problem from its initial estimates, one workgroup per problem,
@@ -376,9 +399,18 @@ int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src
  * so two contexts -- the front end's poseBundleAdjust beside the back
  * end's localBundleAdjust, mapper.cpp:379-390 vs :268-269 -- may solve at the same time.  If a barrier still gives up (no progress
  * for ~1 s: CUs held by another PROCESS), ms_ba_download repeats the solve with one workgroup per problem before it returns;
- * ms_ba_team_fallbacks counts those repeats.  ms_ba_debug_fail_team_barriers(ba, 1) makes every team barrier of the following
+ * ms_ba_team_fallbacks counts those repeats.  Before the FIRST problem of a team launch is handed out every problem's marker is looked at, so
+ * no result of a launch that is going to be repeated is ever returned.  A barrier gives up after 2 s WITHOUT PROGRESS (arrival counter and
+ * the team's heartbeat both still), not after a fixed number of polls: a long single-workgroup phase is not mistaken for a lost team.
+ *
+ * Process-wide state: team launches are admitted per DEVICE across all contexts of the process (the sum of their workgroups must fit the CUs,
+ * or two half-resident teams would wait for each other).  That list -- one event per running team launch, guarded by a mutex -- is the one
+ * piece of global mutable state in the library; its events live until the process ends.  An event query that fails with anything but "not
+ * ready" retires the entry, is counted (ms_ba_admission_errors) and its text is kept for ms_last_error of the context that saw it.  ms_ba_debug_fail_team_barriers(ba, 1) makes every team barrier of the following
  * launches give up at once (test hook for that path). */
 int ms_ba_team_fallbacks(const ms_ba *ba);
+/* Event-query failures the team admission list has seen in this process (0 in a healthy run; see above). */
+int ms_ba_admission_errors(void);
 int ms_ba_debug_fail_team_barriers(ms_ba *ba, int on);
 /* Results of problem i (synchronises): poses [n_pose*7], points [n_point*3], per-observation chi2
  * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL.  The status is read first: on

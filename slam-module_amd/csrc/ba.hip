@@ -42,6 +42,8 @@ constexpr int CH = 32;           // Schur work items (pairs of observations of o
 constexpr int kMaxFreePoses = 176;   // Cholesky panel (6*176+1) x 16 doubles + solution vector must fit the LDS budget; beyond it the panel lives in global memory
 constexpr int kMaxFreePosesTeam = 2048;   // ... and the factorisation is spread over the team (cholesky_factor_team); the solution vector (6*2048 doubles) still fits the LDS
 constexpr int kMaxTeam = 64;         // workgroups that may share one problem
+constexpr size_t kBaCacheSlack = 8;  // a kept device block serves a request of at least 1/8 of its size
+constexpr size_t kBaCacheMaxBytes = (size_t)1 << 30;   // blocks kept per context for the next ms_ba_create: 1 GiB in total, larger ones are freed at destroy
 constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
 
 // One set of passes of the fused Schur phase.  A pass owns the free-pose rows [row0, row1) of S: their envelope part lives in an
@@ -336,8 +338,10 @@ __device__ double block_max(double v, double *s_red) {
 // vmcnt 0 -> relaxed agent atomic on the arrival counter; then that lane polls the counter (relaxed, agent scope), issues ONE
 // agent-scope ACQUIRE fence (L1 invalidate), waits for it, and the workgroup barrier releases the other waves.  The counter only
 // grows (barrier k completes at k * team arrivals), so there is no reset to race with.  All workgroups of a team must be resident:
-// the host keeps problems * team <= CUs with one workgroup per CU (LDS), so they all become resident.  A poll that never completes gives up after ~1 s and marks
-// the problem failed instead of hanging the GPU.
+// the host keeps problems * team <= CUs with one workgroup per CU (LDS), so they all become resident.  A poll gives up after kGiveUpTicks (2 s of the
+// constant 100 MHz s_memrealtime clock) WITHOUT PROGRESS and marks the problem failed instead of hanging the GPU.  Progress = the arrival counter
+// moved, or the team's heartbeat word did: a workgroup that works alone through a long phase while the others wait (the lead's factorisation of
+// a large window) beats once per panel, so a legitimately long phase is not mistaken for a lost team.
 #define BA_IDS                                                                                                   \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                               \
     const int T_ = P.team, rank_ = T_ > 1 ? (int)(blockIdx.x % (unsigned)T_) : 0;                                \
@@ -346,6 +350,14 @@ __device__ double block_max(double v, double *s_red) {
     /* on the first 2000 threads of a team are four workgroups at two waves per SIMD while 28 workgroups watch */                          \
     const int gts = tid * T_ + rank_, gws = (NW - 1 - wave) * T_ + rank_;                                        \
     (void)lane; (void)wave; (void)gt; (void)GT; (void)gw; (void)GW; (void)gts; (void)gws;
+
+constexpr unsigned long long kGiveUpTicks = 200000000ull;      // 2 s of wall_clock64() (s_memrealtime, 100 MHz) without progress
+constexpr int kBeatWord = 16;                                  // P.bar[kBeatWord]: the team's heartbeat (P.bar[0] / P.bar[32] are the two arrival counters)
+
+// one lane of a workgroup that works alone while its team waits: "still here"
+__device__ __forceinline__ void team_heartbeat(const BaProb &P) {
+    if (P.team > 1) (void)__hip_atomic_fetch_add(P.bar + kBeatWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, uint32_t T) {
     if (T == 1) { __syncthreads(); return; }
@@ -356,11 +368,17 @@ __device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, u
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t a = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t target = (a / T + 1u) * T;
-        int spins = 0;
-        while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        uint32_t seen = a + 1u, beat = __hip_atomic_load(P.bar + kBeatWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long t_last = wall_clock64();
+        for (;;) {
+            const uint32_t cur = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int32_t)(cur - target) >= 0) break;
             __builtin_amdgcn_s_sleep(8);
-            // give up after ~1 s (or as soon as another workgroup has): every later barrier then falls through at once
-            if (++spins > (1 << 20) || __hip_atomic_load(P.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            // give up after 2 s without progress (or as soon as another workgroup has): every later barrier then falls through at once
+            const uint32_t b = __hip_atomic_load(P.bar + kBeatWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long now = wall_clock64();
+            if (cur != seen || b != beat) { seen = cur; beat = b; t_last = now; }
+            if (now - t_last > kGiveUpTicks || __hip_atomic_load(P.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                 __hip_atomic_store(P.flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -384,9 +402,15 @@ __device__ __noinline__ double team_reduce(const BaProb &P, double v, double *s_
     ++seq;
     if (threadIdx.x == 0) slot[rank] = b;
     team_sync(P);
-    double t = slot[0];
-    for (int r = 1; r < T; ++r) t = is_max ? fmax(t, slot[r]) : t + slot[r];
-    return t;
+    // one lane combines the partials and hands the result on through LDS: every thread of the workgroup gets the SAME value even when a barrier
+    // has given up and the slots are still being written (control flow that depends on it -- rho > 0 -- must stay uniform: it contains barriers)
+    if (threadIdx.x == 0) {
+        double t = slot[0];
+        for (int r = 1; r < T; ++r) t = is_max ? fmax(t, slot[r]) : t + slot[r];
+        s_red[0] = t;
+    }
+    __syncthreads();
+    return s_red[0];                                   // (the next block_sum / block_max passes a barrier before it writes s_red)
 }
 
 // Two sums over the team behind ONE barrier (the robust chi2 of the new state and the step's gain denominator are needed together)
@@ -398,10 +422,14 @@ __device__ __noinline__ double team_reduce2(const BaProb &P, double v1, double v
     ++seq;
     if (threadIdx.x == 0) { slot[rank] = b1; slot[T + rank] = b2; }
     team_sync(P);
-    double t1 = slot[0], t2 = slot[T];
-    for (int r = 1; r < T; ++r) { t1 += slot[r]; t2 += slot[T + r]; }
-    out2 = t2;
-    return t1;
+    if (threadIdx.x == 0) {                            // as in team_reduce: one reader, the workgroup takes the values from LDS
+        double t1 = slot[0], t2 = slot[T];
+        for (int r = 1; r < T; ++r) { t1 += slot[r]; t2 += slot[T + r]; }
+        s_red[0] = t1; s_red[1] = t2;
+    }
+    __syncthreads();
+    out2 = s_red[1];
+    return s_red[0];
 }
 
 // robust chi2 of the current state (activeRobustChi2); optionally stores the plain chi2 per observation
@@ -1475,6 +1503,7 @@ __device__ __forceinline__ void chol_back_substitute(const BaProb &P, double *xs
     const int last = ((n - 1) / NB) * NB;
     for (int c0 = last; c0 >= 0; c0 -= NB) {
         const int nb = min(NB, n - c0);
+        if (tid == NT - 1 && ((c0 / NB) & 7) == 0) team_heartbeat(P);
         if (wave == 0) {
             double col[NB];                                    // lane k: column c0+k of the diagonal block, L[c0+j][c0+k] for j > k
 #pragma unroll
@@ -1514,6 +1543,7 @@ __device__ __noinline__ void cholesky_solve(const BaProb &P_, double *lds_) {
     const MS_GLOBAL int32_t *env = (const MS_GLOBAL int32_t *)P.env16;
     for (int c0 = 0; c0 < n; c0 += NB) {
         const int nb = min(NB, n - c0), m = n - c0 + 1, cnt = m * NB;
+        if (tid == 0) team_heartbeat(P);
         chol_panel_update<false>(P, c0, nb, m, pan, wave, NW, lane);
         __syncthreads();
         if (wave == 0) {
@@ -1689,6 +1719,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         __syncthreads();
         CWP(0);
         for (int p = 0; p < nblk; ++p) {
+            if (tid == NT - 1 && (p & 7) == 0) team_heartbeat(P);            // (a lane of the last wave: wave 0 carries the pivot chain)
             const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
             const int a0 = act_start[p], m = act_start[p + 1] - a0;
             const bool has_next = p + 1 < nblk, next_active = m > 0 && (act[a0] & 0xFFFF) == p + 1;
@@ -1834,6 +1865,7 @@ __device__ __noinline__ void cholesky_window(const BaProb &P_, double *lds_) {
         __syncthreads();
         CWP(0);
         for (int p = 0; p < nblk; ++p) {
+            if (tid == NT - 1 && (p & 7) == 0) team_heartbeat(P);
             const int c0 = 16 * p, nb = min(16, n - c0), sp = slot[p];
             MS_LDS double *Lpp = tiles + (sp * W + sp) * CT;
             // A. rows below: x L11^T = a (a thread per row), and the panel's part of the rhs
@@ -2285,7 +2317,11 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     } else if (lead) cholesky_solve(P, lds);           // dense front: left-looking, panel in LDS, operands from L2
     team_sync(P);
     { const long long t1 = clock64(); cyc[3] += t1 - t0; t0 = t1; }
-    const bool ok = P.flag[0] != 0;
+    __shared__ int s_sound;                                // one reader: the verdict is the same in every thread of the workgroup whatever else writes the flag
+    if (threadIdx.x == 0) s_sound = __hip_atomic_load(P.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool ok = s_sound != 0;
+    __syncthreads();
     if (!ok) return false;
     if (fused) point_backsub_fused(P, lambda, lds); else point_backsub(P);
     cyc[4] += clock64() - t0;
@@ -2295,7 +2331,15 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
 // before a team launch: arrival counters and the gave-up marker back to zero (the counter is monotonic within a launch)
 __global__ void k_ba_team_reset(const BaProb *probs, int n, int gave_up) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { probs[i].bar[0] = 0; probs[i].bar[32] = 0; probs[i].flag[1] = gave_up; }
+    if (i < n) { probs[i].bar[0] = 0; probs[i].bar[32] = 0; probs[i].bar[kBeatWord] = 0; probs[i].flag[1] = gave_up; }
+}
+
+// after a team launch: did ANY problem of the batch see a barrier give up?  (one word, in the first problem's flag line)
+__global__ void k_ba_collect_gave_up(const BaProb *probs, int n) {
+    int any = 0;
+    for (int i = threadIdx.x; i < n; i += 64) any |= probs[i].flag[1];
+    any = __any(any != 0);
+    if (threadIdx.x == 0) probs[0].flag[2] = any;
 }
 
 // the solved state of src's problems becomes the initial state of dst's (ms_ba_copy_state); poses dst has beyond src's take src's pose extra[p]
@@ -2421,6 +2465,7 @@ struct ms_ba {
     std::vector<double> chol_tiles;    // per problem: row tiles a Cholesky panel touches on average
     int cus = 0;
     int launched_team = 1;             // team size of the last launch
+    bool team_checked = true;          // the last team launch has been looked at (every problem's gave-up marker) and, if need be, repeated
     int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
     int team_fallbacks = 0;            // launches repeated with one workgroup per problem after a team barrier gave up
 };
@@ -2430,11 +2475,13 @@ struct ms_ba {
 struct TeamLaunch { hipEvent_t ev; hipStream_t stream; int wgs; bool live; };
 static std::mutex g_team_mu;
 static std::vector<TeamLaunch> g_team_live[64];
+static int g_team_query_errors = 0;        // hipEventQuery answers other than success / not-ready seen by the admission list (guarded by g_team_mu)
 #define MS_TRY_BA(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
 
 extern "C" {
 
 int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
+    MsRange range("ms_ba_create");
     if (!c || !problems || !out || n < 1) return MS_ERR_INVALID;
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
@@ -2832,17 +2879,30 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     B->ctx = c; B->n = n;
     {   // ONE device block per handle (arena + the problem descriptors behind it), taken from the context's cache of destroyed handles when one is large enough
         const size_t probs_at = ms_align_up(total, 256), need = probs_at + sizeof(BaProb) * n;
+        // best fit among the kept blocks, but never one more than kBaCacheSlack times the request: a small window must not sit on the
+        // gigabytes a global-BA handle left behind (that block waits for the next large request, or goes when the cache is trimmed)
         int best = -1;
         for (int i = 0; i < 4; ++i)
-            if (c->ba_cache[i].p && c->ba_cache[i].bytes >= need && (best < 0 || c->ba_cache[i].bytes < c->ba_cache[best].bytes)) best = i;
+            if (c->ba_cache[i].p && c->ba_cache[i].bytes >= need && c->ba_cache[i].bytes / kBaCacheSlack <= need &&
+                (best < 0 || c->ba_cache[i].bytes < c->ba_cache[best].bytes)) best = i;
         if (best >= 0) { B->d_arena = static_cast<char *>(c->ba_cache[best].p); B->arena_bytes = c->ba_cache[best].bytes; c->ba_cache[best] = {}; }
         else {
-            if (hipMalloc(reinterpret_cast<void **>(&B->d_arena), need) != hipSuccess) { delete B; return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes", need); }
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&B->d_arena), need);
+            if (e != hipSuccess) {                                  // out of memory with blocks kept for later: give them back and try once more
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(c->stream);
+                for (auto &b : c->ba_cache) if (b.p) { (void)hipFree(b.p); b = {}; }
+                e = hipMalloc(reinterpret_cast<void **>(&B->d_arena), need);
+            }
+            if (e != hipSuccess) { (void)hipGetLastError(); delete B; return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes: %s", need, hipGetErrorString(e)); }
             B->arena_bytes = need;
         }
         B->d_probs = reinterpret_cast<BaProb *>(B->d_arena + probs_at);
     }
-    (void)hipMemsetAsync(B->d_arena, 0, total, c->stream);
+    {
+        const hipError_t e = hipMemsetAsync(B->d_arena, 0, total, c->stream);
+        if (e != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: clearing the arena failed: %s", hipGetErrorString(e)); }
+    }
     B->host.resize(n); B->dims.assign(problems, problems + n);
     std::vector<char> stage;
     for (int p = 0; p < n; ++p) {
@@ -2936,7 +2996,10 @@ void ms_ba_destroy(ms_ba *B) {
             for (int i = 1; i < 4; ++i) if (c->ba_cache[i].bytes < c->ba_cache[small].bytes) small = i;
             if (c->ba_cache[small].bytes < B->arena_bytes) { (void)hipFree(c->ba_cache[small].p); c->ba_cache[small] = {}; slot = small; }
         }
-        if (slot >= 0) { c->ba_cache[slot].p = B->d_arena; c->ba_cache[slot].bytes = B->arena_bytes; } else (void)hipFree(B->d_arena);
+        size_t kept = 0;
+        for (int i = 0; i < 4; ++i) if (i != slot) kept += c->ba_cache[i].bytes;
+        if (slot >= 0 && kept + B->arena_bytes <= kBaCacheMaxBytes) { c->ba_cache[slot].p = B->d_arena; c->ba_cache[slot].bytes = B->arena_bytes; }
+        else (void)hipFree(B->d_arena);                            // over the cap (a global-BA sized block): not kept
     }
     delete B;
 }
@@ -2954,6 +3017,7 @@ int ms_ba_set_factor_team(ms_ba *B, int workgroups) {
 }
 
 int ms_ba_solve(ms_ba *B) {
+    MsRange range("ms_ba_solve");
     if (!B) return MS_ERR_INVALID;
     ms_ctx *c = B->ctx;
     MS_HIP(c, hipSetDevice(c->device));
@@ -2993,7 +3057,14 @@ int ms_ba_solve(ms_ba *B) {
         for (TeamLaunch &t : live) {                                   // retire what has finished; launches of this stream precede the new one anyway
             if (t.live) {                                              // anything but "not ready" retires the entry (an error: the stream it was recorded on is gone)
                 const hipError_t q = hipEventQuery(t.ev);
-                if (q != hipErrorNotReady) { t.live = false; if (q != hipSuccess) (void)hipGetLastError(); }
+                if (q != hipErrorNotReady) {
+                    t.live = false;
+                    if (q != hipSuccess) {                             // not swallowed: counted, and the text stays with this context
+                        ++g_team_query_errors;
+                        (void)ms_fail(c, MS_ERR_HIP, "team admission: hipEventQuery of an earlier launch failed: %s (entry retired; %d so far)", hipGetErrorString(q), g_team_query_errors);
+                        (void)hipGetLastError();
+                    }
+                }
             }
             if (t.live && t.stream != c->stream) in_use += t.wgs;
         }
@@ -3026,6 +3097,7 @@ int ms_ba_solve(ms_ba *B) {
         MS_KERNEL_CHECK(c, "k_ba_lm");
     }
     B->launched_team = team;
+    B->team_checked = team == 1;
     return MS_OK;
 }
 
@@ -3038,22 +3110,38 @@ static int ba_relaunch_single(ms_ba *B) {
     MS_KERNEL_CHECK(c, "k_ba_lm");
     MS_HIP(c, hipStreamSynchronize(c->stream));
     B->launched_team = 1;
+    B->team_checked = true;
     ++B->team_fallbacks;
     return MS_OK;
 }
 
 int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_per_obs, ms_ba_result *res) {
+    MsRange range("ms_ba_download");
     if (!B || i < 0 || i >= B->n) return MS_ERR_INVALID;
     ms_ctx *c = B->ctx;
     MS_HIP(c, hipStreamSynchronize(c->stream));
     const BaProb &H = B->host[i];
     // status first: a failed solve must not overwrite the caller's arrays (the host mirrors pass the window itself as output)
+    // A team barrier that gave up anywhere in the batch voids the whole launch (the workgroups of one launch share the chip): before the FIRST
+    // problem of a team launch is handed out, every problem's marker is looked at and the batch is solved again without teams if one is set --
+    // never after some results have already been returned.
+    if (!B->team_checked) {
+        int any = 0;
+        if (B->n > 1) {
+            hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
+            MS_KERNEL_CHECK(c, "k_ba_collect_gave_up");
+            MS_HIP(c, hipMemcpyAsync(&any, B->host[0].flag + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            MS_HIP(c, hipStreamSynchronize(c->stream));
+        } else {
+            double s7 = 0;
+            MS_HIP(c, hipMemcpy(&s7, B->host[0].stats + 7, sizeof(double), hipMemcpyDeviceToHost));
+            any = s7 != 0;
+        }
+        if (any) MS_TRY_BA(ba_relaunch_single(B));
+        B->team_checked = true;
+    }
     double st[16];
     MS_HIP(c, hipMemcpy(st, H.stats, sizeof(st), hipMemcpyDeviceToHost));
-    if (st[7] != 0 && B->launched_team > 1) {            // a team barrier gave up: solve again without a team, then look again
-        MS_TRY_BA(ba_relaunch_single(B));
-        MS_HIP(c, hipMemcpy(st, H.stats, sizeof(st), hipMemcpyDeviceToHost));
-    }
     if (res) {
         for (int k = 0; k < 8; ++k) res->phase_cycles[k] = st[8 + k];
         res->iterations = (int)st[0]; res->trials = (int)st[1]; res->stopped_early = (int)st[2]; res->final_lambda = st[3];
@@ -3092,6 +3180,7 @@ int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src
 }
 
 int ms_ba_team_fallbacks(const ms_ba *B) { return B ? B->team_fallbacks : MS_ERR_INVALID; }
+int ms_ba_admission_errors(void) { std::lock_guard<std::mutex> lk(g_team_mu); return g_team_query_errors; }
 int ms_ba_debug_fail_team_barriers(ms_ba *B, int on) { if (!B) return MS_ERR_INVALID; B->debug_fail_barriers = on ? 1 : 0; return MS_OK; }
 
 int ms_ba_solve_host(ms_ctx *c, const ms_ba_problem *problem, double *pose_out, double *point_out, double *chi2_per_obs, ms_ba_result *res) {

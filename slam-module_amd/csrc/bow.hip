@@ -146,6 +146,7 @@ void ms_bow_vocab_destroy(ms_bow_vocab *v) {
 }
 
 int ms_bow_transform(ms_ctx *c, const ms_bow_vocab *v, const uint32_t *desc, int n, int levels_up, int32_t *word, double *weight, int32_t *node) {
+    MsRange range("Bow index transform");     // the reference's timer name, mapper_helpers.cpp:1193
     if (!c || !v || n < 0 || (n > 0 && (!desc || !word))) return MS_ERR_INVALID;
     if (n == 0) return MS_OK;
     if (reinterpret_cast<uintptr_t>(desc) % 16) return ms_fail(c, MS_ERR_INVALID, "bow transform: descriptors must be 16-byte aligned");

@@ -1,6 +1,30 @@
 // ctx.cpp -- device context, stream, event timing and plain memory helpers of the C ABI.
 #include "ms_internal.h"
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+
+namespace {
+std::atomic<int> g_ranges_on{0};
+std::once_flag g_ranges_once;
+int (*g_push)(const char *) = nullptr;
+int (*g_pop)() = nullptr;
+void ranges_resolve() {
+    for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        g_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (g_push && g_pop) return;
+        g_push = nullptr; g_pop = nullptr;
+    }
+}
+}  // namespace
+
+void ms_range_push(const char *name) { if (g_ranges_on.load(std::memory_order_relaxed) && g_push) (void)g_push(name); }
+void ms_range_pop() { if (g_ranges_on.load(std::memory_order_relaxed) && g_pop) (void)g_pop(); }
 
 int ms_scratch(ms_ctx *c, size_t bytes, void **out) {
     if (bytes > c->scratch_bytes) {
@@ -19,6 +43,18 @@ extern "C" {
 
 const char *ms_version(void) { return "mi355slam 0.1 (gfx950)"; }
 
+int ms_set_trace_ranges(int on) {
+    if (on) {
+        std::call_once(g_ranges_once, ranges_resolve);
+        if (!g_push || !g_pop) return MS_ERR_INVALID;               // no roctx library on this machine
+    }
+    g_ranges_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return MS_OK;
+}
+
+void ms_trace_range_push(const char *name) { ms_range_push(name ? name : ""); }
+void ms_trace_range_pop(void) { ms_range_pop(); }
+
 int ms_ctx_create(int device, ms_ctx **out) {
     if (!out) return MS_ERR_INVALID;
     *out = nullptr;
@@ -29,6 +65,7 @@ int ms_ctx_create(int device, ms_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MS_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MS_ERR_NO_DEVICE;   // kernels are gfx950-only
+    if (const char *e = std::getenv("MS_TRACE_RANGES")) if (e[0] == '1') (void)ms_set_trace_ranges(1);
     ms_ctx *c = new ms_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount;

@@ -920,6 +920,7 @@ __global__ __launch_bounds__(256) void k_greedy_finish(GreedyArgs A, GreedyScrat
 extern "C" {
 
 static int launch_hamming(ms_ctx *c, const HamArgs &A, int n_pairs) {
+    MsRange range("match");
     if (A.nq < 0 || A.nt < 0 || n_pairs < 0 || A.nt >= (1 << 20) || n_pairs > 65535 || A.q_stride < A.nq || A.t_stride < A.nt)
         return ms_fail(c, MS_ERR_INVALID, "hamming search: size out of range");
     if (A.q_stride == 0 || n_pairs == 0) return MS_OK;
@@ -1060,6 +1061,7 @@ int ms_descriptor_medoid(ms_ctx *c, const uint32_t *desc_pool, const int32_t *ob
 static int launch_greedy(ms_ctx *c, bool tri, const ms_match_frame *p1, const ms_match_frame *p2, int n_pairs,
                          const double *E12, const float *sf, float thr_deg, float ratio, int check_orientation,
                          int32_t *const *matched, int32_t *n_matches) {
+    MsRange range("match");
     if (!c || !p1 || !p2 || !matched || !n_matches || n_pairs < 0) return MS_ERR_INVALID;
     if (n_pairs == 0) return MS_OK;
     if (n_pairs > 65535) return ms_fail(c, MS_ERR_CAPACITY, "greedy matcher: %d pairs in one call (max 65535)", n_pairs);

@@ -64,5 +64,18 @@ void umax(int32_t *u16);
 void resize_tables(int src_n, int dst_n, bool is_x, std::vector<int16_t> &ofs, std::vector<int16_t> &coef);
 }  // namespace msgeo
 
+// Stage ranges for a profiler's marker trace (ms_set_trace_ranges): roctxRangePushA / roctxRangePop, resolved at run time from
+// librocprofiler-sdk-roctx / libroctx64 -- no link dependency, nothing happens (one relaxed load) while they are off.
+void ms_range_push(const char *name);
+void ms_range_pop();
+struct MsRange {
+    explicit MsRange(const char *name) { ms_range_push(name); }
+    ~MsRange() { end(); }
+    void end() { if (open_) { ms_range_pop(); open_ = false; } }      // close before the scope does (an early return still closes it)
+    bool open_ = true;
+    MsRange(const MsRange &) = delete;
+    MsRange &operator=(const MsRange &) = delete;
+};
+
 inline int ms_div_up(int a, int b) { return (a + b - 1) / b; }
 inline size_t ms_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

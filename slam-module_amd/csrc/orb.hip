@@ -1058,6 +1058,7 @@ struct ms_orb {
     uint8_t *d_slab = nullptr;
     uint32_t *d_cand = nullptr;
     int32_t *d_cand_count = nullptr, *d_det_count = nullptr, *d_trk_count = nullptr;
+    size_t cand_count_bytes = 0;
     int16_t *d_det_x = nullptr, *d_det_y = nullptr, *d_trk_x = nullptr, *d_trk_y = nullptr;
     uint8_t *d_det_score = nullptr, *d_mask = nullptr;
     float *d_trk_px = nullptr, *d_trk_py = nullptr, *d_track_xy = nullptr;
@@ -1181,6 +1182,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     A(dev_calloc(ctx, &o->d_slab, B * G.slab_stride + 256));   // + slack (round 1's k_describe could touch one byte past the last plane; today's window loads stay inside the level)
     A(dev_calloc(ctx, &o->d_cand, B * G.cand_stride));
     A(dev_calloc(ctx, &o->d_cand_count, B * MS_MAX_LEVELS));
+    o->cand_count_bytes = sizeof(int32_t) * B * MS_MAX_LEVELS;
     A(dev_calloc(ctx, &o->d_det_count, B * MS_MAX_LEVELS));
     A(dev_calloc(ctx, &o->d_trk_count, B));
     A(dev_calloc(ctx, &o->d_det_x, B * (size_t)G.det_stride));
@@ -1306,9 +1308,21 @@ int ms_orb_set_valid_mask(ms_orb *o, const uint8_t *mask) {
     return MS_OK;
 }
 
+static int orb_extract_enqueue(ms_orb *o, const uint8_t *images, int on_device, int n_frames, size_t frame_stride, size_t row_stride,
+                               const float *track_xy, const int32_t *track_id, const int32_t *n_tracks, bool &counters_dirty);
+
 int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames, size_t frame_stride, size_t row_stride,
                    const float *track_xy, const int32_t *track_id, const int32_t *n_tracks) {
     if (!o || !images) return MS_ERR_INVALID;
+    bool counters_dirty = false;
+    const int rc = orb_extract_enqueue(o, images, on_device, n_frames, frame_stride, row_stride, track_xy, track_id, n_tracks, counters_dirty);
+    // k_fast fills the candidate counters and k_select puts them back to zero; a call that fails in between must not leave them to the next one
+    if (rc != MS_OK && counters_dirty) (void)hipMemsetAsync(o->d_cand_count, 0, o->cand_count_bytes, o->ctx->stream);
+    return rc;
+}
+
+static int orb_extract_enqueue(ms_orb *o, const uint8_t *images, int on_device, int n_frames, size_t frame_stride, size_t row_stride,
+                               const float *track_xy, const int32_t *track_id, const int32_t *n_tracks, bool &counters_dirty) {
     ms_ctx *c = o->ctx;
     const PyrGeom &G = o->geom;
     if (n_frames < 1 || n_frames > o->cfg.max_batch) return ms_fail(c, MS_ERR_CAPACITY, "ms_orb_extract: n_frames %d outside [1,%d]", n_frames, o->cfg.max_batch);
@@ -1352,6 +1366,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     int stage = 0;
 #define MS_STAGE_MARK() do { if (o->profiling) MS_HIP(c, hipEventRecord(o->ev[stage++], st)); } while (0)
     MS_STAGE_MARK();
+    MsRange pyramid_range("pyramid");
     for (int l = 1; l < G.levels; ++l) {
         dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4 * kResizeRows), n_frames);
         const ResizeTab T{o->d_xtab[l], o->d_ytab[l]};
@@ -1364,11 +1379,14 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, RA, T);
         MS_KERNEL_CHECK(c, "k_resize");
     }
+    pyramid_range.end();
     MS_STAGE_MARK();
     // The blurred pyramid (image_pyramid.cpp:82-85) is not materialised per frame any more: its only consumer on the path, the BRIEF tests,
     // blurs its own 39 x 39 patches inside k_describe.  ImagePyramid::getBlurredLevel (ms_orb_download_level) runs k_blur on demand.
     o->blur_valid = false;
     MS_STAGE_MARK();
+    MsRange detect_range("detect");
+    counters_dirty = true;
     hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_ftile_tab, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
@@ -1381,6 +1399,7 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         else hipLaunchKernelGGL((k_select<false, 256>), dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
     }
     MS_KERNEL_CHECK(c, "k_select");
+    counters_dirty = false;
     MS_STAGE_MARK();
     if (o->cfg.max_tracks > 0) {                                    // (an extractor built without tracker features: d_trk_count stays at its initial zero)
         hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
@@ -1389,6 +1408,8 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
         MS_KERNEL_CHECK(c, "k_tracks");
     }
     MS_STAGE_MARK();
+    detect_range.end();
+    MsRange describe_range("describe");
     hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
                        o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
                        o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count, G.levels);

@@ -86,6 +86,10 @@ struct BaOutcome {
 };
 
 namespace detail {
+struct TraceRange {                                       // a roctx range named like the reference's timer (no-op unless ms_set_trace_ranges(1))
+    explicit TraceRange(const char *name) { ms_trace_range_push(name); }
+    ~TraceRange() { ms_trace_range_pop(); }
+};
 inline ms_ba_problem as_problem(const BaWindow &w, const std::vector<std::uint8_t> &poseFixed, const std::vector<std::uint8_t> *pointFixed, int iters) {
     ms_ba_problem p{};
     p.n_pose = (std::int32_t)w.poses.size(); p.n_point = (std::int32_t)w.points.size(); p.n_obs = (std::int32_t)w.obsPose.size();
@@ -104,6 +108,7 @@ inline ms_ba_problem as_problem(const BaWindow &w, const std::vector<std::uint8_
 // localBundleAdjust (bundle_adjuster.cpp:141-394) on a prepared window; updates w.poses / w.points in place.
 inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize, const Parameters &parameters, bool neighbourhoodStage = true,
                                    WorkspaceBA *workspace = nullptr) {
+    detail::TraceRange range("localBundleAdjust");                            // timer(slam::TIME_STATS, "localBundleAdjust"), mapper_helpers.cpp:1080
     BaOutcome out;
     const int iterations = static_cast<int>(1 + std::sqrt(static_cast<double>(problemMaxSize)));      // :156
     std::vector<double> chi2(w.obsPose.size());
@@ -140,6 +145,10 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
     ctx.check(ms_ba_copy_state(b2.h, b1.h, &cur), "ms_ba_copy_state");
     ctx.check(ms_ba_solve(b2.h), "ms_ba_solve");
     ctx.check(ms_ba_download(b1.h, 0, nullptr, nullptr, nullptr, &out.stage1), "ms_ba_download");      // a failed stage 1 stops here, the window untouched
+    if (ms_ba_team_fallbacks(b1.h) > 0) {                                      // stage 1 was solved again (a team barrier had given up): stage 2 started from a state
+        ctx.check(ms_ba_copy_state(b2.h, b1.h, &cur), "ms_ba_copy_state");     // that is gone -- chain it again from the repeated solve
+        ctx.check(ms_ba_solve(b2.h), "ms_ba_solve");
+    }
     out.ran = true;
     ctx.check(ms_ba_download(b2.h, 0, w2.poses[0].data(), w2.points.empty() ? nullptr : w2.points[0].data(), chi2.data(), &out.stage2), "ms_ba_download");
     for (std::size_t i = 0; i < w.poses.size(); ++i) w.poses[i] = w2.poses[i];    // applyBundleAdjustResults (:114-137)
@@ -152,6 +161,7 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
 
 // poseBundleAdjust (bundle_adjuster.cpp:396-491): one free pose, every point fixed (:465), parameters.poseBAIterations.
 inline bool poseBundleAdjust(Context &ctx, BaWindow &w, int poseBAIterations, ms_ba_result *res = nullptr) {
+    detail::TraceRange range("poseBundleAdjust");                             // mapper_helpers.cpp:1044
     if (w.obsPose.empty()) return false;                                       // :410-412
     std::vector<std::uint8_t> fixed(w.poses.size(), 1), pfixed(w.points.size(), 1);
     fixed[w.currentKeyframe] = 0;
@@ -168,6 +178,7 @@ inline bool poseBundleAdjust(Context &ctx, BaWindow &w, int poseBAIterations, ms
 // `w` holds the whole map as flat arrays (w.currentKeyframe = the fixed one); up to 2048 free keyframes (the device spreads the
 // factorisation of systems beyond 176 poses over a team of workgroups).
 inline BaOutcome globalBundleAdjust(Context &ctx, BaWindow &w, int globalBAIterations) {
+    detail::TraceRange range("globalBundleAdjust");
     BaOutcome out;
     std::vector<std::uint8_t> fixed(w.poses.size(), 0);
     fixed[w.currentKeyframe] = 1;

@@ -313,17 +313,16 @@ inline std::vector<int> findMatchesTranformedMps(Context &ctx, const std::vector
 inline unsigned matchMapPointsSim3(Context &ctx, const DeviceKeyframe &kf1, const DeviceKeyframe &kf2, const std::vector<Sim3Projection> &mps1in2,
                                    const std::vector<Sim3Projection> &mps2in1, std::vector<std::pair<int, int>> &matches, const StaticSettings &settings) {
     constexpr float margin = 7.5;                                                              // :641
-    std::vector<bool> alreadyMatchedInKf1(mps1in2.size(), false), alreadyMatchedInKf2(mps2in1.size(), false);
-    for (const auto &match : matches) { alreadyMatchedInKf1.at((std::size_t)match.first) = true; alreadyMatchedInKf2.at((std::size_t)match.second) = true; }
-    const std::vector<int> matched_indices_2_in_keyfrm_1 = findMatchesTranformedMps(ctx, mps1in2, alreadyMatchedInKf1, kf2, margin, settings);
-    const std::vector<int> matched_indices_1_in_keyfrm_2 = findMatchesTranformedMps(ctx, mps2in1, alreadyMatchedInKf2, kf1, margin, settings);
-    unsigned num_matches = 0;                                                                  // only matches that agree in both directions (:672-685)
-    for (unsigned i = 0; i < matched_indices_2_in_keyfrm_1.size(); ++i) {
-        const int idx_2 = matched_indices_2_in_keyfrm_1.at(i);
-        if (idx_2 < 0) continue;
-        if (matched_indices_1_in_keyfrm_2.at((std::size_t)idx_2) == static_cast<int>(i)) { matches.emplace_back((int)i, idx_2); ++num_matches; }
-    }
-    return num_matches;
+    // keypoints that already carry a match are left out of both searches (:645-648)
+    std::vector<bool> taken1(mps1in2.size(), false), taken2(mps2in1.size(), false);
+    for (const std::pair<int, int> &m : matches) { taken1.at((std::size_t)m.first) = true; taken2.at((std::size_t)m.second) = true; }
+    const std::vector<int> fwd = findMatchesTranformedMps(ctx, mps1in2, taken1, kf2, margin, settings);      // kf1 keypoint -> kf2 keypoint or -1
+    const std::vector<int> bwd = findMatchesTranformedMps(ctx, mps2in1, taken2, kf1, margin, settings);      // kf2 keypoint -> kf1 keypoint or -1
+    // a pair is kept when each side names the other (:672-685), in ascending kf1 index
+    const std::size_t before = matches.size();
+    for (std::size_t i1 = 0; i1 < fwd.size(); ++i1)
+        if (fwd[i1] >= 0 && bwd.at((std::size_t)fwd[i1]) == (int)i1) matches.emplace_back((int)i1, fwd[i1]);
+    return (unsigned)(matches.size() - before);
 }
 
 // create_E_21 (openvslam/essential_solver.cc:157-162), row-major 3x3

@@ -8,6 +8,7 @@
 // Same call shape, same output order (tracker points first, then level-major), same early return on zero keypoints;
 // pyramid + detector are built lazily on the first frame like orb_extractor.cpp:80-81.
 #pragma once
+#include <cstring>
 #include <functional>
 #include "common.hpp"
 
@@ -15,7 +16,15 @@ namespace mi355slam {
 
 struct OrbExtractor {
     virtual ~OrbExtractor() = default;
+    // cameraValidMask: width x height bytes at level-0 resolution (0 = invalid pixel) or nullptr.  The mask is uploaded when it CHANGES: a new
+    // pointer, or new contents behind the same pointer -- the contents are hashed on every call (64 bits over all bytes, ~50 us for 720p), so a
+    // caller that edits its mask in place is seen.  A caller that knows when its mask changes passes a version number instead (overload below)
+    // and pays nothing per frame.
     virtual void detectAndExtract(const ImageView &img, const std::uint8_t *cameraValidMask,
+                                  const std::vector<TrackPoint> &tracks, KeyPointVector &keyPoints,
+                                  std::vector<int> &keyPointTrackIds) = 0;
+    // the same with the caller's own change counter: the mask is uploaded when (pointer, version) differs from the last call's
+    virtual void detectAndExtract(const ImageView &img, const std::uint8_t *cameraValidMask, std::uint64_t maskVersion,
                                   const std::vector<TrackPoint> &tracks, KeyPointVector &keyPoints,
                                   std::vector<int> &keyPointTrackIds) = 0;
     // The same call with the camera model itself: isValidPixel(x, y) is evaluated on the host at exactly the sub-pixel positions the reference
@@ -49,6 +58,23 @@ public:
 
     void detectAndExtract(const ImageView &img, const std::uint8_t *mask, const std::vector<TrackPoint> &tracks,
                           KeyPointVector &keypts, std::vector<int> &keyptTrackIds) override {
+        run(img, mask, mask ? contentHash(mask, (std::size_t)img.width * img.height) : 0, tracks, keypts, keyptTrackIds);
+    }
+    void detectAndExtract(const ImageView &img, const std::uint8_t *mask, std::uint64_t maskVersion, const std::vector<TrackPoint> &tracks,
+                          KeyPointVector &keypts, std::vector<int> &keyptTrackIds) override {
+        run(img, mask, maskVersion, tracks, keypts, keyptTrackIds);
+    }
+
+private:
+    static std::uint64_t contentHash(const std::uint8_t *p, std::size_t n) {           // multiply-xorshift over 8-byte words, tail bytes one by one
+        std::uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+        std::size_t i = 0;
+        for (; i + 8 <= n; i += 8) { std::uint64_t w; std::memcpy(&w, p + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 32; }
+        for (; i < n; ++i) { h = (h ^ p[i]) * 0x100000001B3ull; }
+        return h;
+    }
+    void run(const ImageView &img, const std::uint8_t *mask, std::uint64_t maskTag, const std::vector<TrackPoint> &tracks,
+             KeyPointVector &keypts, std::vector<int> &keyptTrackIds) {
         const auto &p = settings_.parameters;
         if (!orb_) {                                                     // lazily built on the first frame (:80-81)
             ms_orb_config c{img.width, img.height, (int)p.orbScaleLevels, p.orbScaleFactor, (int)p.maxKeypoints,
@@ -58,7 +84,7 @@ public:
             x_.resize(cap_); y_.resize(cap_); a_.resize(cap_); o_.resize(cap_); t_.resize(cap_); d_.resize(8 * (std::size_t)cap_);
             xy_.assign(2 * (std::size_t)p.maxTracks, 0.f); ids_.assign(p.maxTracks, 0);      // workspace, like orb_extractor.cpp:217-219: nothing is allocated per frame
         }
-        if (mask != mask_) { ctx_.check(ms_orb_set_valid_mask(orb_, mask), "ms_orb_set_valid_mask"); mask_ = mask; }
+        if (mask != mask_ || (mask && maskTag != maskTag_)) { ctx_.check(ms_orb_set_valid_mask(orb_, mask), "ms_orb_set_valid_mask"); mask_ = mask; maskTag_ = maskTag; }
         const std::int32_t nt = (std::int32_t)std::min<std::size_t>(tracks.size(), p.maxTracks);
         for (int i = 0; i < nt; ++i) { xy_[2 * i] = tracks[i].x; xy_[2 * i + 1] = tracks[i].y; ids_[i] = tracks[i].id; }
         ctx_.check(ms_orb_extract(orb_, img.data, img.onDevice ? 1 : 0, 1, img.stride * (std::size_t)img.height, img.stride,
@@ -77,6 +103,7 @@ public:
         }
     }
 
+public:
     std::vector<std::uint8_t> getLevel(std::size_t level, bool blurred, int &w, int &h) override {
         std::int32_t ww = 0, hh = 0;
         ctx_.check(ms_orb_level_size(orb_, (int)level, &ww, &hh), "ms_orb_level_size");
@@ -105,6 +132,7 @@ private:
     StaticSettings settings_;
     ms_orb *orb_ = nullptr;
     const std::uint8_t *mask_ = nullptr;
+    std::uint64_t maskTag_ = 0;
     int cap_ = 0;
     std::vector<float> x_, y_, a_, xy_;
     std::vector<std::int32_t> o_, t_, ids_;

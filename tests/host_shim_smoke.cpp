@@ -65,6 +65,17 @@ int main(int argc, char **argv) {
         std::vector<std::uint8_t> mask((std::size_t)W * H);
         for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) mask[(std::size_t)y * W + x] = valid((float)x, (float)y);
         extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, mask.data(), {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, rast, rastIds);
+        {   // a mask edited IN PLACE (same pointer) must be seen: contents are hashed per call; with a version number the caller says when
+            KeyPointVector k2, k3, k4; std::vector<int> i2, i3, i4;
+            std::fill(mask.begin(), mask.end(), (std::uint8_t)1);                       // now everything is valid again, same pointer
+            extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, mask.data(), {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, k2, i2);
+            if (k2.size() != all.size()) { std::printf("in-place mask edit was ignored: %zu vs %zu\n", k2.size(), all.size()); return 15; }
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) mask[(std::size_t)y * W + x] = valid((float)x, (float)y);
+            extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, mask.data(), 1, {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, k3, i3);
+            std::fill(mask.begin(), mask.end(), (std::uint8_t)1);
+            extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, mask.data(), 1, {TrackPoint{100.f, 100.f, 7}, TrackPoint{20.f, 30.f, 8}}, k4, i4);   // same version: by contract NOT re-read
+            if (k3.size() != rast.size() || k4.size() != rast.size()) { std::printf("mask version handling: %zu %zu vs %zu\n", k3.size(), k4.size(), rast.size()); return 16; }
+        }
         extractor->detectAndExtract(ImageView{img.data(), W, H, (std::size_t)W, false}, nullptr, {TrackPoint{100.f, 100.f, 7}}, kps, ids);   // back to the unmasked state
         std::printf("validity: %zu of %zu keypoints inside (rasterised mask keeps %zu)\n", exact.size(), all.size(), rast.size());
         if (!same || want != exact.size() || exact.size() >= all.size() || exact.empty() || exactIds[0] != 7 || std::find(exactIds.begin(), exactIds.end(), 8) != exactIds.end()) return 12;

@@ -33,6 +33,28 @@ def test_small_problems_match_oracle(oracle, ctx):
         _check(p, ba.download(i), oracle.ba_solve(p, 10, False))
 
 
+def test_rejected_lm_steps_follow_the_oracle(oracle, ctx):
+    """Start far from the optimum: several damped solves are REJECTED (rho < 0: state restored, lambda *= nu, nu *= 2 -- the pop() path of the
+    kernel), so trials > iterations.  The whole trajectory (iterations, trials, final lambda, final state) must be the oracle's, with one
+    workgroup per problem and with teams (the restore sits between team barriers there)."""
+    import mi355slam
+    probs = []
+    for seed, (npose, npt, run, sig) in enumerate([(6, 80, 5, 0.6), (6, 80, 5, 1.5), (20, 400, 6, 1.0), (12, 300, 8, 0.8)]):
+        p = ba_synth.make_problem(npose, npt, run, seed=seed + 2)
+        p["point"] = p["point"] + np.random.default_rng(seed).normal(0, sig, p["point"].shape)
+        probs.append(p)
+    wants = [oracle.ba_solve(p, 12, False) for p in probs]
+    assert all(w["stats"]["trials"] > w["stats"]["iters"] for w in wants)       # every one of them rejects at least one step
+    assert all(w["stats"]["chi2_final"] < 0.01 * w["stats"]["chi2_init"] for w in wants)
+    for team in (1, 4):
+        ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=12)
+        ba.set_team(team); ba.solve()
+        for i, p in enumerate(probs):
+            _check(p, ba.download(i), wants[i])
+        assert ba.team_fallbacks() == 0
+        ba.close()
+
+
 def test_c4_local_ba_matches_oracle(oracle, ctx):
     """BASELINE config C4: 50 keyframes x 2000 points x 20000 observations, 10 LM iterations, seed 42."""
     import mi355slam
@@ -86,6 +108,16 @@ def test_reference_two_stage_schedule(oracle, ctx):
     assert np.abs(g3["pose"] - g2["pose"]).max() < 1e-9 and np.abs(g3["point"] - g2["point"]).max() < 1e-9
     g1b = ba.download(0)                                              # stage 1 as it ran this time (its atomic sums differ in the last bits from run to run)
     assert np.array_equal(g3["pose"][12], g1b["pose"][cur])           # the fixed extra vertex is that run's stage-1 pose, bit for bit
+    # a stage 1 whose team barriers gave up is repeated by its download; the chain is then redone from the repeated solve (the recipe of the
+    # host mirror localBundleAdjust): same end state
+    ba.set_team(4); ba.debug_fail_team_barriers(True)
+    ba.solve(); ba3.copy_state_from(ba, [cur]); ba3.solve()
+    ba.debug_fail_team_barriers(False)
+    ba.download(0)
+    assert ba.team_fallbacks() == 1
+    ba3.copy_state_from(ba, [cur]); ba3.solve()
+    g4 = ba3.download(0)
+    _check(s2w, g4, w2)
     with pytest.raises(mi355slam.MsError):
         ba3.copy_state_from(ba, None)                                   # one pose more than the source and nothing to fill it from
     with pytest.raises(mi355slam.MsError):

@@ -2,6 +2,7 @@
 # PMC passes over the local-BA leg of bench.py (k_ba_lm, 256 distinct C4 windows per launch): usage  bash tools/pmc_ba.sh <out.json>
 # One counter group per run, --kernel-trace only.  Writes the per-launch averages of the 256-workgroup launches.
 cd /tmp && export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the snapshot root)}"
 R=$GRAFT_REPO_ROOT
 OUT=${1:-$R/gpurun_out/pmc_ba.json}; case "$OUT" in /*) ;; *) OUT="$R/$OUT";; esac
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F64 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
@@ -20,6 +21,9 @@ res = {c + "_per_launch": round(sum(v) / len(v), 1) for c, v in sorted(acc.items
 if "FETCH_SIZE_per_launch" in res and "WRITE_SIZE_per_launch" in res:
     res["hbm_bytes_per_launch"] = int((res["FETCH_SIZE_per_launch"] + res["WRITE_SIZE_per_launch"]) * 1024)
 res["launches_seen"] = {c: len(v) for c, v in acc.items()}
+sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "tools"))
+import build_id
+res["src_sha256"] = build_id.source_hash(os.environ["GRAFT_REPO_ROOT"])
 res["note"] = ("rocprofv3 --pmc passes (one counter group per run, --kernel-trace only) of `bench.py --only-ba --ba-steps 2`: the 256-window launches of k_ba_lm "
                "(256 workgroups x 512 threads, 256 distinct C4 windows, 10 LM iterations).  FETCH_SIZE / WRITE_SIZE in KiB as reported, no correction applied "
                "(scattered 8-16 byte accesses: uncalibrated, MI355X_MICROARCH.md HBM section).")

@@ -4,6 +4,7 @@
 # counter group (counters on their own with --kernel-trace only).  Copy what is to be judged into profiles/ afterwards.
 set -e
 tag=$1
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the snapshot root)}"
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p "$O"
