@@ -279,6 +279,19 @@ int ms_projection_candidates(ms_ctx *ctx, const float *sorted_x, const float *so
                              int32_t *best_idx, uint16_t *best_dist, uint16_t *second_dist, int32_t *best_octave, int32_t *second_octave,
                              int32_t *second_idx, int32_t *n_candidates);
 
+/* The same two scans returning, per query, the FOUR best candidates in the order of (distance, position in the scan) instead of (best, second):
+ * top_idx / top_octave [nq*4] (keypoint index / its octave, -1 where the list is shorter), top_dist [nq*4] (256 there), n_scored [nq] = candidates
+ * that were scored (inside the radius, not skipped, inside the octave window).  searchByProjection binds keypoints while it walks its map points
+ * (keyframe_matcher.cpp:356-360,:388-389): with the list a host replay finds the best and second best among the keypoints still free without going
+ * back to the device -- exact whenever two list entries are still free or n_scored <= 4 (the list is the whole candidate set); otherwise that one
+ * query is scored again against the current mask (rare: three of its four best must have been taken by earlier map points of the same call). */
+int ms_hamming_candidates_topk(ms_ctx *ctx, const uint32_t *q_desc, int nq, const uint32_t *t_desc, const int32_t *cand_start, const int32_t *cand_idx,
+                               const uint8_t *t_skip, const int32_t *t_octave, int32_t *top_idx, uint16_t *top_dist, int32_t *top_octave, int32_t *n_scored);
+int ms_projection_topk(ms_ctx *ctx, const float *sorted_x, const float *sorted_y, const int32_t *sorted_idx, int n_kp,
+                       const uint32_t *t_desc, const int32_t *t_octave, const uint8_t *t_skip,
+                       const float *q_x, const float *q_y, const float *q_radius, const int32_t *q_min_octave, const int32_t *q_max_octave,
+                       const uint32_t *q_desc, int nq, int32_t *top_idx, uint16_t *top_dist, int32_t *top_octave, int32_t *n_scored, int32_t *n_candidates);
+
 /* Rotation-consistency histogram (openvslam/match_angle_checker.h:60-134), host arithmetic: 30 bins of
  * cvRound(delta/30), everything outside the 3 fullest bins is invalid (ties between bins go to the lower bin).
  * Writes the ids of invalid entries (bin order, then insertion order) and returns their count. */

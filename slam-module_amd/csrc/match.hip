@@ -293,8 +293,65 @@ __global__ __launch_bounds__(256) void k_descriptor_medoid(const uint32_t *__res
     }
 }
 
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double rl_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+constexpr int kGreedyCpl = 4;            // candidates per lane in k_greedy_nodes: nodes of up to 256 candidates stay in one wave's registers
+
+// Wave-wide reductions on the DPP network (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): 6 steps of
+// 1-2 register moves instead of 6 x ds_bpermute round trips through the LDS crossbar.  The result is read from lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_none(uint32_t v) {               // lanes the control gives no source keep kNone (the identity of min)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)kNone, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void best2_step(uint32_t &best, uint32_t &second) {
+    const uint32_t ob = dpp_or_none<CTRL, ROW_MASK>(best), os = dpp_or_none<CTRL, ROW_MASK>(second);
+    const uint32_t l2 = min(best, ob), h2 = max(best, ob);
+    second = min(min(second, os), h2);
+    best = l2;
+}
+__device__ __forceinline__ void wave_best2(uint32_t &best, uint32_t &second) {      // every source lane enters each lane's result once: no key is counted twice
+    best2_step<0x111, 0xF>(best, second);          // row_shr:1
+    best2_step<0x112, 0xF>(best, second);          // row_shr:2
+    best2_step<0x114, 0xF>(best, second);          // row_shr:4
+    best2_step<0x118, 0xF>(best, second);          // row_shr:8   -> lane 15 of a row holds the row
+    best2_step<0x142, 0xA>(best, second);          // row_bcast:15 into rows 1 and 3
+    best2_step<0x143, 0xC>(best, second);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
+    best = rl_u(best, 63); second = rl_u(second, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_or_none<0x111, 0xF>(v)); v = min(v, dpp_or_none<0x112, 0xF>(v)); v = min(v, dpp_or_none<0x114, 0xF>(v));
+    v = min(v, dpp_or_none<0x118, 0xF>(v)); v = min(v, dpp_or_none<0x142, 0xA>(v)); v = min(v, dpp_or_none<0x143, 0xC>(v));
+    return rl_u(v, 63);
+}
+
+// Top-4 candidate lists (ms_hamming_candidates_topk / ms_projection_topk): a lane keeps the four smallest keys it has seen, sorted; the wave then
+// pops its minimum four times (keys are unique -- they carry the candidate's position -- so exactly one lane owns each minimum).
+struct Top4 { uint32_t k0 = kNone, k1 = kNone, k2 = kNone, k3 = kNone; };
+__device__ __forceinline__ void top4_push(Top4 &t, uint32_t x) {
+    uint32_t a = min(t.k0, x); x = max(t.k0, x); t.k0 = a;
+    a = min(t.k1, x); x = max(t.k1, x); t.k1 = a;
+    a = min(t.k2, x); x = max(t.k2, x); t.k2 = a;
+    t.k3 = min(t.k3, x);
+}
+__device__ __forceinline__ void top4_extract(Top4 &t, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t m = wave_min_u32(t.k0);
+        out[r] = m;
+        if (t.k0 == m && m != kNone) { t.k0 = t.k1; t.k1 = t.k2; t.k2 = t.k3; t.k3 = kNone; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One wavefront per query: lanes scan the query's own candidate list, butterfly merge of (best, second) keys.
+// TOPK: instead of (best, second) the four best candidates -- bi / bo are then [nq][4] (keypoint index, octave), bd is [nq][4] (distance; unused entries
+// -1 / 256), si [nq] the number of candidates that were scored (not skipped): a list with si <= 4 is the complete candidate set
+template <bool TOPK>
 __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__restrict__ qd, int nq, const uint32_t *__restrict__ td,
                                                             const int32_t *__restrict__ cstart, const int32_t *__restrict__ cidx,
                                                             const uint8_t *__restrict__ skip, const int32_t *__restrict__ toct,
@@ -306,14 +363,34 @@ __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__re
     const uint32_t qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
     const int s = cstart[i], e = cstart[i + 1];
     uint32_t best = kNone, second = kNone;
+    Top4 top;
+    int scored = 0;
     for (int r = s + lane; r < e; r += 64) {
         const int j = cidx[r];
         if (skip && skip[j]) continue;
         const uint4 ta = reinterpret_cast<const uint4 *>(td)[2 * j], tb = reinterpret_cast<const uint4 *>(td)[2 * j + 1];
         const uint32_t key = (hamming8(qr, ta, tb) << 20) | (uint32_t)(r - s);
+        if (TOPK) { top4_push(top, key); ++scored; continue; }
         const uint32_t lo = min(best, key), hi = max(best, key);
         second = min(second, hi);
         best = lo;
+    }
+    if (TOPK) {
+        uint32_t out[4];
+        top4_extract(top, out);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) scored += __shfl_xor(scored, off, 64);
+        if (lane < 4) {
+            uint32_t k = out[0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) if (lane == r) k = out[r];
+            const int j = k == kNone ? -1 : cidx[s + (int)(k & 0xFFFFFu)];
+            bi[4 * (size_t)i + lane] = j;
+            bd[4 * (size_t)i + lane] = k == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(k >> 20);
+            bo[4 * (size_t)i + lane] = (j >= 0 && toct) ? toct[j] : -1;
+        }
+        if (lane == 0) si[i] = scored;
+        return;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -339,6 +416,7 @@ __global__ __launch_bounds__(256) void k_hamming_candidates(const uint32_t *__re
 // sorted by y; the wave binary-searches the first y >= qy - r (std::lower_bound), then its lanes walk the range up to
 // y <= qy + r, keep the points with dx*dx + dy*dy < r*r (float32, no contraction), and score the survivors exactly like
 // k_hamming_candidates: candidates are ordered by their position in the sorted array, best = first minimum, second = next.
+template <bool TOPK>       // as in k_hamming_candidates: bi / bd / bo become [nq][4] lists, si the number of scored candidates; ncand keeps its meaning
 __global__ __launch_bounds__(256) void k_projection_candidates(const float *__restrict__ sx, const float *__restrict__ sy, const int32_t *__restrict__ sidx, int n,
                                                                const uint32_t *__restrict__ td, const int32_t *__restrict__ toct, const uint8_t *__restrict__ skip,
                                                                const float *__restrict__ qx, const float *__restrict__ qy, const float *__restrict__ qr_,
@@ -359,7 +437,8 @@ __global__ __launch_bounds__(256) void k_projection_candidates(const float *__re
         if (sy[mid] < ylo) lo = mid + 1; else hi = mid;
     }
     uint32_t best = kNone, second = kNone;
-    int count = 0;
+    Top4 top;
+    int count = 0, scored = 0;
     for (int pos = lo + lane;; pos += 64) {
         const bool in_y = pos < n && sy[pos] <= yhi;
         if (__ballot(in_y) == 0) break;                 // sorted: nothing further can be inside
@@ -372,9 +451,27 @@ __global__ __launch_bounds__(256) void k_projection_candidates(const float *__re
         if (toct && (toct[j] < lmin || toct[j] > lmax)) continue;
         const uint4 ta = reinterpret_cast<const uint4 *>(td)[2 * j], tb = reinterpret_cast<const uint4 *>(td)[2 * j + 1];
         const uint32_t key = (hamming8(qr, ta, tb) << 20) | (uint32_t)pos;
+        if (TOPK) { top4_push(top, key); ++scored; continue; }
         const uint32_t l2 = min(best, key), h2 = max(best, key);
         second = min(second, h2);
         best = l2;
+    }
+    if (TOPK) {
+        uint32_t out[4];
+        top4_extract(top, out);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { scored += __shfl_xor(scored, off, 64); count += __shfl_xor(count, off, 64); }
+        if (lane < 4) {
+            uint32_t k = out[0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) if (lane == r) k = out[r];
+            const int j = k == kNone ? -1 : sidx[k & 0xFFFFFu];
+            bi[4 * (size_t)i + lane] = j;
+            bd[4 * (size_t)i + lane] = k == kNone ? (uint16_t)MS_HAMMING_MAX : (uint16_t)(k >> 20);
+            bo[4 * (size_t)i + lane] = (j >= 0 && toct) ? toct[j] : -1;
+        }
+        if (lane == 0) { si[i] = scored; if (ncand) ncand[i] = count; }
+        return;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -564,42 +661,6 @@ __global__ __launch_bounds__(256) void k_greedy_init(GreedyArgs A, GreedyScratch
     if (i < n2) S.own2[(size_t)p * S.stride2 + i] = 0;
     if (i < 32) S.hist[32 * p + i] = 0;
     if (p == 0 && i < 2) S.big[i] = 0;
-}
-
-__device__ __forceinline__ uint32_t rl_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ double rl_d(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
-constexpr int kGreedyCpl = 4;            // candidates per lane in k_greedy_nodes: nodes of up to 256 candidates stay in one wave's registers
-
-// Wave-wide reductions on the DPP network (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): 6 steps of
-// 1-2 register moves instead of 6 x ds_bpermute round trips through the LDS crossbar.  The result is read from lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_or_none(uint32_t v) {               // lanes the control gives no source keep kNone (the identity of min)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)kNone, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void best2_step(uint32_t &best, uint32_t &second) {
-    const uint32_t ob = dpp_or_none<CTRL, ROW_MASK>(best), os = dpp_or_none<CTRL, ROW_MASK>(second);
-    const uint32_t l2 = min(best, ob), h2 = max(best, ob);
-    second = min(min(second, os), h2);
-    best = l2;
-}
-__device__ __forceinline__ void wave_best2(uint32_t &best, uint32_t &second) {      // every source lane enters each lane's result once: no key is counted twice
-    best2_step<0x111, 0xF>(best, second);          // row_shr:1
-    best2_step<0x112, 0xF>(best, second);          // row_shr:2
-    best2_step<0x114, 0xF>(best, second);          // row_shr:4
-    best2_step<0x118, 0xF>(best, second);          // row_shr:8   -> lane 15 of a row holds the row
-    best2_step<0x142, 0xA>(best, second);          // row_bcast:15 into rows 1 and 3
-    best2_step<0x143, 0xC>(best, second);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
-    best = rl_u(best, 63); second = rl_u(second, 63);
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    v = min(v, dpp_or_none<0x111, 0xF>(v)); v = min(v, dpp_or_none<0x112, 0xF>(v)); v = min(v, dpp_or_none<0x114, 0xF>(v));
-    v = min(v, dpp_or_none<0x118, 0xF>(v)); v = min(v, dpp_or_none<0x142, 0xA>(v)); v = min(v, dpp_or_none<0x143, 0xC>(v));
-    return rl_u(v, 63);
 }
 
 template <bool TRIANGULATION>
@@ -972,9 +1033,22 @@ int ms_hamming_candidates(ms_ctx *c, const uint32_t *q_desc, int nq, const uint3
     if (nq == 0) return MS_OK;
     if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_candidates: descriptors must be 16-byte aligned");
     MS_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_hamming_candidates, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, q_desc, nq, t_desc, cand_start, cand_idx, t_skip, t_octave,
+    hipLaunchKernelGGL(k_hamming_candidates<false>, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, q_desc, nq, t_desc, cand_start, cand_idx, t_skip, t_octave,
                        best_idx, best_dist, second_dist, best_octave, second_octave, second_idx);
     MS_KERNEL_CHECK(c, "k_hamming_candidates");
+    return MS_OK;
+}
+
+int ms_hamming_candidates_topk(ms_ctx *c, const uint32_t *q_desc, int nq, const uint32_t *t_desc, const int32_t *cand_start, const int32_t *cand_idx,
+                               const uint8_t *t_skip, const int32_t *t_octave, int32_t *top_idx, uint16_t *top_dist, int32_t *top_octave, int32_t *n_scored) {
+    if (!c || !q_desc || !t_desc || !cand_start || !cand_idx || !top_idx || !top_dist || !top_octave || !n_scored || nq < 0) return MS_ERR_INVALID;
+    if (nq == 0) return MS_OK;
+    if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_hamming_candidates_topk: descriptors must be 16-byte aligned");
+    MsRange range("match");
+    MS_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_hamming_candidates<true>, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, q_desc, nq, t_desc, cand_start, cand_idx, t_skip, t_octave,
+                       top_idx, top_dist, static_cast<uint16_t *>(nullptr), top_octave, static_cast<int32_t *>(nullptr), n_scored);
+    MS_KERNEL_CHECK(c, "k_hamming_candidates<topk>");
     return MS_OK;
 }
 
@@ -999,9 +1073,27 @@ int ms_projection_candidates(ms_ctx *c, const float *sorted_x, const float *sort
     if (nq == 0) return MS_OK;
     if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_projection_candidates: descriptors must be 16-byte aligned");
     MS_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_projection_candidates, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, sorted_x, sorted_y, sorted_idx, n_kp, t_desc, t_octave, t_skip,
+    hipLaunchKernelGGL(k_projection_candidates<false>, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, sorted_x, sorted_y, sorted_idx, n_kp, t_desc, t_octave, t_skip,
                        q_x, q_y, q_radius, q_min_octave, q_max_octave, q_desc, nq, best_idx, best_dist, second_dist, best_octave, second_octave, second_idx, n_candidates);
     MS_KERNEL_CHECK(c, "k_projection_candidates");
+    return MS_OK;
+}
+
+int ms_projection_topk(ms_ctx *c, const float *sorted_x, const float *sorted_y, const int32_t *sorted_idx, int n_kp,
+                       const uint32_t *t_desc, const int32_t *t_octave, const uint8_t *t_skip,
+                       const float *q_x, const float *q_y, const float *q_radius, const int32_t *q_min_octave, const int32_t *q_max_octave,
+                       const uint32_t *q_desc, int nq, int32_t *top_idx, uint16_t *top_dist, int32_t *top_octave, int32_t *n_scored, int32_t *n_candidates) {
+    if (!c || n_kp < 0 || nq < 0 || !q_x || !q_y || !q_radius || !q_desc || !top_idx || !top_dist || !top_octave || !n_scored) return MS_ERR_INVALID;
+    if (n_kp && (!sorted_x || !sorted_y || !sorted_idx || !t_desc)) return MS_ERR_INVALID;
+    if (n_kp >= (1 << 20)) return ms_fail(c, MS_ERR_CAPACITY, "ms_projection_topk: %d keypoints (max %d)", n_kp, (1 << 20) - 1);
+    if (nq == 0) return MS_OK;
+    if (reinterpret_cast<uintptr_t>(q_desc) % 16 || reinterpret_cast<uintptr_t>(t_desc) % 16) return ms_fail(c, MS_ERR_INVALID, "ms_projection_topk: descriptors must be 16-byte aligned");
+    MsRange range("match");
+    MS_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_projection_candidates<true>, dim3(ms_div_up(nq, 4)), dim3(256), 0, c->stream, sorted_x, sorted_y, sorted_idx, n_kp, t_desc, t_octave, t_skip,
+                       q_x, q_y, q_radius, q_min_octave, q_max_octave, q_desc, nq, top_idx, top_dist, static_cast<uint16_t *>(nullptr), top_octave,
+                       static_cast<int32_t *>(nullptr), n_scored, n_candidates);
+    MS_KERNEL_CHECK(c, "k_projection_candidates<topk>");
     return MS_OK;
 }
 

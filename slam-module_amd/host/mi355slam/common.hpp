@@ -74,15 +74,33 @@ public:
     explicit Context(int device = 0) {
         if (ms_ctx_create(device, &ctx_) != MS_OK) throw std::runtime_error("mi355slam: no usable gfx950 device (no CPU fallback)");
     }
-    ~Context() { ms_ctx_destroy(ctx_); }
+    ~Context() { if (ws_) ms_dev_free(ctx_, ws_); ms_ctx_destroy(ctx_); }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     ms_ctx *get() const { return ctx_; }
+    // Errors of the C ABI become exceptions HERE, in the shims, and only for conditions the reference treats as fatal too (it asserts; it has no error
+    // codes and no exceptions): no device, a failed HIP call, a capacity given at create time exceeded.  Soft failures keep the reference's
+    // conventions (false / 0 / empty set).  Nothing throws across the C ABI itself.
     void check(int rc, const char *what) const {
         if (rc != MS_OK) throw std::runtime_error(std::string(what) + ": " + ms_last_error(ctx_));
     }
+    // Device workspace of the shims' per-call tables (queries in, scores out): grows, never shrinks, one allocation instead of a dozen per call.
+    // Like every handle it belongs to the one thread that drives this context.
+    unsigned char *workspace(std::size_t bytes) {
+        if (bytes > wsBytes_) {
+            if (ws_) ms_dev_free(ctx_, ws_);
+            ws_ = nullptr; wsBytes_ = 0;
+            check(ms_dev_alloc(ctx_, 2 * bytes + 256, &ws_), "ms_dev_alloc");
+            wsBytes_ = 2 * bytes + 256;
+        }
+        return static_cast<unsigned char *>(ws_);
+    }
+    std::vector<unsigned char> &staging() { return stage_; }          // host side of the same tables, reused across calls
 private:
     ms_ctx *ctx_ = nullptr;
+    void *ws_ = nullptr;
+    std::size_t wsBytes_ = 0;
+    std::vector<unsigned char> stage_;
 };
 
 }  // namespace mi355slam

@@ -5,6 +5,7 @@
 // kf.shared->keyPoints, kf.mapPoints and kf.shared->bowFeatureVec) and uploaded by DeviceKeyframe.
 #pragma once
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <utility>
 #include "common.hpp"
@@ -45,7 +46,15 @@ public:
         for (std::size_t i = 0; i < n; ++i) { x[i] = kps[i].pt.x; y[i] = kps[i].pt.y; }
         ctx_.check(ms_feature_search_sort(x.data(), y.data(), (int)n, sx.data(), sy.data(), si.data()), "ms_feature_search_sort");
         sx_ = up(sx); sy_ = up(sy); si_ = up(si);
+        // host copies of what a single query's scan needs (searchByProjectionCore settles the rare query whose top-4 list ran out right here,
+        // instead of a round trip to the device): 48 bytes per keypoint
+        hsx_ = std::move(sx); hsy_ = std::move(sy); hsi_ = std::move(si); hdesc_ = std::move(desc); hoct_ = std::move(oct);
     }
+    const std::vector<float> &hostSortedX() const { return hsx_; }
+    const std::vector<float> &hostSortedY() const { return hsy_; }
+    const std::vector<std::int32_t> &hostSortedIndex() const { return hsi_; }
+    const std::uint32_t *hostDescriptor(std::size_t i) const { return hdesc_.data() + 8 * i; }
+    int hostOctave(std::size_t i) const { return hoct_[i]; }
     const float *sortedX() const { return sx_; }
     const float *sortedY() const { return sy_; }
     const std::int32_t *sortedIndex() const { return si_; }
@@ -64,34 +73,43 @@ private:
     ms_match_frame f_{};
     const float *sx_ = nullptr, *sy_ = nullptr;
     const std::int32_t *si_ = nullptr;
+    std::vector<float> hsx_, hsy_;
+    std::vector<std::int32_t> hsi_, hoct_;
+    std::vector<std::uint32_t> hdesc_;
     std::vector<void *> owned_;
 };
 
 namespace detail {
+inline std::size_t pad16(std::size_t n) { return (n + 15) / 16 * 16; }
+
 inline unsigned run_greedy(Context &ctx, bool triangulation, const DeviceKeyframe &kf1, const DeviceKeyframe &kf2, std::vector<int> &out,
                            float ratio, const double *E12, const std::vector<float> *scaleFactors, float thrDeg) {
+    // one workspace block: [match count (16 B)][matched: n1 ints][E: 9 doubles][scale factors]; one upload (M2 only), one call, one download
     const std::size_t n1 = (std::size_t)kf1.frame().n;
-    void *d_m = nullptr, *d_n = nullptr, *d_E = nullptr, *d_sf = nullptr;
-    ctx.check(ms_dev_alloc(ctx.get(), 4 * n1 + 16, &d_m), "ms_dev_alloc");
-    ctx.check(ms_dev_alloc(ctx.get(), 16, &d_n), "ms_dev_alloc");
-    std::int32_t *mptr = static_cast<std::int32_t *>(d_m);
+    const std::size_t oM = 16, oE = oM + pad16(4 * n1), oS = oE + 80, total = oS + pad16(4 * (scaleFactors ? scaleFactors->size() : 0));
+    unsigned char *ws = ctx.workspace(total);
+    std::int32_t *mptr = reinterpret_cast<std::int32_t *>(ws + oM);
     ms_match_frame f1 = kf1.frame(), f2 = kf2.frame();
     int rc;
     if (triangulation) {
-        ctx.check(ms_dev_alloc(ctx.get(), 72, &d_E), "ms_dev_alloc"); ctx.check(ms_dev_upload(ctx.get(), d_E, E12, 72), "upload");
-        ctx.check(ms_dev_alloc(ctx.get(), scaleFactors->size() * 4 + 16, &d_sf), "ms_dev_alloc");
-        ctx.check(ms_dev_upload(ctx.get(), d_sf, scaleFactors->data(), scaleFactors->size() * 4), "upload");
-        rc = ms_match_triangulation(ctx.get(), &f1, &f2, 1, static_cast<const double *>(d_E), static_cast<const float *>(d_sf), thrDeg, 1, &mptr,
-                                    static_cast<std::int32_t *>(d_n));
+        std::vector<unsigned char> &st = ctx.staging();
+        st.assign(total - oE, 0);
+        std::memcpy(st.data(), E12, 72);
+        std::memcpy(st.data() + 80, scaleFactors->data(), 4 * scaleFactors->size());
+        ctx.check(ms_dev_upload(ctx.get(), ws + oE, st.data(), st.size()), "ms_dev_upload");
+        rc = ms_match_triangulation(ctx.get(), &f1, &f2, 1, reinterpret_cast<const double *>(ws + oE), reinterpret_cast<const float *>(ws + oS), thrDeg, 1, &mptr,
+                                    reinterpret_cast<std::int32_t *>(ws));
     } else {
-        rc = ms_match_loop_closure(ctx.get(), &f1, &f2, 1, ratio, 1, &mptr, static_cast<std::int32_t *>(d_n));
+        rc = ms_match_loop_closure(ctx.get(), &f1, &f2, 1, ratio, 1, &mptr, reinterpret_cast<std::int32_t *>(ws));
     }
     ctx.check(rc, "greedy matcher");
+    std::vector<unsigned char> &st = ctx.staging();
+    st.resize(oM + 4 * n1);
+    ctx.check(ms_dev_download(ctx.get(), st.data(), ws, st.size()), "ms_dev_download");
     std::int32_t num = 0;
+    std::memcpy(&num, st.data(), 4);
     out.assign(n1, -1);
-    ctx.check(ms_dev_download(ctx.get(), &num, d_n, 4), "download");
-    if (n1) ctx.check(ms_dev_download(ctx.get(), out.data(), d_m, 4 * n1), "download");
-    for (void *p : {d_m, d_n, d_E, d_sf}) if (p) ms_dev_free(ctx.get(), p);
+    if (n1) std::memcpy(out.data(), st.data() + oM, 4 * n1);
     return (unsigned)num;
 }
 }  // namespace detail
@@ -132,105 +150,163 @@ struct RadiusQuery {
     std::int32_t minOctave = -0x7fffffff, maxOctave = 0x7fffffff;      // findMatchesTranformedMps keeps [pred - 1, pred] (:611)
 };
 
-struct CandidateScores { std::vector<std::int32_t> best, second, bestOctave, secondOctave; std::vector<std::uint16_t> bestDist, secondDist; };
+// Per query the four best candidates in (distance, scan position) order -- ms_hamming_candidates_topk / ms_projection_topk -- and how many candidates
+// were scored in all: with nScored <= 4 the list IS the candidate set.
+struct CandidateLists {
+    std::vector<std::int32_t> idx, octave, nScored;      // [4 n], [4 n], [n]
+    std::vector<std::uint16_t> dist;                     // [4 n]
+};
 
 namespace detail {
-inline CandidateScores score_candidates(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &qs,
-                                        const std::vector<std::uint8_t> *skip, std::size_t first = 0, std::size_t count = ~std::size_t(0)) {
+// uploads the queries (one block), runs the scan, downloads the lists (one block)
+inline CandidateLists score_candidates(Context &ctx, const DeviceKeyframe &kf, const std::vector<ProjectionQuery> &qs,
+                                       const std::vector<std::uint8_t> *skip, std::size_t first = 0, std::size_t count = ~std::size_t(0)) {
     count = std::min(count, qs.size() - first);
-    CandidateScores out;
-    out.best.assign(count, -1); out.second.assign(count, -1); out.bestOctave.assign(count, -1); out.secondOctave.assign(count, -1);
-    out.bestDist.assign(count, MS_HAMMING_MAX); out.secondDist.assign(count, MS_HAMMING_MAX);
+    CandidateLists out;
+    out.idx.assign(4 * count, -1); out.octave.assign(4 * count, -1); out.nScored.assign(count, 0); out.dist.assign(4 * count, MS_HAMMING_MAX);
     if (count == 0) return out;
-    std::vector<std::uint32_t> desc(8 * count);
-    std::vector<std::int32_t> start(count + 1, 0), idx;
+    std::size_t nc = 0;
+    for (std::size_t i = 0; i < count; ++i) nc += qs[first + i].candidates.size();
+    const std::size_t nk = skip ? skip->size() : 0;
+    const std::size_t oD = 0, oS = oD + 32 * count, oI = oS + pad16(4 * (count + 1)), oK = oI + pad16(4 * nc), inBytes = oK + pad16(nk);
+    const std::size_t oTi = inBytes, oTo = oTi + 16 * count, oN = oTo + 16 * count, oTd = oN + pad16(4 * count), total = oTd + pad16(8 * count);
+    std::vector<unsigned char> &st = ctx.staging();
+    st.assign(inBytes, 0);
+    std::int32_t *start = reinterpret_cast<std::int32_t *>(st.data() + oS), *idx = reinterpret_cast<std::int32_t *>(st.data() + oI);
+    std::size_t at = 0;
     for (std::size_t i = 0; i < count; ++i) {
-        for (int k = 0; k < 8; ++k) desc[8 * i + k] = qs[first + i].descriptor[k];
-        idx.insert(idx.end(), qs[first + i].candidates.begin(), qs[first + i].candidates.end());
-        start[i + 1] = (std::int32_t)idx.size();
+        const ProjectionQuery &q = qs[first + i];
+        std::memcpy(st.data() + oD + 32 * i, q.descriptor.data(), 32);
+        start[i] = (std::int32_t)at;
+        if (!q.candidates.empty()) std::memcpy(idx + at, q.candidates.data(), 4 * q.candidates.size());
+        at += q.candidates.size();
     }
-    std::vector<void *> bufs;
-    auto up = [&](const void *src, std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d);
-                                                         if (bytes) { ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); }
-                                                         return d; };
-    auto dn = [&](std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d); return d; };
-    void *dq = up(desc.data(), desc.size() * 4), *ds = up(start.data(), start.size() * 4), *di = up(idx.data(), idx.size() * 4);
-    void *dk = skip ? up(skip->data(), skip->size()) : nullptr;
-    void *b = dn(4 * count), *bd = dn(2 * count), *sd = dn(2 * count), *bo = dn(4 * count), *so = dn(4 * count), *si = dn(4 * count);
+    start[count] = (std::int32_t)at;
+    if (nk) std::memcpy(st.data() + oK, skip->data(), nk);
+    unsigned char *ws = ctx.workspace(total);
+    ctx.check(ms_dev_upload(ctx.get(), ws, st.data(), inBytes), "ms_dev_upload");
     const ms_match_frame &f = kf.frame();
-    ctx.check(ms_hamming_candidates(ctx.get(), static_cast<const std::uint32_t *>(dq), (int)count, f.desc, static_cast<const std::int32_t *>(ds),
-                                    static_cast<const std::int32_t *>(di), static_cast<const std::uint8_t *>(dk), f.octave, static_cast<std::int32_t *>(b),
-                                    static_cast<std::uint16_t *>(bd), static_cast<std::uint16_t *>(sd), static_cast<std::int32_t *>(bo),
-                                    static_cast<std::int32_t *>(so), static_cast<std::int32_t *>(si)), "ms_hamming_candidates");
-    ctx.check(ms_dev_download(ctx.get(), out.best.data(), b, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.second.data(), si, 4 * count), "download");
-    ctx.check(ms_dev_download(ctx.get(), out.bestDist.data(), bd, 2 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondDist.data(), sd, 2 * count), "download");
-    ctx.check(ms_dev_download(ctx.get(), out.bestOctave.data(), bo, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondOctave.data(), so, 4 * count), "download");
-    for (void *p : bufs) ms_dev_free(ctx.get(), p);
+    ctx.check(ms_hamming_candidates_topk(ctx.get(), reinterpret_cast<const std::uint32_t *>(ws + oD), (int)count, f.desc, reinterpret_cast<const std::int32_t *>(ws + oS),
+                                         reinterpret_cast<const std::int32_t *>(ws + oI), nk ? ws + oK : nullptr, f.octave, reinterpret_cast<std::int32_t *>(ws + oTi),
+                                         reinterpret_cast<std::uint16_t *>(ws + oTd), reinterpret_cast<std::int32_t *>(ws + oTo), reinterpret_cast<std::int32_t *>(ws + oN)),
+              "ms_hamming_candidates_topk");
+    st.resize(total - oTi);
+    ctx.check(ms_dev_download(ctx.get(), st.data(), ws + oTi, total - oTi), "ms_dev_download");
+    std::memcpy(out.idx.data(), st.data(), 16 * count); std::memcpy(out.octave.data(), st.data() + (oTo - oTi), 16 * count);
+    std::memcpy(out.nScored.data(), st.data() + (oN - oTi), 4 * count); std::memcpy(out.dist.data(), st.data() + (oTd - oTi), 8 * count);
+    return out;
+}
+
+inline CandidateLists score_candidates(Context &ctx, const DeviceKeyframe &kf, const std::vector<RadiusQuery> &qs,
+                                       const std::vector<std::uint8_t> *skip, std::size_t first = 0, std::size_t count = ~std::size_t(0)) {
+    count = std::min(count, qs.size() - first);
+    CandidateLists out;
+    out.idx.assign(4 * count, -1); out.octave.assign(4 * count, -1); out.nScored.assign(count, 0); out.dist.assign(4 * count, MS_HAMMING_MAX);
+    if (count == 0) return out;
+    const std::size_t nk = skip ? skip->size() : 0, sec = pad16(4 * count);
+    const std::size_t oD = 0, oX = 32 * count, oY = oX + sec, oR = oY + sec, oLo = oR + sec, oHi = oLo + sec, oK = oHi + sec, inBytes = oK + pad16(nk);
+    const std::size_t oTi = inBytes, oTo = oTi + 16 * count, oN = oTo + 16 * count, oTd = oN + sec, total = oTd + pad16(8 * count);
+    std::vector<unsigned char> &st = ctx.staging();
+    st.assign(inBytes, 0);
+    float *x = reinterpret_cast<float *>(st.data() + oX), *y = reinterpret_cast<float *>(st.data() + oY), *r = reinterpret_cast<float *>(st.data() + oR);
+    std::int32_t *lo = reinterpret_cast<std::int32_t *>(st.data() + oLo), *hi = reinterpret_cast<std::int32_t *>(st.data() + oHi);
+    for (std::size_t i = 0; i < count; ++i) {
+        const RadiusQuery &q = qs[first + i];
+        std::memcpy(st.data() + oD + 32 * i, q.descriptor.data(), 32);
+        x[i] = q.x; y[i] = q.y; r[i] = q.radius; lo[i] = q.minOctave; hi[i] = q.maxOctave;
+    }
+    if (nk) std::memcpy(st.data() + oK, skip->data(), nk);
+    unsigned char *ws = ctx.workspace(total);
+    ctx.check(ms_dev_upload(ctx.get(), ws, st.data(), inBytes), "ms_dev_upload");
+    const ms_match_frame &f = kf.frame();
+    ctx.check(ms_projection_topk(ctx.get(), kf.sortedX(), kf.sortedY(), kf.sortedIndex(), f.n, f.desc, f.octave, nk ? ws + oK : nullptr,
+                                 reinterpret_cast<const float *>(ws + oX), reinterpret_cast<const float *>(ws + oY), reinterpret_cast<const float *>(ws + oR),
+                                 reinterpret_cast<const std::int32_t *>(ws + oLo), reinterpret_cast<const std::int32_t *>(ws + oHi),
+                                 reinterpret_cast<const std::uint32_t *>(ws + oD), (int)count, reinterpret_cast<std::int32_t *>(ws + oTi),
+                                 reinterpret_cast<std::uint16_t *>(ws + oTd), reinterpret_cast<std::int32_t *>(ws + oTo), reinterpret_cast<std::int32_t *>(ws + oN), nullptr),
+              "ms_projection_topk");
+    st.resize(total - oTi);
+    ctx.check(ms_dev_download(ctx.get(), st.data(), ws + oTi, total - oTi), "ms_dev_download");
+    std::memcpy(out.idx.data(), st.data(), 16 * count); std::memcpy(out.octave.data(), st.data() + (oTo - oTi), 16 * count);
+    std::memcpy(out.nScored.data(), st.data() + (oN - oTi), 4 * count); std::memcpy(out.dist.data(), st.data() + (oTd - oTi), 8 * count);
     return out;
 }
 }  // namespace detail
 
 namespace detail {
-inline CandidateScores score_candidates(Context &ctx, const DeviceKeyframe &kf, const std::vector<RadiusQuery> &qs,
-                                        const std::vector<std::uint8_t> *skip, std::size_t first = 0, std::size_t count = ~std::size_t(0)) {
-    count = std::min(count, qs.size() - first);
-    CandidateScores out;
-    out.best.assign(count, -1); out.second.assign(count, -1); out.bestOctave.assign(count, -1); out.secondOctave.assign(count, -1);
-    out.bestDist.assign(count, MS_HAMMING_MAX); out.secondDist.assign(count, MS_HAMMING_MAX);
-    if (count == 0) return out;
-    std::vector<std::uint32_t> desc(8 * count);
-    std::vector<float> x(count), y(count), r(count);
-    std::vector<std::int32_t> lo(count), hi(count);
-    for (std::size_t i = 0; i < count; ++i) {
-        const RadiusQuery &q = qs[first + i];
-        for (int k = 0; k < 8; ++k) desc[8 * i + k] = q.descriptor[k];
-        x[i] = q.x; y[i] = q.y; r[i] = q.radius; lo[i] = q.minOctave; hi[i] = q.maxOctave;
+struct Best2 { int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1; };
+inline int hamming256(const std::uint32_t *a, const std::uint32_t *b) { int d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; }
+inline void best2_update(Best2 &b, int idx, int dist, int level) {                        // keyframe_matcher.cpp:369-377
+    if (dist < b.bestDist) { b.bestDist2 = b.bestDist; b.bestDist = dist; b.bestLevel2 = b.bestLevel; b.bestLevel = level; b.best = idx; }
+    else if (dist < b.bestDist2) { b.bestLevel2 = level; b.bestDist2 = dist; }
+}
+// one query's whole scan on the host, against the CURRENT mask (the reference's loop :356-378 as it stands); a handful of queries per keyframe get here
+inline Best2 rescan_on_host(const DeviceKeyframe &kf, const ProjectionQuery &q, const std::vector<std::uint8_t> &bound) {
+    Best2 b;
+    for (std::int32_t j : q.candidates)
+        if (!bound[(std::size_t)j]) best2_update(b, j, hamming256(q.descriptor.data(), kf.hostDescriptor((std::size_t)j)), kf.hostOctave((std::size_t)j));
+    return b;
+}
+inline Best2 rescan_on_host(const DeviceKeyframe &kf, const RadiusQuery &q, const std::vector<std::uint8_t> &bound) {
+    // FeatureSearch::getFeaturesAround (feature_search.cpp:33-48) in float32, every operation rounded on its own (a product or sum formed in double and
+    // rounded to float IS the float32 result, so the compiler's contraction setting cannot change it) -- the same arithmetic as k_projection_candidates
+    const std::vector<float> &sx = kf.hostSortedX(), &sy = kf.hostSortedY();
+    const float ylo = q.y - q.radius, yhi = q.y + q.radius, r2 = (float)((double)q.radius * (double)q.radius);
+    Best2 b;
+    for (std::size_t pos = (std::size_t)(std::lower_bound(sy.begin(), sy.end(), ylo) - sy.begin()); pos < sy.size() && sy[pos] <= yhi; ++pos) {
+        const float dx = q.x - sx[pos], dy = q.y - sy[pos];
+        const float dx2 = (float)((double)dx * (double)dx), dy2 = (float)((double)dy * (double)dy);
+        if (!((float)((double)dx2 + (double)dy2) < r2)) continue;
+        const std::size_t j = (std::size_t)kf.hostSortedIndex()[pos];
+        if (bound[j] || kf.hostOctave(j) < q.minOctave || kf.hostOctave(j) > q.maxOctave) continue;
+        best2_update(b, (int)j, hamming256(q.descriptor.data(), kf.hostDescriptor(j)), kf.hostOctave(j));
     }
-    std::vector<void *> bufs;
-    auto up = [&](const void *src, std::size_t bytes) { void *d = nullptr; ctx.check(ms_dev_alloc(ctx.get(), bytes + 16, &d), "ms_dev_alloc"); bufs.push_back(d);
-                                                         if (bytes && src) { ctx.check(ms_dev_upload(ctx.get(), d, src, bytes), "ms_dev_upload"); }
-                                                         return d; };
-    void *dq = up(desc.data(), desc.size() * 4), *dx = up(x.data(), 4 * count), *dy = up(y.data(), 4 * count), *dr = up(r.data(), 4 * count);
-    void *dlo = up(lo.data(), 4 * count), *dhi = up(hi.data(), 4 * count), *dk = skip ? up(skip->data(), skip->size()) : nullptr;
-    void *b = up(nullptr, 4 * count), *bd = up(nullptr, 2 * count), *sd = up(nullptr, 2 * count), *bo = up(nullptr, 4 * count), *so = up(nullptr, 4 * count), *si = up(nullptr, 4 * count);
-    const ms_match_frame &f = kf.frame();
-    ctx.check(ms_projection_candidates(ctx.get(), kf.sortedX(), kf.sortedY(), kf.sortedIndex(), f.n, f.desc, f.octave, static_cast<const std::uint8_t *>(dk),
-                                       static_cast<const float *>(dx), static_cast<const float *>(dy), static_cast<const float *>(dr),
-                                       static_cast<const std::int32_t *>(dlo), static_cast<const std::int32_t *>(dhi), static_cast<const std::uint32_t *>(dq), (int)count,
-                                       static_cast<std::int32_t *>(b), static_cast<std::uint16_t *>(bd), static_cast<std::uint16_t *>(sd), static_cast<std::int32_t *>(bo),
-                                       static_cast<std::int32_t *>(so), static_cast<std::int32_t *>(si), nullptr), "ms_projection_candidates");
-    ctx.check(ms_dev_download(ctx.get(), out.best.data(), b, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.second.data(), si, 4 * count), "download");
-    ctx.check(ms_dev_download(ctx.get(), out.bestDist.data(), bd, 2 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondDist.data(), sd, 2 * count), "download");
-    ctx.check(ms_dev_download(ctx.get(), out.bestOctave.data(), bo, 4 * count), "download"); ctx.check(ms_dev_download(ctx.get(), out.secondOctave.data(), so, 4 * count), "download");
-    for (void *p : bufs) ms_dev_free(ctx.get(), p);
-    return out;
+    return b;
 }
 }  // namespace detail
 
 // Scoring + accept rule of searchByProjection (keyframe_matcher.cpp:349-389).  `bound[k]` != 0 marks keypoints that already
 // carry an observed map point (:358-360); it is updated as matches are accepted, in query order, exactly like the
-// reference's loop: all queries are scored in one launch against the initial mask, and a query whose best or second
-// candidate was taken by an earlier query of this call is re-scored (on the GPU) against the current mask.
+// reference's loop.  ONE launch scores every query against the initial mask and returns its four best candidates; the replay below
+// walks the queries in order and takes, per query, the first two list entries that no earlier query of this call has bound -- the
+// best and second best of the reference's scan over the keypoints still free (the scan order is the list's tie-break).  A query whose
+// list is too short for that (more than four candidates in all, and fewer than two of its four best still free: three of its four best
+// went to earlier map points of the same call) is scanned again on the host against the current mask (detail::rescan_on_host).
 // Returns, per query, the matched keypoint index or -1; the caller performs addObservation (:388-389).
 // `Query` is ProjectionQuery (candidate lists from the host's getFeaturesAround) or RadiusQuery (radius query on the device).
 template <class Query>
 inline std::vector<int> searchByProjectionCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<Query> &queries,
-                                               std::vector<std::uint8_t> &bound) {
+                                               std::vector<std::uint8_t> &bound, unsigned *rescored = nullptr) {
     std::vector<int> match(queries.size(), -1);
-    CandidateScores s = detail::score_candidates(ctx, kf, queries, &bound);
+    const CandidateLists s = detail::score_candidates(ctx, kf, queries, &bound);
     std::vector<std::uint8_t> taken(bound.size(), 0);            // bound during this call
+    unsigned again = 0;
     for (std::size_t i = 0; i < queries.size(); ++i) {
-        int best = s.best[i], bestDist = s.bestDist[i], bestDist2 = s.secondDist[i], bestLevel = s.bestOctave[i], bestLevel2 = s.secondOctave[i];
-        if ((best >= 0 && taken[best]) || (s.second[i] >= 0 && taken[s.second[i]])) {        // greedy state changed under this query
-            CandidateScores r = detail::score_candidates(ctx, kf, queries, &bound, i, 1);
-            best = r.best[0]; bestDist = r.bestDist[0]; bestDist2 = r.secondDist[0]; bestLevel = r.bestOctave[0]; bestLevel2 = r.secondOctave[0];
+        int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, found = 0;
+        auto walk = [&](const CandidateLists &l, std::size_t q) {
+            best = -1; bestDist = 256; bestDist2 = 256; bestLevel = -1; bestLevel2 = -1; found = 0;
+            for (int e = 0; e < 4 && found < 2; ++e) {
+                const int j = l.idx[4 * q + e];
+                if (j < 0) break;
+                if (taken[(std::size_t)j]) continue;
+                if (found == 0) { best = j; bestDist = l.dist[4 * q + e]; bestLevel = l.octave[4 * q + e]; }
+                else { bestDist2 = l.dist[4 * q + e]; bestLevel2 = l.octave[4 * q + e]; }
+                ++found;
+            }
+        };
+        walk(s, i);
+        if (found < 2 && s.nScored[i] > 4) {                       // the list ran out before the candidate set did
+            const detail::Best2 r = detail::rescan_on_host(kf, queries[i], bound);               // `bound` = initial mask + everything taken so far
+            best = r.best; bestDist = r.bestDist; bestDist2 = r.bestDist2; bestLevel = r.bestLevel; bestLevel2 = r.bestLevel2;
+            ++again;
         }
         if (best == -1) continue;                                                          // :380
         if (bestDist <= (int)HAMMING_DIST_THR_HIGH) {                                        // :382-383
             if (bestLevel == bestLevel2 && bestDist > 0.8 * bestDist2) continue;             // :385-386
-            match[i] = best; bound[best] = 1; taken[best] = 1;
+            match[i] = best; bound[(std::size_t)best] = 1; taken[(std::size_t)best] = 1;
         }
     }
+    if (rescored) *rescored = again;
     return match;
 }
 
@@ -238,9 +314,9 @@ inline std::vector<int> searchByProjectionCore(Context &ctx, const DeviceKeyfram
 // (:600-627: accept <= 100; the caller pre-filters candidates by octave, :611).  No greedy state in the scoring itself.
 template <class Query>
 inline std::vector<int> bestCandidateCore(Context &ctx, const DeviceKeyframe &kf, const std::vector<Query> &queries, unsigned maxDist) {
-    CandidateScores s = detail::score_candidates(ctx, kf, queries, nullptr);
+    const CandidateLists s = detail::score_candidates(ctx, kf, queries, nullptr);
     std::vector<int> match(queries.size(), -1);
-    for (std::size_t i = 0; i < queries.size(); ++i) if (s.best[i] >= 0 && s.bestDist[i] <= maxDist) match[i] = s.best[i];
+    for (std::size_t i = 0; i < queries.size(); ++i) if (s.idx[4 * i] >= 0 && s.dist[4 * i] <= maxDist) match[i] = s.idx[4 * i];
     return match;
 }
 

@@ -396,6 +396,41 @@ def projection_candidates(ctx, kp_x, kp_y, t_desc, q_x, q_y, q_r, q_desc, t_octa
     return tuple(o.download(d, (nq,)) for o, d in zip(outs, dts))
 
 
+def projection_topk(ctx, kp_x, kp_y, t_desc, q_x, q_y, q_r, q_desc, t_octave=None, t_skip=None, q_min_octave=None, q_max_octave=None):
+    """Radius query + the four best candidates per query (ms_projection_topk).  Returns (top_idx [nq,4], top_dist [nq,4], top_octave [nq,4], n_scored, n_candidates)."""
+    sx, sy, si = feature_search_sort(kp_x, kp_y)
+    t = np.ascontiguousarray(t_desc, np.uint32).reshape(-1, 8); q = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8)
+    nq, n = len(q), len(sx)
+    up = lambda a, dt: ctx.upload(np.ascontiguousarray(a, dt) if len(a) else np.zeros(4, dt))
+    dsx, dsy, dsi, dt_, dq = up(sx, np.float32), up(sy, np.float32), up(si, np.int32), ctx.upload(t if n else np.zeros((1, 8), np.uint32)), ctx.upload(q if nq else np.zeros((1, 8), np.uint32))
+    doc = None if t_octave is None else up(t_octave, np.int32)
+    dsk = None if t_skip is None else up(t_skip, np.uint8)
+    dqx, dqy, dqr = up(q_x, np.float32), up(q_y, np.float32), up(q_r, np.float32)
+    dlo = None if q_min_octave is None else up(q_min_octave, np.int32)
+    dhi = None if q_max_octave is None else up(q_max_octave, np.int32)
+    ti, td, to, ns, nc = ctx.alloc(16 * nq + 16), ctx.alloc(8 * nq + 16), ctx.alloc(16 * nq + 16), ctx.alloc(4 * nq + 16), ctx.alloc(4 * nq + 16)
+    ctx.check(lib().ms_projection_topk(ctx._h, _vp(dsx), _vp(dsy), _vp(dsi), n, _vp(dt_), _vp(doc), _vp(dsk), _vp(dqx), _vp(dqy), _vp(dqr), _vp(dlo), _vp(dhi),
+                                       _vp(dq), nq, _vp(ti), _vp(td), _vp(to), _vp(ns), _vp(nc)), "ms_projection_topk")
+    ctx.sync()
+    return (ti.download(np.int32, (nq, 4)), td.download(np.uint16, (nq, 4)), to.download(np.int32, (nq, 4)), ns.download(np.int32, (nq,)), nc.download(np.int32, (nq,)))
+
+
+def hamming_candidates_topk(ctx, q_desc, t_desc, cand_lists, t_skip=None, t_octave=None):
+    """The four best of each query's own candidate list (ms_hamming_candidates_topk): (top_idx [nq,4], top_dist [nq,4], top_octave [nq,4], n_scored)."""
+    q = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8); t = np.ascontiguousarray(t_desc, np.uint32).reshape(-1, 8)
+    nq = len(q)
+    start = np.zeros(nq + 1, np.int32)
+    start[1:] = np.cumsum([len(c) for c in cand_lists])
+    idx = np.concatenate([np.asarray(c, np.int32) for c in cand_lists] + [np.zeros(0, np.int32)]).astype(np.int32)
+    dq, dt, ds, di = ctx.upload(q), ctx.upload(t if len(t) else np.zeros((1, 8), np.uint32)), ctx.upload(start), ctx.upload(idx if len(idx) else np.zeros(1, np.int32))
+    dsk = ctx.upload(np.asarray(t_skip, np.uint8)) if t_skip is not None else None
+    doc = ctx.upload(np.asarray(t_octave, np.int32)) if t_octave is not None else None
+    ti, td, to, ns = ctx.alloc(16 * nq + 16), ctx.alloc(8 * nq + 16), ctx.alloc(16 * nq + 16), ctx.alloc(4 * nq + 16)
+    ctx.check(lib().ms_hamming_candidates_topk(ctx._h, _vp(dq), nq, _vp(dt), _vp(ds), _vp(di), _vp(dsk), _vp(doc), _vp(ti), _vp(td), _vp(to), _vp(ns)), "ms_hamming_candidates_topk")
+    ctx.sync()
+    return ti.download(np.int32, (nq, 4)), td.download(np.uint16, (nq, 4)), to.download(np.int32, (nq, 4)), ns.download(np.int32, (nq,))
+
+
 def descriptor_medoid(ctx, desc_pool, obs_lists):
     """MapPoint::updateDescriptor for many map points: obs_lists[p] = indices into desc_pool.  Returns (best_local, best_pool)."""
     pool = np.ascontiguousarray(desc_pool, np.uint32).reshape(-1, 8)

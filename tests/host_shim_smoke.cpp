@@ -1,6 +1,7 @@
 // Compile + link check of the host-side C++ mirrors against libmi355slam.so; when a GPU is present it also runs one
 // extraction, one triangulation match and one two-stage local BA end to end (used by tests/test_host_shims.py).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -166,6 +167,67 @@ int main(int argc, char **argv) {
         int nm = 0; for (int m : want) nm += m >= 0;
         std::printf("searchByProjection (device radius query): %d matches of %zu queries\n", nm, rq.size());
         if (got != want || bound != bound_ref || nm < 20) { std::printf("radius searchByProjectionCore mismatch\n"); return 8; }
+    }
+    // searchByProjection at the size a keyframe has (mapper_helpers.cpp:231-269): 2000 keypoints on 1280 x 720, 2000 map points that reproject near
+    // "their" keypoint with a 15 px radius, a third of them sharing their best keypoint with another map point (greedy conflicts); timed, and
+    // checked against the sequential restatement
+    {
+        unsigned rng = 4711u;
+        auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+        auto popc = [](const KeyPoint::Descriptor &a, const KeyPoint::Descriptor &b) { int d = 0; for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]); return d; };
+        KeyPointVector big(2000);
+        for (auto &k : big) {
+            k.pt = {(float)(rnd() % 12800) / 10.f, (float)(rnd() % 7200) / 10.f}; k.angle = 0; k.octave = (int)(rnd() % 8);
+            for (int w = 0; w < 8; ++w) k.descriptor[w] = (rnd() << 8) ^ rnd();
+        }
+        KeyframeFeatures fb; fb.keyPoints = &big; fb.usable.assign(big.size(), 1);
+        DeviceKeyframe dbig(ctx, fb);
+        std::vector<std::size_t> order(big.size());
+        for (std::size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](std::size_t a, std::size_t b) { return big[a].pt.y < big[b].pt.y; });
+        std::vector<RadiusQuery> rq;
+        for (int i = 0; i < 2000; ++i) {
+            const KeyPoint &k = big[i % 3 == 0 ? (std::size_t)(rnd() % 600) : (std::size_t)i];      // a third of the map points aim at one of 600 keypoints
+            RadiusQuery q; q.descriptor = k.descriptor;
+            for (int f = 0; f < 12; ++f) q.descriptor[rnd() % 8] ^= 1u << (rnd() % 32);
+            q.x = k.pt.x + (float)(rnd() % 7) - 3.f; q.y = k.pt.y + (float)(rnd() % 7) - 3.f; q.radius = 15.f;
+            rq.push_back(q);
+        }
+        std::vector<std::uint8_t> bound(big.size(), 0), bound_ref;
+        for (std::size_t k = 0; k < bound.size(); k += 9) bound[k] = 1;
+        bound_ref = bound;
+        const std::vector<std::uint8_t> bound0 = bound;
+        std::vector<int> want(rq.size(), -1);
+        int conflicts = 0;
+        {
+            std::vector<int> firstChoice(rq.size(), -1);
+            for (std::size_t i = 0; i < rq.size(); ++i) {
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, free0 = -1, free0d = 256;
+                for (std::size_t o : order) {
+                    const float dx = rq[i].x - big[o].pt.x, dy = rq[i].y - big[o].pt.y;
+                    if (big[o].pt.y < rq[i].y - rq[i].radius || !(big[o].pt.y <= rq[i].y + rq[i].radius) || !(dx * dx + dy * dy < rq[i].radius * rq[i].radius)) continue;
+                    const int dist = popc(rq[i].descriptor, big[o].descriptor), level = big[o].octave;
+                    if (!bound0[o] && dist < free0d) { free0d = dist; free0 = (int)o; }
+                    if (bound_ref[o]) continue;
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level; bestIdx = (int)o; }
+                    else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+                }
+                if (free0 >= 0 && free0 != bestIdx) ++conflicts;          // the keypoint it would have taken on an untouched keyframe is gone
+                if (bestIdx == -1) continue;
+                if (bestDist <= 100) { if (bestLevel == bestLevel2 && bestDist > 0.8 * bestDist2) continue; want[i] = bestIdx; bound_ref[bestIdx] = 1; }
+            }
+        }
+        unsigned rescored = 0;
+        std::vector<std::uint8_t> b1 = bound0;
+        std::vector<int> got = searchByProjectionCore(ctx, dbig, rq, b1, &rescored);       // warm-up (workspace allocation)
+        const auto t0 = std::chrono::steady_clock::now();
+        const int reps = 10;
+        for (int r = 0; r < reps; ++r) { b1 = bound0; got = searchByProjectionCore(ctx, dbig, rq, b1, &rescored); }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+        int nm = 0; for (int m : want) nm += m >= 0;
+        std::printf("searchByProjection 2000 map points x 2000 keypoints, radius 15 px: %d matches, %d queries lost their first choice to an earlier one, %u scored again, %.3f ms per call\n",
+                    nm, conflicts, rescored, ms);
+        if (got != want || b1 != bound_ref || nm < 1000 || conflicts < 300) { std::printf("searchByProjectionCore (keyframe size) mismatch\n"); return 17; }
     }
     // M5: matchMapPointsSim3 on two keyframes whose map points see each other (kf2 = kf1 shifted by (3, -2) px with a few bits flipped),
     // against a sequential restatement of keyframe_matcher.cpp:552-686 (radius query in y-sorted order, octave window, <= 100, seeds, mutual check)

@@ -329,3 +329,46 @@ def test_matrix_core_search_equals_popcount_search(ctx):
             for x, y in zip(a, b): assert np.array_equal(x, y)
     finally:
         L.ms_hamming_set_path(ctx._h, 0)
+
+
+def test_top4_candidate_lists(oracle, ctx):
+    """ms_projection_topk / ms_hamming_candidates_topk: per query the four smallest (distance, scan position) keys among the candidates that are
+    not skipped and inside the octave window -- the order the reference's strict-less scan induces (keyframe_matcher.cpp:356-378) -- and the
+    number of candidates scored.  The first two entries are exactly ms_projection_candidates' best / second."""
+    import mi355slam
+    rng = np.random.default_rng(5)
+    n, nq = 1500, 700
+    kx = rng.uniform(0, 640, n).astype(np.float32); ky = np.round(rng.uniform(0, 480, n)).astype(np.float32)      # rounded y: ties in the sort key
+    t = rng.integers(0, 2**32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    src = rng.integers(0, n, nq)
+    q = t[src] ^ np.packbits(rng.random((nq, 256)) < 0.05, axis=1, bitorder="little").view(np.uint32)
+    q[::5] &= 0xF; t[::3] &= 0xF                                                              # low-entropy rows: equal distances, position decides
+    qx = (kx[src] + rng.uniform(-6, 6, nq)).astype(np.float32); qy = (ky[src] + rng.uniform(-6, 6, nq)).astype(np.float32)
+    qr = rng.choice([0.5, 4.0, 12.0, 40.0, 90.0], nq).astype(np.float32)
+    toct = rng.integers(0, 8, n).astype(np.int32); skip = (rng.random(n) < 0.2).astype(np.uint8)
+    lo = rng.integers(0, 4, nq).astype(np.int32); hi = (lo + rng.integers(0, 5, nq)).astype(np.int32)
+    ti, td, to, ns, nc = mi355slam.projection_topk(ctx, kx, ky, t, qx, qy, qr, q, toct, skip, lo, hi)
+    bi, bd, sd, bo, so, si, nc2 = mi355slam.projection_candidates(ctx, kx, ky, t, qx, qy, qr, q, toct, skip, lo, hi)
+    assert np.array_equal(nc, nc2)
+    assert np.array_equal(ti[:, 0], bi) and np.array_equal(td[:, 0], bd) and np.array_equal(ti[:, 1], si) and np.array_equal(td[:, 1], sd)
+    sx, sy, sidx = mi355slam.feature_search_sort(kx, ky)
+    lists = []
+    for i in range(nq):
+        cand = oracle.features_around(sx, sy, qx[i], qy[i], qr[i])                            # positions in the sorted array, ascending
+        keep = [p for p in cand if not skip[sidx[p]] and lo[i] <= toct[sidx[p]] <= hi[i]]
+        d = [oracle.hamming256(q[i], t[sidx[p]]) for p in keep]
+        order = sorted(range(len(keep)), key=lambda k: (d[k], keep[k]))[:4]
+        assert ns[i] == len(keep) and nc[i] == len(cand)
+        want_i = [int(sidx[keep[k]]) for k in order] + [-1] * (4 - len(order)); want_d = [d[k] for k in order] + [256] * (4 - len(order))
+        assert list(ti[i]) == want_i and list(td[i]) == want_d, i
+        assert list(to[i]) == [int(toct[j]) if j >= 0 else -1 for j in want_i]
+        lists.append([int(sidx[p]) for p in cand])
+    assert (ns > 4).sum() > 100 and (ns == 0).sum() > 5
+    # the same lists handed over explicitly (the host's getFeaturesAround route)
+    ci, cd, co, cn = mi355slam.hamming_candidates_topk(ctx, q, t, lists, skip, toct)
+    for i in range(nq):
+        keep = [j for j in lists[i] if not skip[j]]
+        d = [oracle.hamming256(q[i], t[j]) for j in keep]
+        order = sorted(range(len(keep)), key=lambda k: (d[k], k))[:4]
+        assert cn[i] == len(keep)
+        assert list(ci[i]) == [keep[k] for k in order] + [-1] * (4 - len(order)) and list(cd[i]) == [d[k] for k in order] + [256] * (4 - len(order)), i
