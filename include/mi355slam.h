@@ -73,8 +73,19 @@ int ms_event_elapsed_ms(ms_ctx *ctx, int slot_a, int slot_b, float *ms);
 /* plain device memory helpers so a C caller needs no HIP headers */
 int ms_dev_alloc(ms_ctx *ctx, size_t bytes, void **out);
 int ms_dev_free(ms_ctx *ctx, void *p);
+/* Page-locked host memory for frames going in and results coming out: copies from / to it are truly asynchronous (the copy engines read it
+ * directly), which is what lets ms_orb_extract overlap a batch's copies with its kernels and ms_dev_download_async run under the next batch. */
+int ms_host_alloc(ms_ctx *ctx, size_t bytes, void **out);
+int ms_host_free(ms_ctx *ctx, void *p);
 int ms_dev_upload(ms_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ms_dev_download(ms_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* The same copy without waiting for it: it runs on a stream of its own, after everything enqueued on the context stream so far, while the context
+ * stream goes on (the next batch's kernels and copies run under it).  `dst` should be pinned host memory (pageable memory is staged by the runtime and
+ * the call then waits).  What the copy READS must stay intact until it is done: ms_orb_extract orders itself after the downloads issued so far (it
+ * is the call that overwrites the extractor's outputs, and everything enqueued after it is ordered behind it); other writers of the source are the
+ * caller's business.  ms_dev_download_wait blocks the host until every asynchronous download has arrived (ms_ctx_sync does, too). */
+int ms_dev_download_async(ms_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int ms_dev_download_wait(ms_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * S1/S2: pyramid geometry -- replaces StaticSettings (static_settings.cpp:9-60) and the level

@@ -26,6 +26,11 @@ void ranges_resolve() {
 void ms_range_push(const char *name) { if (g_ranges_on.load(std::memory_order_relaxed) && g_push) (void)g_push(name); }
 void ms_range_pop() { if (g_ranges_on.load(std::memory_order_relaxed) && g_pop) (void)g_pop(); }
 
+int ms_ctx_order_after_downloads(ms_ctx *c) {
+    if (c->d2h_pending) MS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_d2h_done, 0));
+    return MS_OK;
+}
+
 int ms_scratch(ms_ctx *c, size_t bytes, void **out) {
     if (bytes > c->scratch_bytes) {
         MS_HIP(c, hipStreamSynchronize(c->stream));
@@ -81,6 +86,9 @@ int ms_ctx_create(int device, ms_ctx **out) {
 void ms_ctx_destroy(ms_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
+    if (c->ev_d2h_gate) (void)hipEventDestroy(c->ev_d2h_gate);
+    if (c->ev_d2h_done) (void)hipEventDestroy(c->ev_d2h_done);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->scratch) (void)hipFree(c->scratch);
     for (auto &b : c->ba_cache) if (b.p) (void)hipFree(b.p);
@@ -93,6 +101,7 @@ void ms_ctx_destroy(ms_ctx *c) {
 int ms_ctx_sync(ms_ctx *c) {
     if (!c) return MS_ERR_INVALID;
     MS_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d2h_pending) { MS_HIP(c, hipStreamSynchronize(c->d2h_stream)); c->d2h_pending = false; }
     return MS_OK;
 }
 
@@ -142,10 +151,46 @@ int ms_dev_free(ms_ctx *c, void *p) {
     return MS_OK;
 }
 
+int ms_host_alloc(ms_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return MS_ERR_INVALID;
+    MS_HIP(c, hipSetDevice(c->device));
+    MS_HIP(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return MS_OK;
+}
+
+int ms_host_free(ms_ctx *c, void *p) {
+    if (!c) return MS_ERR_INVALID;
+    if (p) MS_HIP(c, hipHostFree(p));
+    return MS_OK;
+}
+
 int ms_dev_upload(ms_ctx *c, void *dst, const void *src, size_t bytes) {
     if (!c || (!dst && bytes) || (!src && bytes)) return MS_ERR_INVALID;
     MS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     MS_HIP(c, hipStreamSynchronize(c->stream));
+    return MS_OK;
+}
+
+int ms_dev_download_async(ms_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) return MS_ERR_INVALID;
+    if (!bytes) return MS_OK;
+    MS_HIP(c, hipSetDevice(c->device));
+    if (!c->d2h_stream) {
+        MS_HIP(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+        MS_HIP(c, hipEventCreateWithFlags(&c->ev_d2h_gate, hipEventDisableTiming));
+        MS_HIP(c, hipEventCreateWithFlags(&c->ev_d2h_done, hipEventDisableTiming));
+    }
+    MS_HIP(c, hipEventRecord(c->ev_d2h_gate, c->stream));               // after everything enqueued on the context stream so far
+    MS_HIP(c, hipStreamWaitEvent(c->d2h_stream, c->ev_d2h_gate, 0));
+    MS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->d2h_stream));
+    MS_HIP(c, hipEventRecord(c->ev_d2h_done, c->d2h_stream));
+    c->d2h_pending = true;
+    return MS_OK;
+}
+
+int ms_dev_download_wait(ms_ctx *c) {
+    if (!c) return MS_ERR_INVALID;
+    if (c->d2h_pending) { MS_HIP(c, hipStreamSynchronize(c->d2h_stream)); c->d2h_pending = false; }
     return MS_OK;
 }
 

@@ -22,8 +22,16 @@ struct ms_ctx {
     // device blocks of destroyed bundle-adjustment handles, kept for the next ms_ba_create on this context: a window per keyframe then allocates nothing after
     // warm-up (hipFree synchronises the whole device -- with one sequence per context that stalled every other sequence's stream once per keyframe)
     struct BaBlock { void *p = nullptr; size_t bytes = 0; } ba_cache[4];
+    // asynchronous downloads (ms_dev_download_async): a stream of their own, ordered after the work enqueued before them; work that overwrites what
+    // they read is ordered after them on the device (ms_ctx_order_after_downloads, called by ms_orb_extract)
+    hipStream_t d2h_stream = nullptr;
+    hipEvent_t ev_d2h_gate = nullptr, ev_d2h_done = nullptr;
+    bool d2h_pending = false;
     char err[512] = {0};
 };
+
+// makes the context stream wait (on the device) for the asynchronous downloads issued so far
+int ms_ctx_order_after_downloads(ms_ctx *ctx);
 
 // device scratch of at least `bytes`, reused across calls on the context stream
 int ms_scratch(ms_ctx *ctx, size_t bytes, void **out);

@@ -1076,6 +1076,11 @@ struct ms_orb {
     bool profiling = false;
     bool blur_valid = false;           // the blurred planes of the slab hold the last batch (k_blur runs on demand only)
     hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
+    // host frames come in as up to kChunks pieces on a stream of their own: piece k+1 is copied while the kernels of piece k run
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[4] = {nullptr}, ev_free[4] = {nullptr}, ev_end = nullptr;
+    int chunked_frames = 0;            // n_frames of the last chunked call (its ev_free[] mark the pieces of exactly that split); 0 = none
+    bool end_recorded = false;
     // state of the last call
     FrameSrc last_src{};
     int last_frames = 0;
@@ -1253,6 +1258,15 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     }
     if (rc == MS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
     if (rc != MS_OK) { ms_orb_destroy(o); return ms_fail(ctx, rc, "ms_orb_create: device allocation failed"); }
+    {   // the copy stream and its events (batches of host frames only; a one-frame extractor never uses them)
+        bool ok = hipEventCreateWithFlags(&o->ev_end, hipEventDisableTiming) == hipSuccess;
+        if (cfg->max_batch >= 32) {
+            ok = ok && hipStreamCreateWithFlags(&o->copy_stream, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 4 && ok; ++i)
+                ok = hipEventCreateWithFlags(&o->ev_copied[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&o->ev_free[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) { ms_orb_destroy(o); return ms_fail(ctx, MS_ERR_HIP, "ms_orb_create: stream / event creation failed"); }
+    }
     *out = o;
     return MS_OK;
 }
@@ -1269,6 +1283,9 @@ void ms_orb_destroy(ms_orb *o) {
     if (o->d_pattern_f) (void)hipFree(o->d_pattern_f);
     if (o->d_ftile_tab) (void)hipFree(o->d_ftile_tab);
     for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
+    if (o->copy_stream) { (void)hipStreamSynchronize(o->copy_stream); (void)hipStreamDestroy(o->copy_stream); }
+    for (int i = 0; i < 4; ++i) { if (o->ev_copied[i]) (void)hipEventDestroy(o->ev_copied[i]); if (o->ev_free[i]) (void)hipEventDestroy(o->ev_free[i]); }
+    if (o->ev_end) (void)hipEventDestroy(o->ev_end);
 
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
         if (o->d_xtab[l]) (void)hipFree(o->d_xtab[l]);
@@ -1321,62 +1338,32 @@ int ms_orb_extract(ms_orb *o, const uint8_t *images, int on_device, int n_frames
     return rc;
 }
 
-static int orb_extract_enqueue(ms_orb *o, const uint8_t *images, int on_device, int n_frames, size_t frame_stride, size_t row_stride,
-                               const float *track_xy, const int32_t *track_id, const int32_t *n_tracks, bool &counters_dirty) {
+// the kernels of one extract over frames [f0, f0 + nf) of the batch: every per-frame array is linear in the frame index, so a piece of the batch
+// is the same launches on offset pointers
+static int orb_enqueue_kernels(ms_orb *o, FrameSrc src, int f0, int nf, bool have_tracks, bool have_ids, bool &counters_dirty) {
     ms_ctx *c = o->ctx;
     const PyrGeom &G = o->geom;
-    if (n_frames < 1 || n_frames > o->cfg.max_batch) return ms_fail(c, MS_ERR_CAPACITY, "ms_orb_extract: n_frames %d outside [1,%d]", n_frames, o->cfg.max_batch);
-    if (row_stride < (size_t)G.width || frame_stride < row_stride * (size_t)(G.height - 1) + G.width)
-        return ms_fail(c, MS_ERR_INVALID, "ms_orb_extract: strides smaller than the frame");
-    MS_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    FrameSrc src{};
-    src.slab = o->d_slab;
-    const bool aligned = on_device && (reinterpret_cast<uintptr_t>(images) % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
-    if (aligned) {   // use the caller's frames in place as pyramid level 0 (image_pyramid.cpp:75 without the copy)
-        src.lvl0 = images; src.lvl0_frame_stride = frame_stride; src.lvl0_pitch = (int)row_stride;
-        o->lvl0_in_slab = false;
-    } else {
-        uint8_t *dst = o->d_slab + o->lvl0_off;
-        if (on_device) {
-            dim3 grid(ms_div_up(G.width, 256), G.height, n_frames);
-            hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, images, (uint64_t)frame_stride, (uint64_t)row_stride, o->d_slab,
-                               G.slab_stride, o->lvl0_off, G.width, G.height, o->lvl0_pitch);
-            MS_KERNEL_CHECK(c, "k_copy_level0");
-        } else {
-            for (int f = 0; f < n_frames; ++f) {
-                if (row_stride == (size_t)o->lvl0_pitch)            // rows as far apart on the host as in the slab: one linear copy per frame (the copy engines move these faster than pitched 2-D copies)
-                    MS_HIP(c, hipMemcpyAsync(dst + (size_t)f * G.slab_stride, images + (size_t)f * frame_stride, row_stride * (size_t)(G.height - 1) + G.width, hipMemcpyHostToDevice, st));
-                else
-                    MS_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * G.slab_stride, o->lvl0_pitch, images + (size_t)f * frame_stride, row_stride,
-                                               G.width, G.height, hipMemcpyHostToDevice, st));
-            }
-        }
-        src.lvl0 = dst; src.lvl0_frame_stride = G.slab_stride; src.lvl0_pitch = o->lvl0_pitch;
-        o->lvl0_in_slab = true;
-    }
-    const bool have_tracks = track_xy && n_tracks && o->cfg.max_tracks > 0;
-    if (have_tracks) {
-        const size_t T = o->cfg.max_tracks;
-        MS_HIP(c, hipMemcpyAsync(o->d_track_xy, track_xy, (size_t)n_frames * T * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-        MS_HIP(c, hipMemcpyAsync(o->d_n_tracks, n_tracks, (size_t)n_frames * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        if (track_id) MS_HIP(c, hipMemcpyAsync(o->d_track_id, track_id, (size_t)n_frames * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
-    // (d_cand_count is zero here: allocated zeroed, and k_select puts every counter it has consumed back to zero)
+    const size_t F = (size_t)f0, T = (size_t)o->cfg.max_tracks, L = (size_t)G.levels;
+    src.lvl0 += F * src.lvl0_frame_stride; src.slab += F * G.slab_stride;
+    uint32_t *cand = o->d_cand + F * G.cand_stride;
+    int32_t *cand_count = o->d_cand_count + F * L, *det_count = o->d_det_count + F * L, *trk_count = o->d_trk_count + F;
+    int16_t *det_x = o->d_det_x + F * G.det_stride, *det_y = o->d_det_y + F * G.det_stride;
+    uint8_t *det_score = o->d_det_score + F * G.det_stride;
     int stage = 0;
 #define MS_STAGE_MARK() do { if (o->profiling) MS_HIP(c, hipEventRecord(o->ev[stage++], st)); } while (0)
     MS_STAGE_MARK();
     MsRange pyramid_range("pyramid");
     for (int l = 1; l < G.levels; ++l) {
-        dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4 * kResizeRows), n_frames);
-        const ResizeTab T{o->d_xtab[l], o->d_ytab[l]};
+        dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4 * kResizeRows), nf);
+        const ResizeTab RT{o->d_xtab[l], o->d_ytab[l]};
         ResizeArgs RA{};
         if (l == 1) { RA.src = src.lvl0; RA.src_frame_stride = src.lvl0_frame_stride; RA.src_pitch = src.lvl0_pitch; }
         else { RA.src = src.slab + G.L[l - 1].img_off; RA.src_frame_stride = G.slab_stride; RA.src_pitch = G.L[l - 1].pitch; }
         RA.sw = G.L[l - 1].w;
         RA.dst = src.slab + G.L[l].img_off; RA.dst_frame_stride = G.slab_stride; RA.dst_pitch = G.L[l].pitch; RA.dw = G.L[l].w; RA.dh = G.L[l].h;
-        if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, RA, T);
-        else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, RA, T);
+        if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, RA, RT);
+        else hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, st, RA, RT);
         MS_KERNEL_CHECK(c, "k_resize");
     }
     pyramid_range.end();
@@ -1387,35 +1374,117 @@ static int orb_extract_enqueue(ms_orb *o, const uint8_t *images, int on_device, 
     MS_STAGE_MARK();
     MsRange detect_range("detect");
     counters_dirty = true;
-    hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, n_frames), dim3(kFastThreads), 0, st, src, o->d_geom, o->d_cand, o->d_cand_count, o->d_ftile_tab, o->tile_levels);
+    hipLaunchKernelGGL(k_fast, dim3(G.ftiles_total, nf), dim3(kFastThreads), 0, st, src, o->d_geom, cand, cand_count, o->d_ftile_tab, o->tile_levels);
     MS_KERNEL_CHECK(c, "k_fast");
     MS_STAGE_MARK();
-    const bool few = n_frames * G.levels <= 64;                     // a frame or a handful: one block per level is the whole launch -- give it 1024 threads
+    const bool few = nf * G.levels <= 64;                           // a frame or a handful: one block per level is the whole launch -- give it 1024 threads
     if (o->cfg.min_distance > 0.f) {
-        if (few) hipLaunchKernelGGL((k_select<true, 1024>), dim3(G.levels, n_frames), dim3(1024), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
-        else hipLaunchKernelGGL((k_select<true, 256>), dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+        if (few) hipLaunchKernelGGL((k_select<true, 1024>), dim3(G.levels, nf), dim3(1024), 0, st, o->d_geom, cand, cand_count, o->d_mask, det_x, det_y, det_score, det_count);
+        else hipLaunchKernelGGL((k_select<true, 256>), dim3(G.levels, nf), dim3(256), 0, st, o->d_geom, cand, cand_count, o->d_mask, det_x, det_y, det_score, det_count);
     } else {
-        if (few) hipLaunchKernelGGL((k_select<false, 1024>), dim3(G.levels, n_frames), dim3(1024), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
-        else hipLaunchKernelGGL((k_select<false, 256>), dim3(G.levels, n_frames), dim3(256), 0, st, o->d_geom, o->d_cand, o->d_cand_count, o->d_mask, o->d_det_x, o->d_det_y, o->d_det_score, o->d_det_count);
+        if (few) hipLaunchKernelGGL((k_select<false, 1024>), dim3(G.levels, nf), dim3(1024), 0, st, o->d_geom, cand, cand_count, o->d_mask, det_x, det_y, det_score, det_count);
+        else hipLaunchKernelGGL((k_select<false, 256>), dim3(G.levels, nf), dim3(256), 0, st, o->d_geom, cand, cand_count, o->d_mask, det_x, det_y, det_score, det_count);
     }
     MS_KERNEL_CHECK(c, "k_select");
     counters_dirty = false;
     MS_STAGE_MARK();
     if (o->cfg.max_tracks > 0) {                                    // (an extractor built without tracker features: d_trk_count stays at its initial zero)
-        hipLaunchKernelGGL(k_tracks, dim3(n_frames), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy : nullptr,
-                           (have_tracks && track_id) ? o->d_track_id : nullptr, have_tracks ? o->d_n_tracks : nullptr, o->d_mask,
-                           o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count);
+        hipLaunchKernelGGL(k_tracks, dim3(nf), dim3(64), 0, st, o->d_geom, have_tracks ? o->d_track_xy + F * T * 2 : nullptr,
+                           (have_tracks && have_ids) ? o->d_track_id + F * T : nullptr, have_tracks ? o->d_n_tracks + F : nullptr, o->d_mask,
+                           o->d_trk_x + F * T, o->d_trk_y + F * T, o->d_trk_px + F * T, o->d_trk_py + F * T, o->d_trk_id + F * T, trk_count);
         MS_KERNEL_CHECK(c, "k_tracks");
     }
     MS_STAGE_MARK();
     detect_range.end();
     MsRange describe_range("describe");
-    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), n_frames), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, o->d_det_x, o->d_det_y,
-                       o->d_det_count, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_trk_count, o->d_x, o->d_y,
-                       o->d_angle, o->d_octave, o->d_desc, o->d_track, o->d_count, G.levels);
+    const size_t C = (size_t)G.capacity;
+    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), nf), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, det_x, det_y,
+                       det_count, o->d_trk_x + F * T, o->d_trk_y + F * T, o->d_trk_px + F * T, o->d_trk_py + F * T, o->d_trk_id + F * T, trk_count, o->d_x + F * C, o->d_y + F * C,
+                       o->d_angle + F * C, o->d_octave + F * C, o->d_desc + F * C * 8, o->d_track + F * C, o->d_count + F, G.levels);
     MS_KERNEL_CHECK(c, "k_describe");
     MS_STAGE_MARK();
 #undef MS_STAGE_MARK
+    return MS_OK;
+}
+
+static int orb_extract_enqueue(ms_orb *o, const uint8_t *images, int on_device, int n_frames, size_t frame_stride, size_t row_stride,
+                               const float *track_xy, const int32_t *track_id, const int32_t *n_tracks, bool &counters_dirty) {
+    ms_ctx *c = o->ctx;
+    const PyrGeom &G = o->geom;
+    if (n_frames < 1 || n_frames > o->cfg.max_batch) return ms_fail(c, MS_ERR_CAPACITY, "ms_orb_extract: n_frames %d outside [1,%d]", n_frames, o->cfg.max_batch);
+    if (row_stride < (size_t)G.width || frame_stride < row_stride * (size_t)(G.height - 1) + G.width)
+        return ms_fail(c, MS_ERR_INVALID, "ms_orb_extract: strides smaller than the frame");
+    MS_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    MS_TRY(ms_ctx_order_after_downloads(c));               // asynchronous downloads of the previous outputs (ms_dev_download_async) finish before they are overwritten
+    FrameSrc src{};
+    src.slab = o->d_slab;
+    const bool have_tracks = track_xy && n_tracks && o->cfg.max_tracks > 0;
+    if (have_tracks) {
+        const size_t T = o->cfg.max_tracks;
+        MS_HIP(c, hipMemcpyAsync(o->d_track_xy, track_xy, (size_t)n_frames * T * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+        MS_HIP(c, hipMemcpyAsync(o->d_n_tracks, n_tracks, (size_t)n_frames * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (track_id) MS_HIP(c, hipMemcpyAsync(o->d_track_id, track_id, (size_t)n_frames * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    // (d_cand_count is zero here: allocated zeroed, and k_select puts every counter it has consumed back to zero)
+    const bool aligned = on_device && (reinterpret_cast<uintptr_t>(images) % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    if (aligned) {   // use the caller's frames in place as pyramid level 0 (image_pyramid.cpp:75 without the copy)
+        src.lvl0 = images; src.lvl0_frame_stride = frame_stride; src.lvl0_pitch = (int)row_stride;
+        o->lvl0_in_slab = false;
+        MS_TRY(orb_enqueue_kernels(o, src, 0, n_frames, have_tracks, track_id != nullptr, counters_dirty));
+    } else {
+        uint8_t *dst = o->d_slab + o->lvl0_off;
+        src.lvl0 = dst; src.lvl0_frame_stride = G.slab_stride; src.lvl0_pitch = o->lvl0_pitch;
+        o->lvl0_in_slab = true;
+        // frames whose rows are as far apart on the host as in the slab move as whole frames: one linear copy each, or ONE 2-D copy for a run of frames
+        // ("rows" = whole frames, host pitch = frame_stride, slab pitch = slab_stride) -- 256 x 21 us of per-frame copies were 5.4 ms of a 9.7 ms step
+        const bool whole = row_stride == (size_t)o->lvl0_pitch;
+        const size_t frame_bytes = row_stride * (size_t)(G.height - 1) + G.width;
+        auto copy_frames = [&](int f0, int nf, hipStream_t cs) -> int {
+            if (whole && nf > 1) {
+                MS_HIP(c, hipMemcpy2DAsync(dst + (size_t)f0 * G.slab_stride, G.slab_stride, images + (size_t)f0 * frame_stride, frame_stride, frame_bytes, nf, hipMemcpyHostToDevice, cs));
+            } else {
+                for (int f = f0; f < f0 + nf; ++f) {
+                    if (whole) MS_HIP(c, hipMemcpyAsync(dst + (size_t)f * G.slab_stride, images + (size_t)f * frame_stride, frame_bytes, hipMemcpyHostToDevice, cs));
+                    else MS_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * G.slab_stride, o->lvl0_pitch, images + (size_t)f * frame_stride, row_stride, G.width, G.height, hipMemcpyHostToDevice, cs));
+                }
+            }
+            return MS_OK;
+        };
+        const int kChunks = 4;
+        const bool chunked = !on_device && !o->profiling && n_frames >= 8 * kChunks && o->copy_stream != nullptr;
+        if (on_device) {
+            dim3 grid(ms_div_up(G.width, 256), G.height, n_frames);
+            hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, images, (uint64_t)frame_stride, (uint64_t)row_stride, o->d_slab,
+                               G.slab_stride, o->lvl0_off, G.width, G.height, o->lvl0_pitch);
+            MS_KERNEL_CHECK(c, "k_copy_level0");
+            MS_TRY(orb_enqueue_kernels(o, src, 0, n_frames, have_tracks, track_id != nullptr, counters_dirty));
+        } else if (!chunked) {
+            MS_TRY(copy_frames(0, n_frames, st));
+            MS_TRY(orb_enqueue_kernels(o, src, 0, n_frames, have_tracks, track_id != nullptr, counters_dirty));
+        } else {
+            // Piece k's kernels run under piece k+1's copy (the copy engine and the CUs work side by side; the design rule: copies on a stream of their own).
+            // A piece of the slab may be overwritten once the PREVIOUS call's kernels on it are done: its ev_free when that call was split the same way,
+            // else the end of that call.  With pinned host memory the call returns after enqueueing; pageable memory is staged by the runtime (correct, no overlap).
+            const int per = ms_div_up(n_frames, kChunks);
+            const bool same_split = o->chunked_frames == n_frames;      // (0 unless the LAST call was split: any other call resets it)
+            if (!same_split && o->end_recorded) MS_HIP(c, hipStreamWaitEvent(o->copy_stream, o->ev_end, 0));
+            for (int k = 0; k < kChunks; ++k) {
+                const int f0 = k * per, nf = std::min(per, n_frames - f0);
+                if (nf <= 0) break;
+                if (same_split) MS_HIP(c, hipStreamWaitEvent(o->copy_stream, o->ev_free[k], 0));
+                MS_TRY(copy_frames(f0, nf, o->copy_stream));
+                MS_HIP(c, hipEventRecord(o->ev_copied[k], o->copy_stream));
+                MS_HIP(c, hipStreamWaitEvent(st, o->ev_copied[k], 0));
+                MS_TRY(orb_enqueue_kernels(o, src, f0, nf, have_tracks, track_id != nullptr, counters_dirty));
+                MS_HIP(c, hipEventRecord(o->ev_free[k], st));
+            }
+            o->chunked_frames = n_frames;
+        }
+        if (!chunked) o->chunked_frames = 0;
+    }
+    if (aligned) o->chunked_frames = 0;
+    if (o->ev_end) { MS_HIP(c, hipEventRecord(o->ev_end, st)); o->end_recorded = true; }
     o->last_src = src;
     o->last_frames = n_frames;
     return MS_OK;

@@ -78,6 +78,7 @@ def _vp(x):
 class Context:
     def __init__(self, device=0):
         self._children = []          # weakrefs to objects that must be destroyed before the context
+        self._pinned = []            # page-locked host blocks handed out by pinned()
         self._h = C.c_void_p()
         rc = lib().ms_ctx_create(device, C.byref(self._h))
         if rc != 0:
@@ -120,6 +121,21 @@ class Context:
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
 
+    def pinned(self, shape, dtype=np.uint8):
+        """A numpy array in page-locked host memory (ms_host_alloc); freed with the context or by free_pinned()."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self.check(lib().ms_host_alloc(self._h, C.c_size_t(max(n, 1)), C.byref(p)), "ms_host_alloc")
+        self._pinned.append(p.value)
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free_pinned(self):
+        for p in self._pinned:
+            lib().ms_host_free(self._h, C.c_void_p(p))
+        self._pinned = []
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         b = DevBuf(self, arr.nbytes)
@@ -134,6 +150,8 @@ class Context:
                 if o is not None:
                     o.close()
             self._children = []
+            lib().ms_ctx_sync(self._h)
+            self.free_pinned()
             lib().ms_ctx_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -288,3 +288,51 @@ def test_keypoint_records_round_trip(oracle, ctx):
         assert (x, y, a, o1, o2) == (want[f]["x"][i], want[f]["y"][i], want[f]["angle"][i], want[f]["octave"][i], want[f]["octave"][i])
         assert (b0, b1, b2) == tuple(bearing[i]) and d == want[f]["desc"][i].tolist()
     assert np.array_equal(mi355slam.unpack_keypoints(ex.pack_keypoints(0))["bearing"], np.zeros((len(want[0]["x"]), 3)))     # no bearing given: zeros
+
+
+def test_host_batches_in_pieces_and_asynchronous_downloads(oracle, ctx):
+    """A batch of >= 32 host frames goes in as four pieces on a copy stream, each piece's kernels under the next piece's copy (frames whose rows are
+    contiguous move as ONE 2-D copy per piece, others frame by frame); ms_dev_download_async takes the outputs out on a third stream while the
+    next batch is already enqueued.  Every frame must equal what the same frames give when they are resident on the device -- and the oracle."""
+    import ctypes as C
+    import synth
+    import mi355slam
+    for (w, h, n, pad) in [(320, 192, 45, 0), (333, 222, 37, 5)]:          # 320 = slab pitch (whole-frame copies); 333: pitched 2-D copies per frame
+        frames = np.stack([synth.synth_frame(w, h, 300 + i, i % 5, i % 3) for i in range(n)])
+        host = np.zeros((n, h, w + pad), np.uint8); host[:, :, :w] = frames
+        ex = mi355slam.OrbExtractor(ctx, w, h, levels=5, max_kpts=600, max_batch=n)
+        cap = ex.capacity
+        lib = mi355slam.lib()
+        sizes = {"count": 4 * n, "x": 4 * n * cap, "y": 4 * n * cap, "angle": 4 * n * cap, "octave": 4 * n * cap, "desc": 32 * n * cap}
+        rounds = []
+        for rep in range(3):                                             # three batches back to back: the pieces of batch k+1 wait for batch k's kernels and downloads
+            src = ctx.pinned(host.shape)                                 # page-locked: the copies really are asynchronous
+            src[...] = np.roll(host, rep, axis=0)                        # a different frame order per round
+            ctx.check(lib.ms_orb_extract(ex._h, C.c_void_p(src.ctypes.data), 0, n, C.c_size_t(h * (w + pad)), C.c_size_t(w + pad), None, None, None), "ms_orb_extract")
+            v = ex.device_view()
+            outs = {k: ctx.pinned((b,)) for k, b in sizes.items()}
+            ptr = {"count": v.count, "x": v.x, "y": v.y, "angle": v.angle, "octave": v.octave, "desc": v.desc}
+            for k, b in sizes.items():
+                ctx.check(lib.ms_dev_download_async(ctx._h, C.c_void_p(outs[k].ctypes.data), C.c_void_p(ptr[k]), C.c_size_t(b)), "ms_dev_download_async")
+            rounds.append((src, outs))                                   # keep both alive until the copies are done
+        ctx.check(lib.ms_dev_download_wait(ctx._h), "ms_dev_download_wait")
+        ocfg = oracle.cfg(levels=5, max_kpts=600)
+        for rep, (src, outs) in enumerate(rounds):
+            cnt = outs["count"].view(np.int32)
+            for f in (0, 1, n // 4, n // 4 + 1, n // 2, n - 2, n - 1):  # frames on both sides of every piece boundary
+                want = oracle.orb_extract(ocfg, frames[(f - rep) % n])
+                k = cnt[f]
+                assert k == len(want["x"]) > 100
+                assert np.array_equal(outs["x"].view(np.float32).reshape(n, cap)[f, :k], want["x"])
+                assert np.array_equal(outs["y"].view(np.float32).reshape(n, cap)[f, :k], want["y"])
+                assert np.array_equal(outs["angle"].view(np.uint32).reshape(n, cap)[f, :k], want["angle"].view(np.uint32))
+                assert np.array_equal(outs["octave"].view(np.int32).reshape(n, cap)[f, :k], want["octave"])
+                assert np.array_equal(outs["desc"].view(np.uint32).reshape(n, cap, 8)[f, :k], want["desc"])
+        # the same frames resident on the device (one launch over the whole batch): identical counts for every frame
+        dev = ctx.upload(np.ascontiguousarray(frames))
+        if w % 16 == 0:
+            ex.extract(dev, n_frames=n, frame_stride=w * h, row_stride=w)
+            cnt_dev = np.array([len(ex.download(f)["x"]) for f in range(n)])
+            assert np.array_equal(cnt_dev, rounds[0][1]["count"].view(np.int32))
+        ex.close()
+        ctx.free_pinned()
