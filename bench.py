@@ -34,7 +34,7 @@ for _p in ("slam-module_amd", "tools", "tests"):
 W, H, LEVELS, SCALE, MAX_KPTS, FAST_THR, BATCH = 1280, 720, 8, 1.2, 2000, 20, 256
 LOWE_RATIO = 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")      # HBM bytes / instruction counts per launch of the committed build
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")      # HBM bytes / instruction counts per launch of the committed kernel sources
 N_SEQ = 8                      # C5: independent sequences of the whole job
 
 
@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--c5-frames", type=int, default=320, help="frames per sequence in the C5 leg")
     ap.add_argument("--c5-distinct", type=int, default=40, help="distinct images per sequence (walked forwards and backwards)")
     ap.add_argument("--c5-keyframe-every", type=int, default=5)
+    ap.add_argument("--c5-team", type=int, default=0, help="workgroups per BA window in the C5 leg (0 = by the number of sequences sharing the GPU)")
     ap.add_argument("--c5-native", action="store_true", help="drive the C5 sequences from C++ threads (tools/c5_native.cpp) instead of Python threads")
     ap.add_argument("--plumbing", action="store_true", help="no GPU work: launcher / rendezvous / aggregation only (gloo)")
     ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="with --plumbing: this rank exits with code 3 (launcher test)")
@@ -729,6 +730,11 @@ def bench_ba(R, ctx, args):
            "new_window_ms": round(new_window_ms, 3), "dtype": "f64", "two_stage": two_stage,
            "roofline": {"kernel": "k_ba_lm", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": pmc.get("hbm_bytes_per_launch") if pmc and not pmc.get("stale") else None,
+                        # fp64 issue: VALU wave-instructions of the launch (PMC, ~95 % of them fp64) x the 6.5 cycles at which ONE wave issues dependent-free
+                        # v_fma_f64 back to back (tools/valu_rates.hip), over the SIMD-cycles of the launch
+                        "fp64_issue_frac": round(pmc["SQ_INSTS_VALU_per_launch"] * (args.ba_batch / 256.0) * 6.5 / (1024 * 2.4e9 * kernel_ms * 1e-3), 3)
+                                           if pmc and not pmc.get("stale") and pmc.get("SQ_INSTS_VALU_per_launch") else None,
+                        "traffic_calibration": pmc.get("fetch_calibration") if pmc and not pmc.get("stale") else None,
                         "traffic_source": ((PMC_FILE + " (rocprofv3 --pmc passes of these kernel sources over the 256-window launch, tools/pmc_ba.sh)") if not pmc.get("stale")
                                            else (PMC_FILE + " was taken on other kernel sources than this tree's: traffic withheld")) if pmc else None}}
     if R.rank == 0 and not args.no_cpu_baseline:
@@ -1005,8 +1011,9 @@ class SequenceRunner(threading.Thread):
     previous frame -> ratio test; on every k-th frame (a keyframe) one local BA of a NEW C4-shaped window (create + solve + download).
     Own context (stream) and handles; nothing is batched across frames."""
 
-    def __init__(self, device, seq_id, frames_np, windows, kf_every, start_evt, on_frame=None, n_total=None):
+    def __init__(self, device, seq_id, frames_np, windows, kf_every, start_evt, on_frame=None, n_total=None, ba_team=0):
         super().__init__()
+        self.ba_team = ba_team                                   # workgroups per BA window (0 = the library's choice: up to 32)
         self.device, self.seq_id, self.frames_np, self.windows, self.kf_every, self.start_evt = device, seq_id, frames_np, windows, kf_every, start_evt
         self.n_total = n_total or len(frames_np)                 # frames of the sequence: the images are walked forwards and backwards (image_of)
         self.on_frame = on_frame                                 # tests only: called after every frame with the device results (synchronises)
@@ -1038,6 +1045,8 @@ class SequenceRunner(threading.Thread):
                 ba_out = None
                 if i % self.kf_every == 0 and self.windows:
                     b = mi355slam.BundleAdjuster(ctx, [self.windows[(i // self.kf_every) % len(self.windows)]], max_iters=10)
+                    if self.ba_team:
+                        b.set_team(self.ba_team)
                     b.solve(); ba_out = b.download(0); b.close()
                     if count:
                         self.ba_done += 1
@@ -1077,6 +1086,9 @@ def bench_c5(R, args):
         g = synth.SequenceSynth(W, H, 2000 + s, 2 * (FD - 1), FD - 1)
         seq_frames.append(np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(FD)])))
         seq_windows.append([] if args.no_ba else [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + 16 * s + k) for k in range(4)])
+    # (measured with 8 sequences on one GPU: teams of 32 / 16 / 8 / 4 workgroups per window give 4.4 k / 4.0 k / 3.2 k / 2.3 k frames/s -- a sequence waits for
+    # its own window, so the window's latency decides, not the CUs it leaves to the others)
+    ba_team = args.c5_team                     # 0 = the library's choice (up to 32 workgroups per window)
     native = _c5_native_lib() if args.c5_native else None
     if native is not None and mine:
         # the sequences' threads are C++ (tools/c5_native.cpp, the C ABI and nothing else).  Measured equal to the Python threads below (3.4 k frames/s + 690 BA/s
@@ -1105,7 +1117,7 @@ def bench_c5(R, args):
         del keep
     else:
         start = threading.Event()
-        runners = [SequenceRunner(R.local_rank, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start, n_total=F) for k, s in enumerate(mine)]
+        runners = [SequenceRunner(R.local_rank, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start, n_total=F, ba_team=ba_team) for k, s in enumerate(mine)]
         for r in runners:
             r.start()
         for r in runners:
@@ -1125,7 +1137,7 @@ def bench_c5(R, args):
     ba_total, _ = R.aggregate(ba_mine, dt)
     return {"workload": "8 independent 720p sequences x %d frames (%d distinct images each, walked forwards and backwards); per frame extract -> match vs previous -> ratio test; "
                         "every %d-th frame a local BA of a new C4 window (create + solve + download); sequence s on GPU s mod N, one host thread + context per sequence" % (F, FD, args.c5_keyframe_every),
-            "driver": driver,
+            "driver": driver, "ba_team": ba_team or "library default (up to 32)",
             "scaling": "strong (8 sequences in total)", "frames_per_s": round(frames_total / dt_max, 1), "ba_per_s": round(ba_total / dt_max, 1),
             "seconds": round(dt_max, 4), "per_gpu": [round(v, 1) for v in R.gather(frames_mine / dt)],
             "sequences_per_gpu": R.gather(len(mine)), "last_frame_matches": matches}

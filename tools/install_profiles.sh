@@ -9,6 +9,7 @@ cp $P/stats/p_kernel_stats.csv profiles/${T}_kernel_stats_full_command.csv
 cp $P/stats_headline/p_kernel_stats.csv profiles/${T}_kernel_stats_headline.csv
 cp $P/pmc_traffic.json profiles/${T%_*}_pmc_traffic.json
 cp $P/pmc_ba.json profiles/${T}_ba_pmc.json
+cp $P/pmc_calibration.json profiles/${T}_pmc_calibration.json 2>/dev/null || true
 for n in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT; do python3 - $P/pmc/$n/p_counter_collection.csv profiles/${T}_pmc_$n.csv <<'PY'
 import csv, sys, collections
 # condensed: per kernel and counter, dispatches and totals (the raw file has one row per dispatch and counter)
