@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--only-ba", action="store_true", help="local-BA leg only (profiling runs): prints its object as the line")
     ap.add_argument("--ba-batch", type=int, default=256)
     ap.add_argument("--ba-steps", type=int, default=3)
+    ap.add_argument("--no-ba-two-stage", action="store_true", help="skip the two-stage schedule of the local-BA leg (counter passes: only the single-stage 256-window launches)")
     ap.add_argument("--c5-frames", type=int, default=320, help="frames per sequence in the C5 leg")
     ap.add_argument("--c5-distinct", type=int, default=40, help="distinct images per sequence (walked forwards and backwards)")
     ap.add_argument("--c5-keyframe-every", type=int, default=5)
@@ -719,7 +720,7 @@ def bench_ba(R, ctx, args):
     for i in range(n_new):
         b = mi355slam.BundleAdjuster(ctx, [probs[i % len(probs)]], max_iters=10); b.solve(); b.download(0); b.close()
     new_window_ms = (time.perf_counter() - t1) / n_new * 1e3
-    two_stage = bench_ba_two_stage(R, ctx, args, probs)
+    two_stage = None if args.no_ba_two_stage else bench_ba_two_stage(R, ctx, args, probs)
     alg_bytes_per_launch = 6.61e6 * trials * args.ba_batch    # 6.61 MB per LM iteration (= per damped solve) at C4
     achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     pmc = pmc_of("k_ba_lm")

@@ -26,6 +26,11 @@ __global__ __launch_bounds__(256) void k_calib_strided8(const double *__restrict
     if (threadIdx.x == 0) out[blockIdx.x] = 1;
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void k_calib_write(T *__restrict__ dst, size_t n, T v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
+}
+
 int main() {
     const size_t bytes = (size_t)1 << 30;
     void *buf = nullptr; uint32_t *out = nullptr;
@@ -37,6 +42,10 @@ int main() {
         hipLaunchKernelGGL(k_calib_stream<uint2>, dim3(grid), dim3(256), 0, 0, static_cast<const uint2 *>(buf), bytes / 8, out);
         hipLaunchKernelGGL(k_calib_stream<uint4>, dim3(grid), dim3(256), 0, 0, static_cast<const uint4 *>(buf), bytes / 16, out);
         hipLaunchKernelGGL(k_calib_strided8, dim3(grid), dim3(256), 0, 0, static_cast<const double *>(buf), bytes / 64, out);
+    }
+    for (int rep = 0; rep < 3; ++rep) {                    // stores: the same 1 GiB written once with 4- and 16-byte stores per lane
+        hipLaunchKernelGGL(k_calib_write<uint32_t>, dim3(grid), dim3(256), 0, 0, static_cast<uint32_t *>(buf), bytes / 4, 1u);
+        hipLaunchKernelGGL(k_calib_write<uint4>, dim3(grid), dim3(256), 0, 0, static_cast<uint4 *>(buf), bytes / 16, make_uint4(1, 2, 3, 4));
     }
     CK(hipDeviceSynchronize());
     std::printf("known bytes per launch: stream 4 / 8 / 16 B per lane = %zu each; strided 8 B = %zu useful, %zu in touched 64-byte halves, %zu in touched 128-byte lines\n",

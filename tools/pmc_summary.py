@@ -7,6 +7,16 @@ import collections, csv, glob, json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import build_id
 root, out = sys.argv[1], sys.argv[2]
+# FETCH_SIZE on gfx950 counts a fetched 128-byte line as 64 bytes: tools/fetch_calib.hip (1 GiB read with 4 / 8 / 16-byte loads per lane and with strided 8-byte
+# loads) measures bytes fetched = 2.0 x FETCH_SIZE for every access width, WRITE_SIZE exact.  The factor comes from that run's pmc_calibration.json when it
+# lies next to the output, else the measured 2.0.
+FETCH_FACTOR = 2.0
+try:
+    cal = json.load(open(os.path.join(os.path.dirname(os.path.abspath(out)), "pmc_calibration.json")))["kernels"]
+    fs = [v["factor_known_over_counter"] for k, v in cal.items() if k.startswith("str") and v.get("factor_known_over_counter")]
+    if fs: FETCH_FACTOR = sum(fs) / len(fs)
+except Exception:
+    pass
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -20,12 +30,14 @@ res = {}
 for k, cs in sorted(acc.items()):
     e = {c + "_per_step": round(v / steps, 1) for c, v in cs.items()}
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        e["hbm_bytes_per_step"] = int((cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024 / steps)
+        e["hbm_bytes_per_step"] = int((FETCH_FACTOR * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024 / steps)
+        e["hbm_bytes_per_step_uncorrected"] = int((cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024 / steps)
     e["launches_per_step"] = round(max(launches[k].values()) / steps, 2)
     res[k] = e
 json.dump({"note": "rocprofv3 --pmc passes (one counter group per run, --kernel-trace only) of `bench.py --steps 2 --warmup 1 --only-headline`, "
-                   "256 frames per step; summed over a step's launches of each kernel.  FETCH_SIZE / WRITE_SIZE in KiB as reported, no x2 correction: "
-                   "these kernels load 4 B per lane and k_blur, whose byte count is known (each level byte once + a 6-row halo per 8 rows through L2), "
-                   "reads ~1.08x it, so the half-count artefact of 16 B/lane streams does not apply.  SQ_INSTS_* are wave-level instruction counts.",
+                   "256 frames per step; summed over a step's launches of each kernel.  FETCH_SIZE / WRITE_SIZE are KiB; hbm_bytes = FETCH_SIZE x %.2f + WRITE_SIZE: "
+                   "the calibration run (tools/fetch_calib.hip, pmc_calibration.json) shows FETCH_SIZE counting half of the bytes fetched at every access width "
+                   "(4, 8, 16 B per lane, strided 8 B) and WRITE_SIZE exact -- rounds 1 and 2 quoted the uncorrected sum.  SQ_INSTS_* are wave-level instruction counts." % FETCH_FACTOR,
+           "fetch_factor": FETCH_FACTOR,
            "steps_seen": steps, "src_sha256": build_id.source_hash(), "kernels": res}, open(out, "w"), indent=1)
 print("wrote", out, "steps", steps)

@@ -9,6 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+if [ -z "$SKIP_HEAD" ]; then      # SKIP_HEAD=1: the bench line, the kernel stats and the front-end counter passes are already in $O; do the calibration and the BA passes
 python3 "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err"
 echo "bench done"
 rocprofv3 --kernel-trace --stats -d "$O/stats" -o p --output-format csv -- python3 "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/rocprof.err"
@@ -23,14 +24,23 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   echo "pmc $name done"
 done
 python3 "$R/tools/pmc_summary.py" "$O/pmc" "$O/pmc_traffic.json"
+fi
 # what FETCH_SIZE / WRITE_SIZE report for loads of known size (tools/fetch_calib.hip): the factors the BA traffic below is corrected with
 hipcc --offload-arch=gfx950 -O2 "$R/tools/fetch_calib.hip" -o "$O/fetch_calib" 2>> "$O/rocprof.err" && \
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE -d "$O/pmc_calib" -o p --output-format csv -- "$O/fetch_calib" > "$O/fetch_calib.log" 2>> "$O/rocprof.err" || echo "calibration pass failed"
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/pmc_calib" -o p --output-format csv -- "$O/fetch_calib" > "$O/fetch_calib.log" 2>> "$O/rocprof.err" || echo "calibration pass failed"
+timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/pmc_calib_w" -o p --output-format csv -- "$O/fetch_calib" >> "$O/fetch_calib.log" 2>> "$O/rocprof.err" || echo "write calibration pass failed"
+echo "calibration done"
 python3 - "$O/pmc_calib" "$O/pmc_calibration.json" <<'PY'
 import csv, glob, json, os, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+wacc = collections.defaultdict(list)
+for f in glob.glob(os.path.join(sys.argv[1] + "_w", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_calib_write" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE":
+            wacc["write16" if ", 4u>" in r["Kernel_Name"] or "uint4" in r["Kernel_Name"] else "write4"].append(float(r["Counter_Value"]))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
+        if "k_calib_write" in r["Kernel_Name"]: continue
         if "k_calib" in r["Kernel_Name"]:
             kn = r["Kernel_Name"]
             name = "strided8" if "strided8" in kn else ("stream16" if ", 4u>" in kn or ",4u>" in kn or "uint4" in kn else ("stream8" if ", 2u>" in kn or ",2u>" in kn or "uint2" in kn else "stream4"))
@@ -40,25 +50,23 @@ res = {}
 for k, cs in acc.items():
     fetch = sum(cs["FETCH_SIZE"]) / max(len(cs["FETCH_SIZE"]), 1) * 1024
     res[k] = {"known_bytes": GiB, "FETCH_SIZE_bytes": fetch, "factor_known_over_counter": round(GiB / fetch, 3) if fetch else None, "launches": len(cs["FETCH_SIZE"])}
-json.dump({"note": "tools/fetch_calib.hip under rocprofv3 --pmc FETCH_SIZE WRITE_SIZE: 1 GiB read once with coalesced 4 / 8 / 16-byte loads per lane, and 128 MiB of doubles read at a "
+for k, v in wacc.items():
+    wb = sum(v) / len(v) * 1024
+    res[k] = {"known_bytes": GiB, "WRITE_SIZE_bytes": wb, "factor_known_over_counter": round(GiB / wb, 3) if wb else None, "launches": len(v)}
+json.dump({"note": "tools/fetch_calib.hip under rocprofv3 --pmc FETCH_SIZE (one counter per pass): 1 GiB read once with coalesced 4 / 8 / 16-byte loads per lane, and 128 MiB of doubles read at a "
                    "64-byte stride (every 64-byte half of the same 1 GiB touched).  factor = bytes really fetched / (FETCH_SIZE x 1024).", "kernels": res}, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(res))
 PY
 # the local-BA launch (k_ba_lm) has passes of its own; its per-launch averages join the same file under kernels.k_ba_lm
 bash "$R/tools/pmc_ba.sh" "$O/pmc_ba.json" > "$O/pmc_ba.log" 2>&1 || true
+[ -f "$O/pmc_traffic.json" ] || { echo "no front-end summary in $O (SKIP_HEAD run): merge pmc_ba.json / pmc_calibration.json into it where it is"; exit 0; }
 python3 - "$O/pmc_traffic.json" "$O/pmc_ba.json" <<'PY'
 import json, sys
 t = json.load(open(sys.argv[1])); b = json.load(open(sys.argv[2]))
 try:
     import os
     cal = json.load(open(os.path.join(os.path.dirname(sys.argv[1]), "pmc_calibration.json")))["kernels"]
-    f = {k: v["factor_known_over_counter"] for k, v in cal.items()}
-    b["fetch_calibration"] = {"factors_known_over_counter": f,
-                              "note": "FETCH_SIZE x factor = bytes fetched; the BA kernel mixes 8-byte gathers (strided8) and 16-byte streams (stream16): its fetched bytes lie between "
-                                      "FETCH_SIZE x min and x max of those two factors"}
-    if "FETCH_SIZE_per_launch" in b and f.get("strided8") and f.get("stream16"):
-        lo, hi = sorted([f["strided8"], f["stream16"]])
-        b["hbm_bytes_per_launch_calibrated_range"] = [int((b["FETCH_SIZE_per_launch"] * lo + b["WRITE_SIZE_per_launch"]) * 1024), int((b["FETCH_SIZE_per_launch"] * hi + b["WRITE_SIZE_per_launch"]) * 1024)]
+    b["fetch_calibration"] = {k: v["factor_known_over_counter"] for k, v in cal.items()}
 except Exception as e:
     b["fetch_calibration"] = {"error": str(e)}
 t["kernels"]["k_ba_lm"] = b
