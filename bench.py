@@ -221,7 +221,7 @@ def cpu_baseline_frames(frames):
                           "sample": "%d frames in runs of 8 over %d host threads (the oracle's C code runs outside the GIL)" % (nall, cores)}}
 
 
-def cpu_baseline_ba(problems):
+def cpu_baseline_ba(problems, pose_problems=None):
     mso = _oracle()
     cores = host_cores()
     n1 = 32
@@ -230,7 +230,8 @@ def cpu_baseline_ba(problems):
     rall = _pool_rate(lambda p: mso.ba_solve(p, 10, False), [problems[i % len(problems)] for i in range(nall)], cores)
     return {"value": round(r1, 2), "unit": "solves/s", "cores": 1, "kind": "port",
             "sample": "%d solves of distinct C4 windows, oracle/libmso.so (Schur + dense Cholesky, fp64), 1 thread" % n1,
-            "all_cores": {"value": round(rall, 2), "unit": "solves/s", "cores": cores, "sample": "%d solves over %d host threads" % (nall, cores)}}
+            "all_cores": {"value": round(rall, 2), "unit": "solves/s", "cores": cores, "sample": "%d solves over %d host threads" % (nall, cores)},
+            "pose_only_ms_per_solve_1_thread": round(1e3 / _pool_rate(lambda p: mso.ba_solve(p, 10, False), pose_problems, 1), 4) if pose_problems else None}
 
 
 # ------------------------------------------------------------------------------------------------------------------ rank
@@ -721,6 +722,26 @@ def bench_ba(R, ctx, args):
         b = mi355slam.BundleAdjuster(ctx, [probs[i % len(probs)]], max_iters=10); b.solve(); b.download(0); b.close()
     new_window_ms = (time.perf_counter() - t1) / n_new * 1e3
     two_stage = None if args.no_ba_two_stage else bench_ba_two_stage(R, ctx, args, probs)
+    # poseBundleAdjust (bundle_adjuster.cpp:396-491; runs on every non-keyframe, mapper_helpers.cpp:1043-1050): one free keyframe, its map points fixed, the odometry
+    # edge to the fixed previous keyframe -- k_ba_pose_only.  One problem per call (what a frame pays) and 256 of them in one launch
+    pose_probs = [ba_synth.pose_only_from_window(probs[i % len(probs)], 25) for i in range(256)]
+    pb = mi355slam.BundleAdjuster(ctx, pose_probs[:1], max_iters=10)
+    pb.solve(); ctx.sync(); ctx.event_mark(4)
+    for _ in range(10):
+        pb.solve()
+    ctx.event_mark(5)
+    pose_one_ms = ctx.event_elapsed_ms(4, 5) / 10
+    pstats = pb.download(0)["stats"]; pb.close()
+    t1 = time.perf_counter()
+    for i in range(10):
+        b = mi355slam.BundleAdjuster(ctx, [pose_probs[i]], max_iters=10); b.solve(); b.download(0); b.close()
+    pose_new_ms = (time.perf_counter() - t1) / 10 * 1e3
+    pbb = mi355slam.BundleAdjuster(ctx, pose_probs, max_iters=10)
+    pbb.solve(); ctx.sync(); ctx.event_mark(4); pbb.solve(); ctx.event_mark(5)
+    pose_batch_ms = ctx.event_elapsed_ms(4, 5); pbb.close()
+    pose_only = {"workload": "one free keyframe, %d fixed map points / observations, odometry edge to the fixed previous keyframe, 10 iterations" % len(pose_probs[0]["obs_pose"]),
+                 "ms_per_solve": round(pose_one_ms, 4), "new_problem_ms": round(pose_new_ms, 4), "iterations_trials": [pstats["iters"], pstats["trials"]],
+                 "batch_of_256_ms": round(pose_batch_ms, 4), "batch_solves_per_s": round(256 / pose_batch_ms * 1e3, 1)}
     alg_bytes_per_launch = 6.61e6 * trials * args.ba_batch    # 6.61 MB per LM iteration (= per damped solve) at C4
     achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     pmc = pmc_of("k_ba_lm")
@@ -728,7 +749,7 @@ def bench_ba(R, ctx, args):
            "unit": "solves/s", "windows_per_launch": args.ba_batch, "distinct_windows": len(probs), "ms_per_launch": round(kernel_ms, 3),
            "lm_iterations": round(iters, 2), "lm_trials": round(trials, 2),
            "single_window_ms": round(single_ms, 3), "single_window_solves_per_s": round(1e3 / single_ms, 1),
-           "new_window_ms": round(new_window_ms, 3), "dtype": "f64", "two_stage": two_stage,
+           "new_window_ms": round(new_window_ms, 3), "dtype": "f64", "two_stage": two_stage, "pose_only": pose_only,
            "roofline": {"kernel": "k_ba_lm", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": pmc.get("hbm_bytes_per_launch") if pmc and not pmc.get("stale") else None,
                         # fp64 issue: VALU wave-instructions of the launch (PMC, ~95 % of them fp64) x the 6.5 cycles at which ONE wave issues dependent-free
@@ -739,7 +760,7 @@ def bench_ba(R, ctx, args):
                         "traffic_source": ((PMC_FILE + " (rocprofv3 --pmc passes of these kernel sources over the 256-window launch, tools/pmc_ba.sh)") if not pmc.get("stale")
                                            else (PMC_FILE + " was taken on other kernel sources than this tree's: traffic withheld")) if pmc else None}}
     if R.rank == 0 and not args.no_cpu_baseline:
-        R.deferred.append((res, lambda: cpu_baseline_ba(probs[:32])))
+        R.deferred.append((res, lambda: cpu_baseline_ba(probs[:32], pose_probs[:32])))
     ba.close(); one.close()
     return res
 

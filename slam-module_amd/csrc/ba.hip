@@ -2447,6 +2447,244 @@ __global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
     }
 }
 
+// ---------------------------------------------------------------- pose-only problems: poseBundleAdjust (bundle_adjuster.cpp:396-491)
+// ONE free pose, every point fixed: the projection edges of the current frame (+ the odometry edge to the fixed previous keyframe, :440-447) give a 6 x 6
+// system per trial.  The general kernel walks such a problem through ~20 phases with a workgroup barrier and a round trip to memory each (0.47 ms for
+// 12 iterations of a 6-dof problem -- and poseBundleAdjust runs on EVERY non-keyframe, mapper_helpers.cpp:1043-1050); here a 256-thread workgroup keeps
+// the trial in registers: one sweep over the observations accumulates H (21 entries), b and the robust chi2 per thread, one reduction, lane 0 factors the
+// 6 x 6 matrix, one more sweep gives the chi2 of the moved pose.  Same LM schedule, same arithmetic per edge as k_ba_lm.
+constexpr int PO_NT = 256, PO_K = 8, PO_MAXE = 8;       // threads; observations a thread keeps in registers; SE3 edges with constants in LDS
+__device__ __forceinline__ void po_block_sum(double v, double *s_w, int slot) {      // s_w: [4 waves][32 slots]
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) s_w[(threadIdx.x >> 6) * 32 + slot] = v;
+}
+
+__global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
+    __shared__ double s_w[4 * 32], s_sum[32];
+    __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
+    __shared__ int s_eSide[PO_MAXE], s_ne;
+    const BaProb &P = probs[blockIdx.x];
+    const int tid = threadIdx.x, pi = P.free2pose[0];
+    for (int i = tid; i < 7 * P.n_pose; i += PO_NT) P.pose[i] = P.pose0[i];
+    for (int i = tid; i < 3 * P.n_point; i += PO_NT) P.point[i] = P.point0[i];
+    if (tid < 24) s_Hc[tid] = 0;
+    if (tid == 0) { s_ne = 0; s_const = 0; }
+    __syncthreads();
+    double pose[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) pose[a] = P.pose0[7 * (size_t)pi + a];
+    // ---- what never changes: the observations of the free pose go into registers (PO_K per thread), the others' chi2 and the edges between fixed poses
+    //      into one constant; an edge that touches the free pose leaves its fixed side's transform, -J^T W and J^T W J in LDS (its Jacobian does not depend
+    //      on the free pose: Ji = adj(Tj^-1 M), Jj = -adj(Ti^-1 M^-1)), so a sweep only takes its logarithm
+    double X[PO_K][3], uv[PO_K][2], info[PO_K], cacc = 0;
+    unsigned have = 0;
+#pragma unroll
+    for (int j = 0; j < PO_K; ++j) {
+        const int o = tid + PO_NT * j;
+        X[j][0] = X[j][1] = X[j][2] = uv[j][0] = uv[j][1] = info[j] = 0;
+        if (o < P.n_obs) {
+            const int po = P.obs_pose[o], l = P.obs_point[o];
+            if (po == pi) {
+                have |= 1u << j;
+                X[j][0] = P.point0[3 * (size_t)l]; X[j][1] = P.point0[3 * (size_t)l + 1]; X[j][2] = P.point0[3 * (size_t)l + 2];
+                uv[j][0] = P.obs_uv[2 * (size_t)o]; uv[j][1] = P.obs_uv[2 * (size_t)o + 1]; info[j] = P.obs_info[o];
+            }
+        }
+    }
+    for (int o = tid; o < P.n_obs; o += PO_NT) {                            // observations from FIXED poses: constant
+        const int po = P.obs_pose[o];
+        if (po == pi) continue;
+        double e[2], r, w;
+        proj_edge<false>(P.pose0 + 7 * (size_t)po, P.point0 + 3 * (size_t)P.obs_point[o], P.obs_uv + 2 * (size_t)o, e, nullptr, nullptr);
+        const double chi2 = P.obs_info[o] * (e[0] * e[0] + e[1] * e[1]);
+        huber(chi2, P.huber, r, w);
+        P.chi2_obs[o] = chi2;
+        cacc += r;
+    }
+    if (tid < P.n_edge) {
+        const int k = tid, vi = P.edge_i[k], vj = P.edge_j[k];
+        const double *W = P.edge_info + 36 * (size_t)k;
+        double e[6], Ji[36], Jj[36];
+        pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+        if (vi != pi && vj != pi) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j]; }
+        else {
+            const int sl = atomicAdd(&s_ne, 1), side = vi == pi ? 0 : 1;
+            const double *J = side ? Jj : Ji;
+            s_eSide[sl] = side;
+            if (side == 0) { double Tjinv[7], A2[7]; se3_inv(P.pose0 + 7 * (size_t)vj, Tjinv); se3_mul(Tjinv, P.edge_meas + 7 * (size_t)k, A2); for (int i = 0; i < 7; ++i) s_eC[sl][i] = A2[i]; }
+            else for (int i = 0; i < 7; ++i) { s_eC[sl][i] = P.pose0[7 * (size_t)vi + i]; s_eM[sl][i] = P.edge_meas[7 * (size_t)k + i]; }
+            for (int i = 0; i < 36; ++i) s_eW[sl][i] = W[i];
+            for (int a = 0; a < 6; ++a)                                     // G = -J^T W
+                for (int c = 0; c < 6; ++c) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += J[6 * r2 + a] * W[6 * r2 + c]; s_eG[sl][6 * a + c] = -v; }
+            int kk = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b2 = a; b2 < 6; ++b2) {
+                    double v = 0;
+                    for (int r2 = 0; r2 < 6; ++r2) { double m = 0; for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * J[6 * c2 + b2]; v += J[6 * r2 + a] * m; }
+                    lds_addd((MS_LDS double *)&s_Hc[kk++], v);
+                }
+        }
+    }
+    cacc = wave_sum_d(cacc);
+    if ((tid & 63) == 0) lds_addd((MS_LDS double *)&s_const, cacc);
+    __syncthreads();
+    const int ne = s_ne;
+    // ---- one sweep over the free pose's edges: robust chi2, and (lin) the upper triangle of H and b
+    auto sweep = [&](bool lin, bool store) {
+        double A[21], g[6], acc = 0;
+#pragma unroll
+        for (int a = 0; a < 21; ++a) A[a] = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) g[a] = 0;
+        auto one = [&](const double *Xo, const double *uvo, double inf, int o) {
+            double e[2], Jp[12], Jl[6];
+            if (lin) proj_edge<true>(pose, Xo, uvo, e, Jp, Jl); else proj_edge<false>(pose, Xo, uvo, e, nullptr, nullptr);
+            const double chi2 = inf * (e[0] * e[0] + e[1] * e[1]);
+            double r, w;
+            huber(chi2, P.huber, r, w);
+            if (store) P.chi2_obs[o] = chi2;
+            acc += r;
+            if (lin) {
+                const double wi = w * inf;
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    g[a] += -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi;
+#pragma unroll
+                    for (int b2 = a; b2 < 6; ++b2) A[k++] += wi * (Jp[a] * Jp[b2] + Jp[6 + a] * Jp[6 + b2]);
+                }
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < PO_K; ++j) if ((have >> j) & 1u) one(X[j], uv[j], info[j], tid + PO_NT * j);
+        for (int o = tid + PO_NT * PO_K; o < P.n_obs; o += PO_NT) {          // more observations than the registers take: from memory
+            if (P.obs_pose[o] != pi) continue;
+            const double Xo[3] = {P.point0[3 * (size_t)P.obs_point[o]], P.point0[3 * (size_t)P.obs_point[o] + 1], P.point0[3 * (size_t)P.obs_point[o] + 2]};
+            const double uvo[2] = {P.obs_uv[2 * (size_t)o], P.obs_uv[2 * (size_t)o + 1]};
+            one(Xo, uvo, P.obs_info[o], o);
+        }
+        if (tid < ne) {
+            double Bm[7], e[6], We[6];
+            if (s_eSide[tid] == 0) se3_mul(s_eC[tid], pose, Bm);                                    // (Tj^-1 M) Ti
+            else { double Tjinv[7], A2[7]; se3_inv(pose, Tjinv); se3_mul(Tjinv, s_eM[tid], A2); se3_mul(A2, s_eC[tid], Bm); }
+            se3_log(Bm, e);
+            for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[tid][6 * i + j] * e[j]; We[i] = v; }
+            for (int i = 0; i < 6; ++i) acc += e[i] * We[i];
+            if (lin) for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[tid][6 * a + c] * e[c]; g[a] += v; }
+        }
+        __syncthreads();                                                    // (s_w / s_sum of the previous reduction have been read)
+        po_block_sum(acc, s_w, 27);
+        if (lin) {
+#pragma unroll
+            for (int a = 0; a < 21; ++a) po_block_sum(A[a], s_w, a);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) po_block_sum(g[a], s_w, 21 + a);
+        }
+        __syncthreads();
+        if (tid < 28) s_sum[tid] = s_w[tid] + s_w[32 + tid] + s_w[64 + tid] + s_w[96 + tid] + (tid < 21 ? s_Hc[tid] : (tid == 27 ? s_const : 0.0));
+        __syncthreads();
+        return s_sum[27];
+    };
+    double lambda = 0, ni = 2;
+    int it = 0, trials = 0, stop = 0;
+    const double chi2_init = sweep(false, false);
+    double chi2_carried = chi2_init;
+    for (it = 0; it < P.max_iters; ++it) {
+        double current = chi2_carried, temp = current;
+        (void)sweep(true, false);
+        double H[21], b[6];
+#pragma unroll
+        for (int a = 0; a < 21; ++a) H[a] = s_sum[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) b[a] = s_sum[21 + a];
+        if (it == 0) {                                                       // computeLambdaInit: 1e-5 x the largest diagonal entry
+            const double md = fmax(fmax(fmax(fabs(H[0]), fabs(H[6])), fmax(fabs(H[11]), fabs(H[15]))), fmax(fabs(H[18]), fabs(H[20])));
+            lambda = 1e-5 * md; ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            // (H + lambda I) dp = b: Cholesky of the 6 x 6 matrix, by every thread for itself (fully unrolled: 21 + 6 registers, ~150 dependent operations --
+            // cheaper than one thread doing it behind a barrier and a trip through LDS)
+            double Lm[21], dpv[6];                                           // lower triangle, row-major: Lm[i (i + 1) / 2 + j]
+            bool ok2 = true;
+            {
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = a; c < 6; ++c) { Lm[c * (c + 1) / 2 + a] = H[k] + (a == c ? lambda : 0.0); ++k; }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double d = Lm[j * (j + 1) / 2 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d -= Lm[j * (j + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
+                if (!(d > 0) || !isfinite(d)) ok2 = false;
+                const double lj = sqrt(d), inv = 1.0 / lj;
+                Lm[j * (j + 1) / 2 + j] = inv;                               // the reciprocal pivot is what the substitutions use
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) {
+                    double v = Lm[i * (i + 1) / 2 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= Lm[i * (i + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
+                    Lm[i * (i + 1) / 2 + j] = v * inv;
+                }
+            }
+            {
+                double y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double v = b[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) v -= Lm[i * (i + 1) / 2 + k] * y[k];
+                    y[i] = v * Lm[i * (i + 1) / 2 + i];
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double v = y[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) v -= Lm[k * (k + 1) / 2 + i] * dpv[k];
+                    dpv[i] = v * Lm[i * (i + 1) / 2 + i];
+                }
+            }
+            double bk[7], sc = 0;
+#pragma unroll
+            for (int a = 0; a < 7; ++a) bk[a] = pose[a];                                    // push()
+            if (ok2) {
+                double dp[6], ex[7];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { dp[a] = dpv[a]; sc += dp[a] * (lambda * dp[a] + b[a]); }
+                se3_exp(dp, ex);
+                se3_mul(ex, bk, pose);                                                      // every thread moves its own copy of the pose: the same arithmetic, the same result
+                temp = sweep(false, false);
+            } else temp = DBL_MAX;
+            const double scale = sc + 1e-3;
+            rho = (current - temp) / scale;
+            if (rho > 0 && isfinite(temp)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2; current = temp; chi2_carried = temp;
+            } else {
+                lambda *= ni; ni *= 2;
+#pragma unroll
+                for (int a = 0; a < 7; ++a) pose[a] = bk[a];                                // pop()
+                if (!isfinite(lambda)) break;
+            }
+            ++qmax; ++trials;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0 || !isfinite(lambda)) { stop = 1; ++it; break; }
+    }
+    const double chi2_final = sweep(false, true);
+    if (tid == 0) {
+        for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
+        P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = chi2_final;
+        P.stats[6] = isfinite(chi2_final) ? 1 : 0; P.stats[7] = 0;
+        for (int k = 8; k < 16; ++k) P.stats[k] = 0;
+    }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -2464,6 +2702,7 @@ struct ms_ba {
     int factor_team = 0;               // of these, workgroups in the distributed Cholesky of a large system (ms_ba_set_factor_team; 0 = automatic)
     std::vector<double> chol_tiles;    // per problem: row tiles a Cholesky panel touches on average
     int cus = 0;
+    bool pose_only = false;            // every problem has ONE free pose and only fixed points: k_ba_pose_only instead of k_ba_lm (poseBundleAdjust)
     int launched_team = 1;             // team size of the last launch
     bool team_checked = true;          // the last team launch has been looked at (every problem's gave-up marker) and, if need be, repeated
     int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
@@ -2966,6 +3205,11 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
         H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1; H.chol_team = 1;
         B->chol_tiles.push_back(R.chol_tiles);
+        {   // poseBundleAdjust-shaped: one free pose, no free point
+            bool po = R.np_free == 1 && problems[p].n_pose_edge <= PO_MAXE;
+            for (int l = 0; l < problems[p].n_point && po; ++l) po = problems[p].point_fixed && problems[p].point_fixed[l];
+            if (p == 0) B->pose_only = po; else B->pose_only = B->pose_only && po;
+        }
 #undef PTR
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
@@ -3025,6 +3269,12 @@ int ms_ba_solve(ms_ba *B) {
     // A workgroup takes more than half a CU's LDS, so one per CU: a team is only possible while problems x team fits the chip
     // (all its workgroups must be resident for the barriers), hence the cooperative launch below.  Automatic choice: as many
     // workgroups per problem as fit, at most 32 (beyond that the single-workgroup Cholesky dominates).
+    if (B->pose_only && B->team <= 1 && !std::getenv("MS_BA_NO_POSE_KERNEL")) {      // (an explicit team request keeps the general kernel: tests compare the two)
+        hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), 0, c->stream, B->d_probs);
+        MS_KERNEL_CHECK(c, "k_ba_pose_only");
+        B->launched_team = 1; B->team_checked = true;
+        return MS_OK;
+    }
     int most_obs = 0;
     for (const auto &h : B->host) most_obs = std::max(most_obs, h.n_obs);
     int team = B->team == 0 ? std::min(32, std::max(1, most_obs / 512)) : B->team;      // small problems are latency-bound on the barriers

@@ -152,3 +152,16 @@ def residuals_fast(prob, pose, point):
     Rs = np.stack([_R_from_quat(p[:4]) for p in pose])
     p = np.einsum("oij,oj->oi", Rs[prob["obs_pose"]], point[prob["obs_point"]]) + pose[prob["obs_pose"], 4:]
     return prob["obs_uv"] - p[:, :2] / p[:, 2:3]
+
+
+def pose_only_from_window(w, cur, use_gt_points=False):
+    """poseBundleAdjust as the reference builds it (bundle_adjuster.cpp:396-491) from a window `w` of make_problem / make_problem_fast: keyframe `cur` free, the
+    previous keyframe fixed and tied to it by the chain's odometry edge, every map point `cur` observes fixed; only `cur`'s observations."""
+    sel = np.flatnonzero(w["obs_pose"] == cur)
+    pts = np.unique(w["obs_point"][sel])
+    remap = -np.ones(len(w["point"]), np.int64); remap[pts] = np.arange(len(pts))
+    k = int(np.flatnonzero((w["edge_i"] == cur) & (w["edge_j"] == cur - 1))[0])
+    point = (w["gt_point"] if use_gt_points and "gt_point" in w else w["point"])[pts] + 0.0
+    return dict(pose=np.stack([w["pose"][cur], w["pose"][cur - 1]]), pose_fixed=np.array([0, 1], np.uint8), point=point, point_fixed=np.ones(len(pts), np.uint8),
+                obs_pose=np.zeros(len(sel), np.int32), obs_point=remap[w["obs_point"][sel]].astype(np.int32), obs_uv=w["obs_uv"][sel].copy(), obs_info=w["obs_info"][sel].copy(),
+                huber_delta=w["huber_delta"], edge_i=np.array([0], np.int32), edge_j=np.array([1], np.int32), edge_meas=w["edge_meas"][k:k + 1].copy(), edge_info=w["edge_info"][k:k + 1].copy())

