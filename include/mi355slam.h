@@ -67,7 +67,7 @@ const char *ms_version(void);
 /* HIP-event timing on the context stream (bench.py measures the hot path with these). */
 int ms_timer_start(ms_ctx *ctx);
 int ms_timer_stop_ms(ms_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */
-/* 16 general event slots: mark = hipEventRecord on the context stream; elapsed synchronises on slot b. */
+/* 1024 general event slots (created on first use): mark = hipEventRecord on the context stream; elapsed synchronises on slot b. */
 int ms_event_mark(ms_ctx *ctx, int slot);
 int ms_event_elapsed_ms(ms_ctx *ctx, int slot_a, int slot_b, float *ms);
 /* plain device memory helpers so a C caller needs no HIP headers */
@@ -178,6 +178,9 @@ int ms_keypoints_unpack(const uint8_t *records, int n, float *x, float *y, float
 #define MS_ORB_STAGES 6
 int ms_orb_set_profiling(ms_orb *orb, int enable);
 int ms_orb_stage_ms(ms_orb *orb, float *ms /* [MS_ORB_STAGES] */);
+/* The same for an earlier profiled call: calls_back = 0 is the last one, up to 127 back (each profiled call records into the next set of a ring), so a
+ * run of calls can be enqueued without a host wait in between and read afterwards. */
+int ms_orb_stage_ms_back(ms_orb *orb, int calls_back, float *ms /* [MS_ORB_STAGES] */);
 /* ImagePyramid::getLevel / getBlurredLevel (image_pyramid.hpp:24-25): copy one level of one frame
  * of the last batch to host, tightly packed w*h bytes (debug / parity testing).
  * LIFETIME of device inputs: frames handed to ms_orb_extract in device memory (16-byte aligned base and strides) are used IN PLACE as

@@ -124,14 +124,14 @@ int ms_timer_stop_ms(ms_ctx *c, float *ms) {
 }
 
 int ms_event_mark(ms_ctx *c, int slot) {
-    if (!c || slot < 0 || slot >= 16) return MS_ERR_INVALID;
+    if (!c || slot < 0 || slot >= 1024) return MS_ERR_INVALID;
     if (!c->slots[slot]) MS_HIP(c, hipEventCreate(&c->slots[slot]));
     MS_HIP(c, hipEventRecord(c->slots[slot], c->stream));
     return MS_OK;
 }
 
 int ms_event_elapsed_ms(ms_ctx *c, int a, int b, float *ms) {
-    if (!c || !ms || a < 0 || a >= 16 || b < 0 || b >= 16 || !c->slots[a] || !c->slots[b]) return MS_ERR_INVALID;
+    if (!c || !ms || a < 0 || a >= 1024 || b < 0 || b >= 1024 || !c->slots[a] || !c->slots[b]) return MS_ERR_INVALID;
     MS_HIP(c, hipEventSynchronize(c->slots[b]));
     MS_HIP(c, hipEventElapsedTime(ms, c->slots[a], c->slots[b]));
     return MS_OK;

@@ -12,7 +12,7 @@ struct ms_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t slots[16] = {nullptr};
+    hipEvent_t slots[1024] = {nullptr};     // ms_event_mark: created on first use
     int n_cu = 0;
     void *scratch = nullptr;      // growable device scratch for small per-call argument tables
     size_t scratch_bytes = 0;

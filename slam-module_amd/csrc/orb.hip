@@ -1075,7 +1075,12 @@ struct ms_orb {
     // optional per-stage HIP events (ms_orb_set_profiling)
     bool profiling = false;
     bool blur_valid = false;           // the blurred planes of the slab hold the last batch (k_blur runs on demand only)
-    hipEvent_t ev[MS_ORB_STAGES + 1] = {nullptr};
+    // a ring of kProfRing event sets: a profiled call records into the next one, so the stage times of the last kProfRing calls can be read
+    // after a run of calls -- without a host wait between them (ms_orb_stage_ms_back)
+    static constexpr int kProfRing = 128;
+    hipEvent_t evr[kProfRing][MS_ORB_STAGES + 1] = {{nullptr}};
+    hipEvent_t *ev = evr[0];           // the set of the current / last profiled call
+    long long prof_calls = 0;
     // host frames come in as up to kChunks pieces on a stream of their own: piece k+1 is copied while the kernels of piece k run
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[4] = {nullptr}, ev_free[4] = {nullptr}, ev_end = nullptr;
@@ -1282,7 +1287,7 @@ void ms_orb_destroy(ms_orb *o) {
     if (o->d_moment_tab) (void)hipFree(o->d_moment_tab);
     if (o->d_pattern_f) (void)hipFree(o->d_pattern_f);
     if (o->d_ftile_tab) (void)hipFree(o->d_ftile_tab);
-    for (int i = 0; i <= MS_ORB_STAGES; ++i) if (o->ev[i]) (void)hipEventDestroy(o->ev[i]);
+    for (auto &set : o->evr) for (int i = 0; i <= MS_ORB_STAGES; ++i) if (set[i]) (void)hipEventDestroy(set[i]);
     if (o->copy_stream) { (void)hipStreamSynchronize(o->copy_stream); (void)hipStreamDestroy(o->copy_stream); }
     for (int i = 0; i < 4; ++i) { if (o->ev_copied[i]) (void)hipEventDestroy(o->ev_copied[i]); if (o->ev_free[i]) (void)hipEventDestroy(o->ev_free[i]); }
     if (o->ev_end) (void)hipEventDestroy(o->ev_end);
@@ -1299,9 +1304,19 @@ int ms_orb_capacity(const ms_orb *o) { return o ? o->geom.capacity : MS_ERR_INVA
 int ms_orb_set_profiling(ms_orb *o, int enable) {
     if (!o) return MS_ERR_INVALID;
     ms_ctx *c = o->ctx;
-    if (enable && !o->ev[0])
-        for (int i = 0; i <= MS_ORB_STAGES; ++i) MS_HIP(c, hipEventCreate(&o->ev[i]));
+    if (enable && !o->evr[0][0])
+        for (auto &set : o->evr) for (int i = 0; i <= MS_ORB_STAGES; ++i) MS_HIP(c, hipEventCreate(&set[i]));
     o->profiling = enable != 0;
+    return MS_OK;
+}
+
+int ms_orb_stage_ms_back(ms_orb *o, int calls_back, float *ms) {
+    if (!o || !ms || calls_back < 0 || calls_back >= ms_orb::kProfRing) return MS_ERR_INVALID;
+    ms_ctx *c = o->ctx;
+    if (!o->evr[0][0] || calls_back >= o->prof_calls) return ms_fail(c, MS_ERR_INVALID, "ms_orb_stage_ms_back: no profiled call %d calls back", calls_back);
+    hipEvent_t *set = o->evr[(o->prof_calls - 1 - calls_back) % ms_orb::kProfRing];
+    MS_HIP(c, hipEventSynchronize(set[MS_ORB_STAGES]));
+    for (int i = 0; i < MS_ORB_STAGES; ++i) MS_HIP(c, hipEventElapsedTime(&ms[i], set[i], set[i + 1]));
     return MS_OK;
 }
 
@@ -1351,6 +1366,7 @@ static int orb_enqueue_kernels(ms_orb *o, FrameSrc src, int f0, int nf, bool hav
     int16_t *det_x = o->d_det_x + F * G.det_stride, *det_y = o->d_det_y + F * G.det_stride;
     uint8_t *det_score = o->d_det_score + F * G.det_stride;
     int stage = 0;
+    if (o->profiling) { o->ev = o->evr[o->prof_calls % ms_orb::kProfRing]; ++o->prof_calls; }
 #define MS_STAGE_MARK() do { if (o->profiling) MS_HIP(c, hipEventRecord(o->ev[stage++], st)); } while (0)
     MS_STAGE_MARK();
     MsRange pyramid_range("pyramid");

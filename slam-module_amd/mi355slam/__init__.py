@@ -304,6 +304,12 @@ class OrbExtractor:
         self.ctx.check(lib().ms_orb_stage_ms(self._h, ms), "ms_orb_stage_ms")
         return dict(zip(("resize", "blur", "fast", "select", "tracks", "describe"), [float(v) for v in ms]))
 
+    def stage_ms_back(self, calls_back):
+        """Stage times of the profiled extract `calls_back` calls ago (0 = the last one; the library keeps 128)."""
+        ms = (C.c_float * 6)()
+        self.ctx.check(lib().ms_orb_stage_ms_back(self._h, int(calls_back), ms), "ms_orb_stage_ms_back")
+        return dict(zip(("resize", "blur", "fast", "select", "tracks", "describe"), [float(v) for v in ms]))
+
     def level_size(self, level):
         w, h = C.c_int32(), C.c_int32()
         self.ctx.check(lib().ms_orb_level_size(self._h, level, C.byref(w), C.byref(h)), "ms_orb_level_size")
