@@ -372,3 +372,14 @@ def test_top4_candidate_lists(oracle, ctx):
         order = sorted(range(len(keep)), key=lambda k: (d[k], k))[:4]
         assert cn[i] == len(keep)
         assert list(ci[i]) == [keep[k] for k in order] + [-1] * (4 - len(order)) and list(cd[i]) == [d[k] for k in order] + [256] * (4 - len(order)), i
+
+
+def test_match_fuzz_tool_on_random_keyframe_pairs():
+    """tools/match_fuzz.py on 40 random keyframe pairs (0..3000 keypoints, 1..600 vocabulary nodes, node sizes across the register / LDS / beyond-LDS regimes,
+    usable masks, low-entropy descriptors, ratios, thresholds), M1 and M2, every execution path: zero mismatches against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "match_fuzz.py"), "40", "2025"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
