@@ -54,7 +54,9 @@ struct FsSet {
     const int32_t *row0, *row1;              // [n_pass]
     const int32_t *batch_start;              // [n_pass + 1] first batch of a pass
     const int32_t *b_obs_start, *b_run_start;    // [n_batch + 1]: lane slots / first pair element (uint16 units, 8-aligned) of a batch
-    const int32_t *b_fmt;                    // [n_batch] 0: the batch's pairs are chunks of 8; n > 0: n single pairs, one per lane (batches with <= 64 pairs)
+    const int32_t *b_fmt;                    // [n_batch] 0: the batch's pairs are chunks of 8; n > 0: n single pairs, one per lane (batches with <= 64 pairs);
+                                             // < 0: G points with the SAME k poses, lane = point * k + pose slot -- no pair list in memory, the kernel enumerates the pairs
+                                             // (slot a >= a0, slot b <= a, all points) itself: -1 - fmt = G | k << 7 | a0 << 12 (a0: first slot inside the pass's rows)
     const int32_t *pobs;                     // per lane slot: observation, pose vertex, point, free pose index (int4)
     const uint16_t *pairs;                   // chunks of 8 pairs (a_lane | b_lane << 8, 0xFFFF = none): the pairs of a chunk fall into the same block (pose a,
                                              // pose b); a batch's chunks are sorted by block
@@ -1022,6 +1024,12 @@ __device__ __forceinline__ void lds_sub(MS_LDS double *p, double v) {
 }
 
 constexpr int FS_RUN = 3;                                        // consecutive batches a wave takes at a time
+#ifndef MS_FS_PROCEDURAL
+#define MS_FS_PROCEDURAL 1
+#endif
+constexpr bool kProceduralPairs = MS_FS_PROCEDURAL != 0;         // batches of equal pose sets carry no pair list (-DMS_FS_PROCEDURAL=0: lists for every batch, for A/B runs)
+template <bool PROCEDURAL>    // PROCEDURAL: the pass set has batches without pair lists (fmt < 0).  Two copies of the function: the enumeration code in the pair loop cost the
+                              // list-only launches (256 windows, one workgroup each) 5 % through register allocation alone, whether or not it ever ran
 __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double *lds_, long long *cyc) {
     __shared__ int s_fs_next;
     const BaProb &P = P_;
@@ -1110,7 +1118,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             u4_t pk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (run_lo + lane < run_hi) pk = chunks[run_lo + lane];
             unsigned single = 0xFFFFu;
-            if (lane < fmt) single = pairs16[b_run[b] + lane];
+            if (fmt > 0 && lane < fmt) single = pairs16[b_run[b] + lane];
             i4_t rec_n = {0, 0, 0, -1};
             int o0_n = 0, nobs_n = 0;
             if (b + 1 < b_hi) { o0_n = b_obs[b + 1]; nobs_n = b_obs[b + 2] - o0_n; if (lane < nobs_n) rec_n = pobs4[o0_n + lane]; }
@@ -1164,6 +1172,23 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[6 * i + j] += A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
             };
+            if (PROCEDURAL && fmt < 0) {
+                // equal pose sets: block q of the batch is (slot a, slot b2), a0 <= a < k, b2 <= a, in that order; its G pairs (one per point) are cut into pieces of
+                // `cap` so that the pieces of all blocks spread over the lanes -- the order and the cut the host's pair lists had, without the lists
+                const int enc = -1 - fmt, G = enc & 127, kq = (enc >> 7) & 31, a0q = enc >> 12;
+                const int nblk = kq * (kq + 1) / 2 - a0q * (a0q + 1) / 2, n_pairs = G * nblk;
+                const int cap = min(8, max(1, (n_pairs + 63) >> 6)), ppb = (G + cap - 1) / cap;          // pairs per piece, pieces per block
+                for (int piece = lane; piece < nblk * ppb; piece += 64) {
+                    const int q = piece / ppb, g0 = (piece - q * ppb) * cap, g1 = min(G, g0 + cap);
+                    int a = a0q, t2 = q;
+                    while (t2 > a) { t2 -= a + 1; ++a; }                      // q-th block: row a, column t2
+                    for (int gp = g0; gp < g1; ++gp) {
+                        const unsigned ab = (unsigned)(gp * kq + a) | ((unsigned)(gp * kq + t2) << 8);
+                        if (gp == g0) take_block(ab);
+                        add_pair(ab);
+                    }
+                }
+            }
             if (single != 0xFFFFu) { take_block(single); add_pair(single); }
             for (int run = run_lo + lane; run < run_hi; run += 64) {
                 u4_t nx = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -2302,7 +2327,7 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     const bool lead = P.team == 1 || blockIdx.x % (unsigned)P.team == 0;
     // P.flag[0] ("this damped solve is sound") is 1 on entry: the caller sets it behind a barrier that every reader of the previous value has passed
     const bool fused = P.fused != 0;
-    if (fused) schur_fused(P, lambda, lds, cyc);
+    if (fused) { if (P.fs[P.team > 1 ? 1 : 0].by_points) schur_fused<true>(P, lambda, lds, cyc); else schur_fused<false>(P, lambda, lds, cyc); }
     else {
         schur_prepare(P, lambda);
         { const long long t1 = clock64(); cyc[6] += t1 - t0; }
@@ -2727,6 +2752,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     const bool tm_on = std::getenv("MS_BA_TIMING") != nullptr;           // prints the host index build and the allocation + upload time of every create to stderr
     auto tm_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tm0 = tm_now();
+    double tm_part[5] = {0, 0, 0, 0, 0}, tm_mark = tm0;                  // CSR + envelope | record-based Schur lists | Cholesky panel lists | fused Schur batches | windowed Cholesky tables
+    auto tm_lap = [&](int k) { if (tm_on) { const double t = tm_now(); tm_part[k] += t - tm_mark; tm_mark = t; } };
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; bool by_points = false; };
     struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
@@ -2795,6 +2822,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             for (int f = 0; f < R.np_free && ok; ++f) if (36 * (f - first[f] + 1) + 6 > kFsTileDoubles) ok = false;
             R.fused = ok;
         }
+        tm_lap(0);
         if (!R.fused) {   // record-based Schur work list: for every free point, every ordered pair (a, b) of its observations with free poses fb <= fa,
             // counting-sorted by (fa, fb), then cut into chunks of CH items of one pose pair
             const int np = R.np_free;
@@ -2858,6 +2886,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 }
             }
         }
+        tm_lap(2);
         {   // fused Schur pass (schur_fused): pose rows -> passes whose envelope part fits the LDS tile, points -> batches of <= 64 observations
             const int np = R.np_free;
             R.fs_cs.resize(np);
@@ -2979,6 +3008,14 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                             const int G = pt_end - batch_first, k = batch_k, j0 = fp_start[pts[batch_first].second];
                             int a0 = 0;
                             while (a0 < k && fp_f[j0 + a0] < r0) ++a0;
+                            // (only for pass sets that own points = team launches: one window per keyframe, where the index build is a fifth of the call; a 256-window launch keeps the
+                            //  lists -- enumerating costs its Schur pass 4 %, 11.4 against 10.9 ms, and its handles are built once.  schur_fused<true> runs exactly these sets)
+                            if (F.by_points && k <= 31 && G <= 127 && kProceduralPairs) {      // the kernel enumerates the pairs of such a batch itself: nothing to build, nothing to upload
+                                F.b_fmt.push_back(-1 - (G | (k << 7) | (a0 << 12)));
+                                F.b_obs_start.push_back((int32_t)(F.pobs.size() / 4)); F.b_run_start.push_back((int32_t)F.pairs.size());
+                                in_batch = 0;
+                                return;
+                            }
                             const size_t n_pairs = (size_t)G * ((size_t)k * (k + 1) / 2 - (size_t)a0 * (a0 + 1) / 2);
                             const size_t cap = std::min<size_t>(8, std::max<size_t>(1, (n_pairs + 63) / 64));
                             single_fmt = n_pairs <= 64 ? (int)n_pairs : 0;
@@ -3037,6 +3074,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 F.b_obs_start.push_back(F.b_obs_start.back());
             }
         }
+        tm_lap(3);
         {   // windowed Cholesky (cholesky_window): active 16-row blocks per panel, LDS slots, tiles entering per panel
             const int np = R.np_free, n6i = 6 * np, nblk = (n6i + 15) / 16;
             std::vector<int> ent(nblk, 0);
@@ -3217,7 +3255,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         ms_ba_destroy(B);
         return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
     }
-    if (tm_on) std::fprintf(stderr, "ms_ba_create: prep %.3f ms, alloc+upload %.3f ms, arena %.1f MB\n", tm1 - tm0, tm_now() - tm1, total / 1e6);
+    if (tm_on) std::fprintf(stderr, "ms_ba_create: prep %.3f ms (CSR + envelope %.3f, record lists + panel lists %.3f, fused-pass batches %.3f, rest %.3f), alloc+upload %.3f ms, arena %.1f MB\n",
+                            tm1 - tm0, tm_part[0], tm_part[2], tm_part[3], tm1 - tm0 - tm_part[0] - tm_part[2] - tm_part[3], tm_now() - tm1, total / 1e6);
     *out = B;
     return MS_OK;
 }
