@@ -29,6 +29,7 @@ def test_launcher_starts_two_ranks_and_reports_the_whole_job():
     assert out["ms_per_step"] >= 3.9
     assert abs(out["value"] - out["units_total"] / (out["ms_per_step"] * 4e-3)) / out["value"] < 0.01
     assert out["c5"]["sequences_of_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]]                      # sequence s -> GPU s mod N
+    assert out["cpu_baseline"]["kind"] == "port"                                                # rank 0 timed it alone, after the process group was gone -- at N = 2 too
     for k in ("metric", "unit", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in out
 
