@@ -376,6 +376,19 @@ int main(int argc, char **argv) {
     std::printf("BA stage1 chi2 %.3f -> %.3f, stage2 -> %.3f, iterations %d/%d\n", o.stage1.chi2_initial, o.stage1.chi2_final, o.stage2.chi2_final,
                 o.stage1.iterations, o.stage2.iterations);
     if (!(o.stage2.chi2_final <= o.stage1.chi2_initial)) return 4;
+    {   // poseBundleAdjust (bundle_adjuster.cpp:396-491) through the mirror: the current keyframe knocked off its place, every point fixed -> the pose-only kernel
+        BaWindow wp = w;
+        const std::array<double, 7> before = wp.poses[2];
+        wp.poses[2][4] += 0.03; wp.poses[2][5] -= 0.02;
+        const auto pts = wp.points; const auto p0 = wp.poses[0], p1 = wp.poses[1];
+        ms_ba_result pr{};
+        const bool ran = poseBundleAdjust(ctx, wp, 10, &pr);
+        const double moved = std::fabs(wp.poses[2][4] - before[4]) + std::fabs(wp.poses[2][5] - before[5]);
+        std::printf("poseBundleAdjust: chi2 %.3f -> %.3f in %d iterations, pose back within %.2e of where it was\n", pr.chi2_initial, pr.chi2_final, pr.iterations, moved);
+        if (!ran || !(pr.chi2_final < 0.05 * pr.chi2_initial) || moved > 2e-3 || wp.points != pts || wp.poses[0] != p0 || wp.poses[1] != p1) return 18;
+        BaWindow empty; empty.poses.push_back({0, 0, 0, 1, 0, 0, 0});
+        if (poseBundleAdjust(ctx, empty, 10)) return 19;                           // nothing to adjust: false, like :410-412
+    }
     // globalBundleAdjust-sized map: 200 keyframes on a line (the current one fixed), 1500 points each seen by 8 consecutive keyframes
     {
         BaWindow g; g.currentKeyframe = 199;
