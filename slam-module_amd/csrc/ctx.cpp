@@ -31,6 +31,17 @@ int ms_ctx_order_after_downloads(ms_ctx *c) {
     return MS_OK;
 }
 
+int ms_pinned(ms_ctx *c, size_t bytes) {
+    if (bytes > c->pinned_bytes) {
+        if (c->pinned) MS_HIP(c, hipHostFree(c->pinned));
+        c->pinned = nullptr; c->pinned_bytes = 0;
+        const size_t want = ms_align_up(bytes * 2, 4096);
+        MS_HIP(c, hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinned_bytes = want;
+    }
+    return MS_OK;
+}
+
 int ms_scratch(ms_ctx *c, size_t bytes, void **out) {
     if (bytes > c->scratch_bytes) {
         MS_HIP(c, hipStreamSynchronize(c->stream));
@@ -91,6 +102,7 @@ void ms_ctx_destroy(ms_ctx *c) {
     if (c->ev_d2h_done) (void)hipEventDestroy(c->ev_d2h_done);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto &b : c->ba_cache) if (b.p) (void)hipFree(b.p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

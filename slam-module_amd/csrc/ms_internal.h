@@ -27,8 +27,13 @@ struct ms_ctx {
     hipStream_t d2h_stream = nullptr;
     hipEvent_t ev_d2h_gate = nullptr, ev_d2h_done = nullptr;
     bool d2h_pending = false;
+    void *pinned = nullptr;       // page-locked host staging of small result blocks (ms_pinned), grow-only
+    size_t pinned_bytes = 0;
     char err[512] = {0};
 };
+
+// page-locked host staging of at least `bytes` in ctx->pinned (contents are valid until the next call that uses it)
+int ms_pinned(ms_ctx *ctx, size_t bytes);
 
 // makes the context stream wait (on the device) for the asynchronous downloads issued so far
 int ms_ctx_order_after_downloads(ms_ctx *ctx);
