@@ -3195,11 +3195,14 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         if (e != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: clearing the arena failed: %s", hipGetErrorString(e)); }
     }
     B->host.resize(n); B->dims.assign(problems, problems + n);
-    std::vector<char> stage;
     for (int p = 0; p < n; ++p) {
         const ms_ba_problem &Q = problems[p]; const Prep &R = prep[p]; const Off &O = off[p]; const size_t D = sizeof(double);
-        stage.assign(in_hi[p] - in_lo[p], 0);
-        auto up = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(stage.data() + (o - in_lo[p]), src, bytes); };
+        // the problem's input block is assembled in the context's page-locked staging and goes up in ONE copy the copy engine reads directly
+        const size_t stage_bytes = in_hi[p] - in_lo[p];
+        if (ms_pinned(c, stage_bytes) != MS_OK) { ms_ba_destroy(B); return MS_ERR_HIP; }
+        char *stage = static_cast<char *>(c->pinned);
+        std::memset(stage, 0, stage_bytes);
+        auto up = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(stage + (o - in_lo[p]), src, bytes); };
         up(O.pose0, Q.pose, 7 * Q.n_pose * D); up(O.point0, Q.point, 3 * Q.n_point * D);
         up(O.pidx, R.pidx.data(), 4 * Q.n_pose); if (Q.point_fixed) up(O.pfix, Q.point_fixed, Q.n_point);
         up(O.obs_pose, Q.obs_pose, 4 * Q.n_obs); up(O.obs_point, Q.obs_point, 4 * Q.n_obs); up(O.obs_uv, Q.obs_uv, 2 * Q.n_obs * D); up(O.obs_info, Q.obs_info, Q.n_obs * D);
@@ -3219,7 +3222,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             up(O.fs_rowoff[set], F.rowoff.data(), 4 * F.rowoff.size()); up(O.fs_yoff[set], F.yoff.data(), 4 * F.yoff.size());
         }
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
-        if (hipMemcpyAsync(B->d_arena + in_lo[p], stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        if (hipMemcpyAsync(B->d_arena + in_lo[p], stage, stage_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
         BaProb &H = B->host[p];
         char *a = B->d_arena;
