@@ -111,6 +111,11 @@ struct BaProb {
     const int32_t *cw_act_start, *cw_act;    // per panel p: the other active blocks (block | slot << 16), ascending
     const int32_t *cw_load_start, *cw_load;  // per panel p: tiles that enter the window (bi | si << 16, bj | sj << 16)
     const int32_t *fs_cs;                    // [np_free] first scalar column of pose row fa held in the tile (<= 6 * first coupled pose, 16-aligned envelope)
+    // one free pose + free points (k_ba_one_pose): the observations sorted by point -- pose vertex, original index, (u, v, information) --, the per-point
+    // records [28][n_point] and the team's partial sums [2][team][64]; null for every other shape
+    const int32_t *op_pose, *op_o;
+    const double *op_uvi;
+    double *op_rec, *op_red;
     // results
     double *stats;                           // [16]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -, then cycles per phase:
                                              //       8 eval, 9 linearise, 10 Schur, 11 Cholesky+backsub, 12 points+update, 13 total
@@ -2724,6 +2729,448 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
     }
 }
 
+
+// ---------------------------------------------------------------- one free pose + free points: stage 1 of localBundleAdjust (bundle_adjuster.cpp:251-252, :268, :322-333)
+// ONE free keyframe, every other keyframe fixed, the map points free: the reduced camera system is 6 x 6 whatever the window's size.  The general kernel
+// still walked it through its whole machinery (pass sets, LDS tile, windowed Cholesky of one block, ~7 team barriers per damped solve): 0.60 ms for the
+// 8 iterations of a C4 window on 32 workgroups, 3.3 ms for 256 such windows with one workgroup each.  Here a point belongs to a GROUP of G = 1 .. 8
+// neighbouring lanes (G chosen so that the launch's lanes cover the points): the group's lanes share the point's observations out, their sums meet over
+// the DPP network, lane 0 of the group keeps the point's record (Hll, bl, W = sum of Jp^T w Jl over the point's observations in the free keyframe) in
+// memory that only this workgroup touches.  Per damped solve: every group forms its point's W (Hll + lambda I)^-1 W^T / ... bl (3 x 3 Cholesky, as in
+// schur_fused) and adds them into 27 LDS accumulators -- only ~1 point in 4 is seen by the free keyframe, so these are few atomics --, ONE reduction over
+// the team, the 6 x 6 Cholesky in every thread (as in k_ba_pose_only), then each group back-substitutes its point, moves it, and evaluates the robust chi2 of
+// its observations at the trial state; a second reduction (chi2, gain denominator) decides.  Trial points live in point_bk and are copied on acceptance:
+// no backup / restore pass.  Observation data comes from copies sorted by point (pose index, u, v, information side by side: one round trip instead of
+// three dependent ones), the poses from an LDS table.  Same LM schedule and the same arithmetic per edge as k_ba_lm.
+constexpr int OP_NT = 512, OP_NW = OP_NT / 64, OP_NV = 64, OP_MAX_LDS_POSES = 1024;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over a group of 2^lg neighbouring lanes (aligned), the result in every lane of the group: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+__device__ __forceinline__ double group_sum_d(double v, int lg) {
+    if (lg >= 1) v += dpp_move_d<0xB1>(v);
+    if (lg >= 2) v += dpp_move_d<0x4E>(v);
+    if (lg >= 3) v += dpp_move_d<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ int group_sum_i(int v, int lg) {
+    if (lg >= 1) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    if (lg >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    if (lg >= 3) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    return v;
+}
+
+// Hll + lambda I = L L^T (3 x 3, packed 00 01 02 11 12 22); returns false when a pivot is not positive
+struct Chol3 { double i11, l21, l31, i22, l32, i33; };
+__device__ __forceinline__ bool chol3(const double *H, double lambda, Chol3 &c) {
+    const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
+    const double l11 = sqrt(a);
+    c.i11 = 1.0 / l11; c.l21 = H[1] * c.i11; c.l31 = H[2] * c.i11;
+    const double d2 = d - c.l21 * c.l21, l22 = sqrt(d2);
+    c.i22 = 1.0 / l22; c.l32 = (H[4] - c.l31 * c.l21) * c.i22;
+    const double d3 = f - c.l31 * c.l31 - c.l32 * c.l32, l33 = sqrt(d3);
+    c.i33 = 1.0 / l33;
+    return a > 0 && d2 > 0 && d3 > 0 && isfinite(c.i11 * c.i22 * c.i33);
+}
+
+__global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int team, int lgG) {
+    extern __shared__ __attribute__((aligned(16))) double op_lds[];      // [7 n_pose] the poses (when they fit)
+    __shared__ double s_acc[OP_NV], s_sum[OP_NV], s_w[OP_NW * 2];
+    __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
+    __shared__ int s_eSide[PO_MAXE], s_ne;
+    const BaProb &P = probs[blockIdx.x / (unsigned)team];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rank = team > 1 ? (int)(blockIdx.x % (unsigned)team) : 0;
+    const int G = 1 << lgG, gl = rank * OP_NT + tid, sub = gl & (G - 1), slot = gl >> lgG, nslot = (team * OP_NT) >> lgG;
+    const int pi = P.free2pose[0], n_point = P.n_point;
+    const bool lds_poses = P.n_pose <= OP_MAX_LDS_POSES;
+    const double *ptab = lds_poses ? op_lds : P.pose0;
+    const MS_GLOBAL int32_t *o_pose = (const MS_GLOBAL int32_t *)P.op_pose, *o_idx = (const MS_GLOBAL int32_t *)P.op_o, *pt_start = (const MS_GLOBAL int32_t *)P.pt_start;
+    const MS_GLOBAL double *o_uvi = (const MS_GLOBAL double *)P.op_uvi;
+    MS_GLOBAL double *rec = (MS_GLOBAL double *)P.op_rec;                 // [28][n_point]: Hll 0-5, bl 6-8, W 9-26, 27 = observations in the free keyframe
+    MS_GLOBAL double *point = (MS_GLOBAL double *)P.point, *trial = (MS_GLOBAL double *)P.point_bk;
+    const MS_GLOBAL uint8_t *pfix = (const MS_GLOBAL uint8_t *)P.point_fixed;
+    int seq = 0;
+    for (int i = gl; i < 7 * P.n_pose; i += team * OP_NT) P.pose[i] = P.pose0[i];
+    if (lds_poses) for (int i = tid; i < 7 * P.n_pose; i += OP_NT) op_lds[i] = P.pose0[i];
+    for (int l = slot; l < n_point; l += nslot) if (sub == 0) { point[3 * (size_t)l] = P.point0[3 * (size_t)l]; point[3 * (size_t)l + 1] = P.point0[3 * (size_t)l + 1]; point[3 * (size_t)l + 2] = P.point0[3 * (size_t)l + 2]; }
+    if (tid < OP_NV) s_acc[tid] = 0;
+    if (tid < 24) s_Hc[tid] = 0;
+    if (tid == 0) { s_ne = 0; s_const = 0; }
+    __syncthreads();
+    double pose[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) pose[a] = P.pose0[7 * (size_t)pi + a];
+    // ---- the SE3 edges (the team's first workgroup): an edge between fixed poses is a constant, one that touches the free pose leaves its fixed side's
+    //      transform, -J^T W and J^T W J in LDS (its Jacobian does not depend on the free pose), exactly as in k_ba_pose_only
+    if (rank == 0 && tid < P.n_edge) {
+        const int k = tid, vi = P.edge_i[k], vj = P.edge_j[k];
+        const double *W = P.edge_info + 36 * (size_t)k;
+        double e[6], Ji[36], Jj[36];
+        pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+        if (vi != pi && vj != pi) { double cacc = 0; for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j]; lds_addd((MS_LDS double *)&s_const, cacc); }
+        else {
+            const int sl = atomicAdd(&s_ne, 1), side = vi == pi ? 0 : 1;
+            const double *J = side ? Jj : Ji;
+            s_eSide[sl] = side;
+            if (side == 0) { double Tjinv[7], A2[7]; se3_inv(P.pose0 + 7 * (size_t)vj, Tjinv); se3_mul(Tjinv, P.edge_meas + 7 * (size_t)k, A2); for (int i = 0; i < 7; ++i) s_eC[sl][i] = A2[i]; }
+            else for (int i = 0; i < 7; ++i) { s_eC[sl][i] = P.pose0[7 * (size_t)vi + i]; s_eM[sl][i] = P.edge_meas[7 * (size_t)k + i]; }
+            for (int i = 0; i < 36; ++i) s_eW[sl][i] = W[i];
+            for (int a = 0; a < 6; ++a)
+                for (int c = 0; c < 6; ++c) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += J[6 * r2 + a] * W[6 * r2 + c]; s_eG[sl][6 * a + c] = -v; }
+            int kk = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b2 = a; b2 < 6; ++b2) {
+                    double v = 0;
+                    for (int r2 = 0; r2 < 6; ++r2) { double m = 0; for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * J[6 * c2 + b2]; v += J[6 * r2 + a] * m; }
+                    lds_addd((MS_LDS double *)&s_Hc[kk++], v);
+                }
+        }
+    }
+    __syncthreads();
+    const int ne = rank == 0 ? s_ne : 0;
+    // ---- sums over the team.  vec: the LDS accumulators s_acc[0 .. nv) (atomic contributions of this workgroup) -> s_sum[0 .. nv), the same bits in every
+    //      workgroup (partials combined in rank order); slot 63 is combined as a maximum (non-negative doubles order like their bit patterns)
+    auto vec_reduce = [&](int nv, bool with_max) {
+        __syncthreads();
+        double mine = 0, mx = 0;
+        if (tid < nv) { mine = s_acc[tid]; s_acc[tid] = 0; }
+        if (with_max && tid == OP_NV - 1) { mx = s_acc[OP_NV - 1]; s_acc[OP_NV - 1] = 0; }
+        if (team > 1) {
+            double *part = P.op_red + (size_t)(seq & 1) * team * OP_NV;
+            if (tid < nv) part[(size_t)rank * OP_NV + tid] = mine;
+            if (with_max && tid == OP_NV - 1) part[(size_t)rank * OP_NV + OP_NV - 1] = mx;
+            team_sync(P);
+            if (tid < nv) { double t = part[tid]; for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid]; mine = t; }
+            if (with_max && tid == OP_NV - 1) { double t = part[OP_NV - 1]; for (int r = 1; r < team; ++r) t = fmax(t, part[(size_t)r * OP_NV + OP_NV - 1]); mx = t; }
+        }
+        ++seq;
+        if (tid < nv) s_sum[tid] = mine;
+        if (with_max && tid == OP_NV - 1) s_sum[OP_NV - 1] = mx;
+        __syncthreads();
+    };
+    // two plain sums (fixed order: lanes, waves, ranks) -> s_sum[32], s_sum[33]
+    auto pair_reduce = [&](double a, double b) {
+        a = wave_sum_d(a); b = wave_sum_d(b);
+        __syncthreads();
+        if (lane == 0) { s_w[2 * wave] = a; s_w[2 * wave + 1] = b; }
+        __syncthreads();
+        double mine = 0;
+        if (tid < 2) { for (int w = 0; w < OP_NW; ++w) mine += s_w[2 * w + tid]; }
+        if (team > 1) {
+            double *part = P.op_red + (size_t)(seq & 1) * team * OP_NV;
+            if (tid < 2) part[(size_t)rank * OP_NV + tid] = mine;
+            team_sync(P);
+            if (tid < 2) { double t = part[tid]; for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid]; mine = t; }
+        }
+        ++seq;
+        if (tid < 2) s_sum[32 + tid] = mine;
+        __syncthreads();
+    };
+    auto load_pose = [&](int pc, const double (&cur)[7], double (&pz)[7]) {
+        if (pc == pi) {
+#pragma unroll
+            for (int a = 0; a < 7; ++a) pz[a] = cur[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 7; ++a) pz[a] = ptab[7 * (size_t)pc + a];
+        }
+    };
+    // ---- robust chi2 of the group's share of point l's observations with the point at X and the free pose at `cur`
+    auto chi2_share = [&](int l, const double (&X)[3], const double (&cur)[7], bool store) {
+        double acc = 0;
+        const int iend = pt_start[l + 1];
+        int ii = pt_start[l] + sub, pn = 0;
+        double un = 0, vn = 0, fn = 0;
+        if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+        while (ii < iend) {
+            const int pc = pn, i0 = ii;
+            const double uvc[2] = {un, vn}, infc = fn;
+            ii += G;
+            if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+            double pz[7], e[2], r, w;
+            load_pose(pc, cur, pz);
+            proj_edge<false>(pz, X, uvc, e, nullptr, nullptr);
+            const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
+            huber(chi2, P.huber, r, w);
+            if (store) P.chi2_obs[o_idx[i0]] = chi2;
+            acc += r;
+        }
+        return acc;
+    };
+    // the SE3 edges at the free pose `cur` (lanes < ne of the team's first workgroup): chi2, and with lin the gradient into the accumulators
+    auto edge_part = [&](const double (&cur)[7], bool lin) {
+        double acc = 0;
+        if (tid < ne) {
+            double Bm[7], e[6], We[6];
+            if (s_eSide[tid] == 0) se3_mul(s_eC[tid], cur, Bm);
+            else { double Tjinv[7], A2[7]; se3_inv(cur, Tjinv); se3_mul(Tjinv, s_eM[tid], A2); se3_mul(A2, s_eC[tid], Bm); }
+            se3_log(Bm, e);
+            for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[tid][6 * i + j] * e[j]; We[i] = v; }
+            for (int i = 0; i < 6; ++i) acc += e[i] * We[i];
+            if (lin) for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[tid][6 * a + c] * e[c]; lds_addd((MS_LDS double *)&s_acc[21 + a], v); }
+        }
+        if (rank == 0 && tid == 0) acc += s_const;
+        return acc;
+    };
+    auto total_chi2 = [&](const double (&cur)[7], bool trial_points, bool store, double extra) {
+        double acc = 0;
+        for (int l = slot; l < n_point; l += nslot) {
+            const MS_GLOBAL double *src = trial_points ? trial : point;
+            const double X[3] = {src[3 * (size_t)l], src[3 * (size_t)l + 1], src[3 * (size_t)l + 2]};
+            acc += chi2_share(l, X, cur, store);
+        }
+        acc += edge_part(cur, false);
+        pair_reduce(acc, extra);
+        return s_sum[32];
+    };
+    // ---- the point's part of the damped system: S -= W (Hll + lambda I)^-1 W^T (upper triangle, 21), y -= W (Hll + lambda I)^-1 bl (6), into the accumulators
+    auto schur_point = [&](const double (&H)[6], const double (&bl)[3], const double (&Wm)[18], double lambda) {
+        Chol3 c;
+        if (!chol3(H, lambda, c)) lds_addd((MS_LDS double *)&s_acc[27], 1.0);
+        const double u0 = bl[0] * c.i11, u1 = (bl[1] - c.l21 * u0) * c.i22, u2 = (bl[2] - c.l31 * u0 - c.l32 * u1) * c.i33;
+        double Z[18];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double z0 = Wm[3 * r] * c.i11, z1 = (Wm[3 * r + 1] - z0 * c.l21) * c.i22, z2 = (Wm[3 * r + 2] - z0 * c.l31 - z1 * c.l32) * c.i33;
+            Z[3 * r] = z0; Z[3 * r + 1] = z1; Z[3 * r + 2] = z2;
+            lds_addd((MS_LDS double *)&s_acc[21 + r], -(z0 * u0 + z1 * u1 + z2 * u2));
+        }
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = a; b2 < 6; ++b2) { lds_addd((MS_LDS double *)&s_acc[k], -(Z[3 * a] * Z[3 * b2] + Z[3 * a + 1] * Z[3 * b2 + 1] + Z[3 * a + 2] * Z[3 * b2 + 2])); ++k; }
+    };
+    double lambda = 0, ni = 2;
+    int it = 0, trials = 0, stop = 0;
+    const double chi2_init = total_chi2(pose, false, false, 0.0);
+    double chi2_carried = chi2_init;
+    for (it = 0; it < P.max_iters; ++it) {
+        double current = chi2_carried, temp = current;
+        // ---- linearisation: per point Hll, bl, W into its record; the free pose's block and gradient into the accumulators 0..20 / 21..26
+        double md = 0;
+        for (int l = slot; l < n_point; l += nslot) {
+            const bool pfree = !(pfix && pfix[l]);
+            const double X[3] = {point[3 * (size_t)l], point[3 * (size_t)l + 1], point[3 * (size_t)l + 2]};
+            double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, Wm[18];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) Wm[q] = 0;
+            int nf = 0;
+            const int iend = pt_start[l + 1];
+            int ii = pt_start[l] + sub, pn = 0;
+            double un = 0, vn = 0, fn = 0;
+            if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+            while (ii < iend) {
+                const int pc = pn;
+                const double uvc[2] = {un, vn}, infc = fn;
+                ii += G;
+                if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+                double pz[7], e[2], Jp[12], Jl[6], r, w;
+                load_pose(pc, pose, pz);
+                proj_edge<true>(pz, X, uvc, e, Jp, Jl);
+                const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
+                huber(chi2, P.huber, r, w);
+                const double wi = w * infc;
+                if (pfree) {
+                    H[0] += wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); H[1] += wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); H[2] += wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+                    H[3] += wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); H[4] += wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); H[5] += wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) bl[c] -= wi * (Jl[c] * e[0] + Jl[3 + c] * e[1]);
+                }
+                if (pc == pi) {
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        lds_addd((MS_LDS double *)&s_acc[21 + a], -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi);
+#pragma unroll
+                        for (int b2 = a; b2 < 6; ++b2) { lds_addd((MS_LDS double *)&s_acc[k], wi * (Jp[a] * Jp[b2] + Jp[6 + a] * Jp[6 + b2])); ++k; }
+                    }
+                    if (pfree) {
+                        ++nf;
+#pragma unroll
+                        for (int r2 = 0; r2 < 6; ++r2)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) Wm[3 * r2 + c] += wi * (Jp[r2] * Jl[c] + Jp[6 + r2] * Jl[3 + c]);
+                    }
+                }
+            }
+            nf = group_sum_i(nf, lgG);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) H[q] = group_sum_d(H[q], lgG);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bl[q] = group_sum_d(bl[q], lgG);
+            if (nf > 0) {
+#pragma unroll
+                for (int q = 0; q < 18; ++q) Wm[q] = group_sum_d(Wm[q], lgG);
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) rec[(size_t)q * n_point + l] = H[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rec[(size_t)(6 + q) * n_point + l] = bl[q];
+                if (nf > 0) {
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) rec[(size_t)(9 + q) * n_point + l] = Wm[q];
+                }
+                rec[(size_t)27 * n_point + l] = pfree ? (double)nf : -1.0;
+                if (pfree) md = fmax(md, fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))));
+            }
+        }
+        (void)edge_part(pose, true);
+        if (rank == 0 && tid < 21) lds_addd((MS_LDS double *)&s_acc[tid], s_Hc[tid]);      // the edges' constant J^T W J: into the sums, so that every workgroup of the team gets it
+        if (it == 0) {
+            for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
+            if (lane == 0) (void)atomicMax(reinterpret_cast<unsigned long long *>(&s_acc[OP_NV - 1]), (unsigned long long)__double_as_longlong(md));
+        }
+        vec_reduce(27, it == 0);
+        double Hp[21], bp[6];
+#pragma unroll
+        for (int a = 0; a < 21; ++a) Hp[a] = s_sum[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) bp[a] = s_sum[21 + a];
+        if (it == 0) {                                                       // computeLambdaInit: 1e-5 x the largest diagonal entry of the whole system
+            const double mdp = fmax(fmax(fmax(fabs(Hp[0]), fabs(Hp[6])), fmax(fabs(Hp[11]), fabs(Hp[15]))), fmax(fabs(Hp[18]), fabs(Hp[20])));
+            lambda = 1e-5 * fmax(mdp, s_sum[OP_NV - 1]); ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            // ---- the points' Schur terms at this lambda
+            for (int l = slot; l < n_point; l += nslot) {
+                if (sub != 0) continue;
+                const double nfv = rec[(size_t)27 * n_point + l];
+                if (nfv < 0) continue;                                       // a fixed point
+                double H[6], bl[3], Wm[18];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) H[q] = rec[(size_t)q * n_point + l];
+                if (nfv > 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bl[q] = rec[(size_t)(6 + q) * n_point + l];
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) Wm[q] = rec[(size_t)(9 + q) * n_point + l];
+                    schur_point(H, bl, Wm, lambda);
+                } else { Chol3 c; if (!chol3(H, lambda, c)) lds_addd((MS_LDS double *)&s_acc[27], 1.0); }
+            }
+            vec_reduce(28, false);
+            // (S + lambda I) dp = y: the 6 x 6 Cholesky by every thread for itself, as in k_ba_pose_only
+            double Lm[21], dpv[6], yv[6];
+            bool ok2 = s_sum[27] == 0.0;
+            {
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = a; c < 6; ++c) { Lm[c * (c + 1) / 2 + a] = Hp[k] + s_sum[k] + (a == c ? lambda : 0.0); ++k; }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) yv[a] = bp[a] + s_sum[21 + a];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double d = Lm[j * (j + 1) / 2 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d -= Lm[j * (j + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
+                if (!(d > 0) || !isfinite(d)) ok2 = false;
+                const double lj = sqrt(d), inv = 1.0 / lj;
+                Lm[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) {
+                    double v = Lm[i * (i + 1) / 2 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= Lm[i * (i + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
+                    Lm[i * (i + 1) / 2 + j] = v * inv;
+                }
+            }
+            {
+                double y2[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double v = yv[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) v -= Lm[i * (i + 1) / 2 + k] * y2[k];
+                    y2[i] = v * Lm[i * (i + 1) / 2 + i];
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double v = y2[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) v -= Lm[k * (k + 1) / 2 + i] * dpv[k];
+                    dpv[i] = v * Lm[i * (i + 1) / 2 + i];
+                }
+            }
+            double trial_pose[7];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) trial_pose[a] = pose[a];
+            if (ok2) {
+                double ex[7], sc = 0, acc = 0;
+                se3_exp(dpv, ex);
+                se3_mul(ex, pose, trial_pose);
+                if (gl == 0) { for (int a = 0; a < 6; ++a) sc += dpv[a] * (lambda * dpv[a] + bp[a]); }
+                // ---- the points follow: dl = (Hll + lambda I)^-1 (bl - W^T dp), the trial point, its share of the gain denominator and the chi2 of its observations
+                for (int l = slot; l < n_point; l += nslot) {
+                    double X[3] = {point[3 * (size_t)l], point[3 * (size_t)l + 1], point[3 * (size_t)l + 2]};
+                    const double nfv = rec[(size_t)27 * n_point + l];
+                    if (nfv >= 0) {
+                        double H[6], bl[3];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) H[q] = rec[(size_t)q * n_point + l];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) bl[q] = rec[(size_t)(6 + q) * n_point + l];
+                        double r0 = bl[0], r1 = bl[1], r2 = bl[2];
+                        if (nfv > 0) {
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) {
+                                const double w0 = rec[(size_t)(9 + 3 * a) * n_point + l], w1 = rec[(size_t)(10 + 3 * a) * n_point + l], w2 = rec[(size_t)(11 + 3 * a) * n_point + l];
+                                r0 -= w0 * dpv[a]; r1 -= w1 * dpv[a]; r2 -= w2 * dpv[a];
+                            }
+                        }
+                        Chol3 c;
+                        (void)chol3(H, lambda, c);
+                        const double v0 = r0 * c.i11, v1 = (r1 - c.l21 * v0) * c.i22, v2 = (r2 - c.l31 * v0 - c.l32 * v1) * c.i33;       // L^-1 r
+                        const double d2 = v2 * c.i33, d1 = (v1 - c.l32 * d2) * c.i22, d0 = (v0 - c.l21 * d1 - c.l31 * d2) * c.i11;         // L^-T ...
+                        if (sub == 0) sc += d0 * (lambda * d0 + bl[0]) + d1 * (lambda * d1 + bl[1]) + d2 * (lambda * d2 + bl[2]);
+                        X[0] += d0; X[1] += d1; X[2] += d2;
+                    }
+                    if (sub == 0) { trial[3 * (size_t)l] = X[0]; trial[3 * (size_t)l + 1] = X[1]; trial[3 * (size_t)l + 2] = X[2]; }
+                    acc += chi2_share(l, X, trial_pose, false);
+                }
+                acc += edge_part(trial_pose, false);
+                pair_reduce(acc, sc);
+                temp = s_sum[32];
+            } else temp = DBL_MAX;
+            const double scale = (ok2 ? s_sum[33] : 0.0) + 1e-3;
+            rho = (current - temp) / scale;
+            if (rho > 0 && isfinite(temp)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2; current = temp; chi2_carried = temp;
+#pragma unroll
+                for (int a = 0; a < 7; ++a) pose[a] = trial_pose[a];
+                for (int l = slot; l < n_point; l += nslot)
+                    if (sub == 0) { point[3 * (size_t)l] = trial[3 * (size_t)l]; point[3 * (size_t)l + 1] = trial[3 * (size_t)l + 1]; point[3 * (size_t)l + 2] = trial[3 * (size_t)l + 2]; }
+                __syncthreads();                                            // the group's other lanes read the moved points next
+            } else {
+                lambda *= ni; ni *= 2;
+                if (!isfinite(lambda)) break;
+            }
+            ++qmax; ++trials;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0 || !isfinite(lambda)) { stop = 1; ++it; break; }
+    }
+    const double chi2_final = total_chi2(pose, false, true, 0.0);
+    if (gl == 0) {
+        const bool hung = team > 1 && P.flag[1] != 0;                      // a team barrier gave up: the result is not to be trusted
+        for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
+        P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
+        P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = hung ? 1 : 0;
+        for (int k = 8; k < 16; ++k) P.stats[k] = 0;
+    }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -2742,6 +3189,9 @@ struct ms_ba {
     std::vector<double> chol_tiles;    // per problem: row tiles a Cholesky panel touches on average
     int cus = 0;
     bool pose_only = false;            // every problem has ONE free pose and only fixed points: k_ba_pose_only instead of k_ba_lm (poseBundleAdjust)
+    bool one_pose = false;             // every problem has ONE free pose and at least one free point: k_ba_one_pose (stage 1 of localBundleAdjust)
+    int one_pose_lg = 0;               // log2 of the lanes per point of the last k_ba_one_pose launch
+    bool last_one_pose = false;        // the last launch was k_ba_one_pose (its fallback after a barrier gave up is the same kernel with one workgroup)
     int launched_team = 1;             // team size of the last launch
     bool team_checked = true;          // the last team launch has been looked at (every problem's gave-up marker) and, if need be, repeated
     int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
@@ -2771,12 +3221,13 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; bool by_points = false; };
     struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
-                  bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0; };
+                  bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0;
+                  bool one_pose = false; std::vector<int32_t> op_pose, op_o; std::vector<double> op_uvi; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -2805,6 +3256,21 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         R.fobs.resize(R.fstart[R.np_free]);
         { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
         for (int o = 0; o < Q.n_obs; ++o) if (R.pidx[Q.obs_pose[o]] < 0) R.fobs.push_back(o);      // behind them: the observations of FIXED poses (fobs[fstart[np_free] .. n_obs))
+        {   // one free pose + at least one free point (stage 1 of localBundleAdjust): k_ba_one_pose reads the observations in point order, indices and values side by side
+            bool any_free_point = false;
+            for (int l = 0; l < Q.n_point && !any_free_point; ++l) any_free_point = !(Q.point_fixed && Q.point_fixed[l]);
+            int touching = 0;
+            if (R.np_free == 1) for (int k = 0; k < Q.n_pose_edge; ++k) touching += Q.edge_i[k] == R.free2pose[0] || Q.edge_j[k] == R.free2pose[0];
+            R.one_pose = R.np_free == 1 && any_free_point && Q.n_pose_edge <= OP_NT && touching <= PO_MAXE;
+            if (R.one_pose) {
+                R.op_pose.resize(Q.n_obs); R.op_o.resize(Q.n_obs); R.op_uvi.resize(3 * (size_t)Q.n_obs);
+                for (int ii = 0; ii < Q.n_obs; ++ii) {
+                    const int o = R.pt_obs[ii];
+                    R.op_pose[ii] = Q.obs_pose[o]; R.op_o[ii] = o;
+                    R.op_uvi[3 * (size_t)ii] = Q.obs_uv[2 * (size_t)o]; R.op_uvi[3 * (size_t)ii + 1] = Q.obs_uv[2 * (size_t)o + 1]; R.op_uvi[3 * (size_t)ii + 2] = Q.obs_info[o];
+                }
+            }
+        }
         // envelope of the reduced camera matrix at pose level: the first free pose each free pose is coupled with (a shared point or a
         // pose-pose edge), and the free observations of every free point, sorted by free pose (flat arrays: the fused Schur pass is built from them)
         std::vector<int> first(R.np_free);
@@ -3155,6 +3621,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             O.fs_bobs[set] = bump(4 * F.b_obs_start.size()); O.fs_brun[set] = bump(4 * F.b_run_start.size()); O.fs_bfmt[set] = bump(4 * F.b_fmt.size()); O.fs_pobs[set] = bump(4 * F.pobs.size());
             O.fs_pairs[set] = bump(2 * F.pairs.size() + 16); O.fs_rowoff[set] = bump(4 * F.rowoff.size()); O.fs_yoff[set] = bump(4 * F.yoff.size());
         }
+        O.op_pose = bump(4 * R.op_pose.size()); O.op_o = bump(4 * R.op_o.size()); O.op_uvi = bump(sizeof(double) * R.op_uvi.size());
         in_hi[p] = total;
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
@@ -3164,6 +3631,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.dinv = bump((n6 + 16) * D);
         O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
         O.bar = bump(256); O.red = bump(4 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
+        O.op_rec = bump(R.one_pose ? 28 * (size_t)Q.n_point * D : 8); O.op_red = bump(R.one_pose ? 2 * (size_t)kMaxTeam * OP_NV * D : 8);
     }
     const double tm1 = tm_now();
     ms_ba *B = new ms_ba();
@@ -3221,6 +3689,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             up(O.fs_pobs[set], F.pobs.data(), 4 * F.pobs.size()); up(O.fs_pairs[set], F.pairs.data(), 2 * F.pairs.size());
             up(O.fs_rowoff[set], F.rowoff.data(), 4 * F.rowoff.size()); up(O.fs_yoff[set], F.yoff.data(), 4 * F.yoff.size());
         }
+        up(O.op_pose, R.op_pose.data(), 4 * R.op_pose.size()); up(O.op_o, R.op_o.data(), 4 * R.op_o.size()); up(O.op_uvi, R.op_uvi.data(), sizeof(double) * R.op_uvi.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
         if (hipMemcpyAsync(B->d_arena + in_lo[p], stage, stage_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
@@ -3259,6 +3728,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.dinv = PTR(double, dinv);
         H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
         H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1; H.chol_team = 1;
+        H.op_pose = R.one_pose ? PTR(int32_t, op_pose) : nullptr; H.op_o = R.one_pose ? PTR(int32_t, op_o) : nullptr; H.op_uvi = R.one_pose ? PTR(double, op_uvi) : nullptr;
+        H.op_rec = R.one_pose ? PTR(double, op_rec) : nullptr; H.op_red = R.one_pose ? PTR(double, op_red) : nullptr;
+        if (p == 0) B->one_pose = R.one_pose; else B->one_pose = B->one_pose && R.one_pose;
         B->chol_tiles.push_back(R.chol_tiles);
         {   // poseBundleAdjust-shaped: one free pose, no free point
             bool po = R.np_free == 1 && problems[p].n_pose_edge <= PO_MAXE;
@@ -3268,7 +3740,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
 #undef PTR
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose), hipFuncAttributeMaxDynamicSharedMemorySize, 7 * OP_MAX_LDS_POSES * (int)sizeof(double)) != hipSuccess) {
         ms_ba_destroy(B);
         return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
     }
@@ -3328,13 +3801,26 @@ int ms_ba_solve(ms_ba *B) {
     if (B->pose_only && B->team <= 1 && !std::getenv("MS_BA_NO_POSE_KERNEL")) {      // (an explicit team request keeps the general kernel: tests compare the two)
         hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), 0, c->stream, B->d_probs);
         MS_KERNEL_CHECK(c, "k_ba_pose_only");
-        B->launched_team = 1; B->team_checked = true;
+        B->launched_team = 1; B->team_checked = true; B->last_one_pose = false;
         return MS_OK;
     }
-    int most_obs = 0;
-    for (const auto &h : B->host) most_obs = std::max(most_obs, h.n_obs);
-    int team = B->team == 0 ? std::min(32, std::max(1, most_obs / 512)) : B->team;      // small problems are latency-bound on the barriers
+    int most_obs = 0, most_points = 0, most_poses = 0;
+    for (const auto &h : B->host) { most_obs = std::max(most_obs, h.n_obs); most_points = std::max(most_points, h.n_point); most_poses = std::max(most_poses, h.n_pose); }
+    // stage 1 of localBundleAdjust (one free pose, free points): a kernel of its own, with or without a team
+    const bool one_pose = B->one_pose && !std::getenv("MS_BA_NO_ONE_POSE_KERNEL");
+    int team = B->team == 0 ? (one_pose ? std::min(16, std::max(1, most_obs / 1024)) : std::min(32, std::max(1, most_obs / 512))) : B->team;      // small problems are latency-bound on the barriers
     team = std::max(1, std::min(team, B->cus / std::max(B->n, 1)));
+    int lgG = 0;                                                          // lanes per point: as many as the launch has to spare, at most 8
+    if (one_pose) {
+        if (const char *e = std::getenv("MS_BA_ONE_POSE_LANES")) { const int g = std::atoi(e); lgG = g >= 8 ? 3 : g >= 4 ? 2 : g >= 2 ? 1 : 0; }
+        else while (lgG < 3 && (long long)(team * OP_NT >> (lgG + 1)) >= most_points) ++lgG;
+    }
+    const size_t op_lds_bytes = most_poses <= OP_MAX_LDS_POSES ? 7 * (size_t)most_poses * sizeof(double) : 0;
+    auto launch_lm = [&](int tm) {
+        if (one_pose) hipLaunchKernelGGL(k_ba_one_pose, dim3(B->n * tm), dim3(OP_NT), op_lds_bytes, c->stream, B->d_probs, tm, lgG);
+        else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, c->stream, B->d_probs, tm);
+    };
+    B->last_one_pose = one_pose; B->one_pose_lg = lgG;
     // the distributed factorisation is barrier-bound on banded systems: it gets one workgroup per 16 row tiles a panel touches
     bool changed = team != B->host[0].team;
     for (int i = 0; i < B->n; ++i) {
@@ -3381,7 +3867,7 @@ int ms_ba_solve(ms_ba *B) {
             in_use -= t.wgs;
         }
         hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, c->stream, B->d_probs, B->n, B->debug_fail_barriers);
-        hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
+        launch_lm(team);
         MS_KERNEL_CHECK(c, "k_ba_lm");
         TeamLaunch *slot = nullptr;
         for (TeamLaunch &t : live) if (!t.live) { slot = &t; break; }
@@ -3399,7 +3885,7 @@ int ms_ba_solve(ms_ba *B) {
         slot->stream = c->stream; slot->wgs = need; slot->live = true;
         if (slot != &live.back()) std::rotate(slot, slot + 1, &live.back() + 1);      // keep the list in launch order (oldest first)
     } else {
-        hipLaunchKernelGGL(k_ba_lm, dim3(B->n * team), dim3(NT), kLdsBytes, c->stream, B->d_probs, team);
+        launch_lm(team);
         MS_KERNEL_CHECK(c, "k_ba_lm");
     }
     B->launched_team = team;
@@ -3412,7 +3898,11 @@ static int ba_relaunch_single(ms_ba *B) {
     ms_ctx *c = B->ctx;
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
     MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
+    if (B->last_one_pose) {
+        int most_poses = 0;
+        for (const auto &h : B->host) most_poses = std::max(most_poses, h.n_pose);
+        hipLaunchKernelGGL(k_ba_one_pose, dim3(B->n), dim3(OP_NT), most_poses <= OP_MAX_LDS_POSES ? 7 * (size_t)most_poses * sizeof(double) : 0, c->stream, B->d_probs, 1, 0);
+    } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
     MS_KERNEL_CHECK(c, "k_ba_lm");
     MS_HIP(c, hipStreamSynchronize(c->stream));
     B->launched_team = 1;

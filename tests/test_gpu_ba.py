@@ -397,3 +397,53 @@ def test_pose_only_kernel_equals_the_general_solver_and_the_oracle(oracle, ctx, 
         _check(q, g3, w3)
         b3.close()
     ba.close()
+
+
+def _stage1(p, cur):
+    s = dict(p); s["pose_fixed"] = np.ones(len(p["pose"]), np.uint8); s["pose_fixed"][cur] = 0
+    return s
+
+
+def test_one_pose_kernel_equals_the_general_solver_and_the_oracle(oracle, ctx, monkeypatch):
+    """Stage 1 of localBundleAdjust (bundle_adjuster.cpp:251-252, :322-333: only the current keyframe free, every point free) goes to k_ba_one_pose.  The same
+    windows through the general kernel (MS_BA_NO_ONE_POSE_KERNEL) and through the oracle: the same LM trajectory and end state -- one workgroup per window,
+    teams of 2 .. 16 workgroups, 1 .. 8 lanes per point, the current keyframe first / last / in the middle, some points fixed, outliers under the Huber
+    kernel, a start far from the optimum (rejected steps), and the 50-keyframe window of the bench."""
+    import mi355slam
+    iters = 8
+    base = ba_synth.make_problem(12, 400, 6, seed=7)
+    far = _stage1(ba_synth.make_problem(12, 300, 8, seed=5), 11)
+    far["point"] = far["point"] + np.random.default_rng(3).normal(0, 4.0, far["point"].shape)
+    some_fixed = _stage1(ba_synth.make_problem(9, 250, 5, seed=12), 4)
+    some_fixed["point_fixed"] = (np.arange(250) % 3 == 0).astype(np.uint8)
+    outl = _stage1(ba_synth.make_problem(17, 111, 17, seed=4, outlier_frac=0.1), 16)
+    probs = [_stage1(base, 11), _stage1(base, 0), _stage1(base, 5), far, some_fixed, outl, _stage1(ba_synth.make_problem(), 49)]
+    wants = [oracle.ba_solve(q, iters, False) for q in probs]
+    assert wants[3]["stats"]["trials"] > wants[3]["stats"]["iters"]                     # the far start rejects at least one step
+    ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=iters)
+    monkeypatch.setenv("MS_BA_NO_ONE_POSE_KERNEL", "1")
+    ba.solve()
+    slow = [ba.download(i) for i in range(len(probs))]
+    monkeypatch.delenv("MS_BA_NO_ONE_POSE_KERNEL")
+    for team, lanes in ((1, None), (1, 2), (2, None), (5, 4), (16, None), (16, 1), (8, 8)):
+        if lanes is None: monkeypatch.delenv("MS_BA_ONE_POSE_LANES", raising=False)
+        else: monkeypatch.setenv("MS_BA_ONE_POSE_LANES", str(lanes))
+        ba.set_team(team); ba.solve()
+        for i, q in enumerate(probs):
+            got = ba.download(i)
+            _check(q, got, wants[i])
+            assert np.abs(got["pose"] - slow[i]["pose"]).max() < 1e-8 and np.abs(got["point"] - slow[i]["point"]).max() < 1e-8
+            fixed = q["pose_fixed"].astype(bool)
+            assert np.array_equal(got["pose"][fixed], q["pose"][fixed])                 # the fixed keyframes did not move
+            if q.get("point_fixed") is not None:
+                pf = q["point_fixed"].astype(bool)
+                assert np.array_equal(got["point"][pf], q["point"][pf])
+        assert ba.team_fallbacks() == 0
+    monkeypatch.delenv("MS_BA_ONE_POSE_LANES", raising=False)
+    for i, q in enumerate(probs):
+        _check(q, slow[i], wants[i])
+    ba.close()
+    # one window alone picks its team and lanes by itself
+    one = mi355slam.BundleAdjuster(ctx, [probs[6]], max_iters=iters); one.solve()
+    _check(probs[6], one.download(0), wants[6])
+    one.close()
