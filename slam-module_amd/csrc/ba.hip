@@ -2735,14 +2735,19 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
 // still walked it through its whole machinery (pass sets, LDS tile, windowed Cholesky of one block, ~7 team barriers per damped solve): 0.60 ms for the
 // 8 iterations of a C4 window on 32 workgroups, 3.3 ms for 256 such windows with one workgroup each.  Here a point belongs to a GROUP of G = 1 .. 8
 // neighbouring lanes (G chosen so that the launch's lanes cover the points): the group's lanes share the point's observations out, their sums meet over
-// the DPP network, lane 0 of the group keeps the point's record (Hll, bl, W = sum of Jp^T w Jl over the point's observations in the free keyframe) in
-// memory that only this workgroup touches.  Per damped solve: every group forms its point's W (Hll + lambda I)^-1 W^T / ... bl (3 x 3 Cholesky, as in
-// schur_fused) and adds them into 27 LDS accumulators -- only ~1 point in 4 is seen by the free keyframe, so these are few atomics --, ONE reduction over
-// the team, the 6 x 6 Cholesky in every thread (as in k_ba_pose_only), then each group back-substitutes its point, moves it, and evaluates the robust chi2 of
-// its observations at the trial state; a second reduction (chi2, gain denominator) decides.  Trial points live in point_bk and are copied on acceptance:
-// no backup / restore pass.  Observation data comes from copies sorted by point (pose index, u, v, information side by side: one round trip instead of
-// three dependent ones), the poses from an LDS table.  Same LM schedule and the same arithmetic per edge as k_ba_lm.
-constexpr int OP_NT = 512, OP_NW = OP_NT / 64, OP_NV = 64, OP_MAX_LDS_POSES = 1024;
+// the DPP network.  With a lane group per point (ONE: a single window on a team) the point -- position, Hll, bl, W = sum of Jp^T w Jl over its observations
+// in the free keyframe -- stays in the group's REGISTERS from the first linearisation to the last trial; a batch (one workgroup per window, several points
+// per group) keeps these records in memory that only the owning workgroup touches.  Per iteration: linearise, and in the same pass every group forms its
+// point's W (Hll + lambda I)^-1 W^T and W (Hll + lambda I)^-1 bl (3 x 3 Cholesky, as in schur_fused).  Only ~1 point in 4 is seen by the free keyframe, so
+// these 27-value contributions are SPARSE: the contributing lanes write them side by side into the wave's LDS slab, the wave adds the entries up and issues
+// one atomic per value (27 uniform-address atomics per observation cost a wave reduction each: 5 x the time of everything else).  ONE reduction over the
+// team, the 6 x 6 Cholesky in every thread (as in k_ba_pose_only), then each group back-substitutes its point, moves it, and evaluates the robust chi2 of
+// its observations at the trial state; a second reduction (chi2, gain denominator) decides.  Trial points are separate from the accepted ones: no backup /
+// restore pass.  Observation data comes from copies sorted by point (pose index, u, v, information side by side: one round trip instead of three dependent
+// ones), the poses from an LDS table.  Same LM schedule and the same arithmetic per edge as k_ba_lm.
+constexpr int OP_NT = 512, OP_NW = OP_NT / 64, OP_NV = 64, OP_MAX_LDS_POSES = 512;
+constexpr int OP_S0 = 32, OP_BAD = 59, OP_MAX = 63;          // accumulators: 0..20 Hpp, 21..26 bp | 32..52 Schur matrix terms, 53..58 rhs terms, 59 unsound point blocks | 63 largest diagonal entry
+__host__ __device__ constexpr int op_slab_cap(int lgG) { return lgG == 0 ? 64 : 32; }     // entries of a wave's staging slab
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_d(double v) {
@@ -2777,26 +2782,72 @@ __device__ __forceinline__ bool chol3(const double *H, double lambda, Chol3 &c) 
     return a > 0 && d2 > 0 && d3 > 0 && isfinite(c.i11 * c.i22 * c.i33);
 }
 
-__global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int team, int lgG) {
-    extern __shared__ __attribute__((aligned(16))) double op_lds[];      // [7 n_pose] the poses (when they fit)
+// Sparse sums: a few lanes of a wave hold 27 values each whose sums go into acc[0 .. 27).  The contributors write their values side by side into the wave's
+// slab ([27][cap], value-major: neighbouring entries in neighbouring banks; entry = a running index over the wave's contributors), then the wave adds the
+// entries up -- value k by lanes 2k and 2k + 1 (even / odd entries) -- and issues one atomic per value.  A contributor beyond the slab's capacity adds its
+// values with plain atomics.
+__device__ __forceinline__ void slab_put(MS_LDS double *slab, int cap, MS_LDS double *acc, int idx, const double (&v)[27]) {
+    if (idx < cap) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) slab[k * cap + idx] = v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) lds_addd(acc + k, v[k]);
+    }
+}
+__device__ __forceinline__ void slab_sum(MS_LDS double *slab, int cap, MS_LDS double *acc, int n, int lane) {      // wave-uniform call, n wave-uniform
+    if (n == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ns = min(n, cap);
+    if (lane < 54) {
+        const int k = lane >> 1;
+        double t = 0;
+        for (int e = lane & 1; e < ns; e += 2) t += slab[k * cap + e];
+        t += dpp_move_d<0xB1>(t);
+        if ((lane & 1) == 0) lds_addd(acc + k, t);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+struct OpPoint { double X[3], H[6], bl[3], W[18]; int nf, i0, i1; bool pfree; };       // nf: the point's observations in the free keyframe (group total)
+
+template <bool ONE>     // ONE: the launch has a lane group per point -- the point's record lives in registers for the whole solve
+__global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int team, int lgG, int pose_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double op_lds[];      // [7 n_pose] the poses (when they fit), then the waves' staging slabs [8][27][cap]
     __shared__ double s_acc[OP_NV], s_sum[OP_NV], s_w[OP_NW * 2];
     __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
     __shared__ int s_eSide[PO_MAXE], s_ne;
     const BaProb &P = probs[blockIdx.x / (unsigned)team];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rank = team > 1 ? (int)(blockIdx.x % (unsigned)team) : 0;
     const int G = 1 << lgG, gl = rank * OP_NT + tid, sub = gl & (G - 1), slot = gl >> lgG, nslot = (team * OP_NT) >> lgG;
-    const int pi = P.free2pose[0], n_point = P.n_point;
-    const bool lds_poses = P.n_pose <= OP_MAX_LDS_POSES;
-    const double *ptab = lds_poses ? op_lds : P.pose0;
+    const int pi = P.free2pose[0], n_point = P.n_point, cap = op_slab_cap(lgG);
+    const bool lds_poses = pose_doubles > 0;                              // (the host's decision for the whole launch: every problem's poses fit the table then)
+    MS_LDS double *slab = (MS_LDS double *)op_lds + pose_doubles + wave * 27 * cap;
+    MS_LDS double *acc = (MS_LDS double *)s_acc;
     const MS_GLOBAL int32_t *o_pose = (const MS_GLOBAL int32_t *)P.op_pose, *o_idx = (const MS_GLOBAL int32_t *)P.op_o, *pt_start = (const MS_GLOBAL int32_t *)P.pt_start;
     const MS_GLOBAL double *o_uvi = (const MS_GLOBAL double *)P.op_uvi;
-    MS_GLOBAL double *rec = (MS_GLOBAL double *)P.op_rec;                 // [28][n_point]: Hll 0-5, bl 6-8, W 9-26, 27 = observations in the free keyframe
+    MS_GLOBAL double *rec = (MS_GLOBAL double *)P.op_rec;                 // (not ONE) [28][n_point]: Hll 0-5, bl 6-8, W 9-26, 27 = observations in the free keyframe, -1 for a fixed point
     MS_GLOBAL double *point = (MS_GLOBAL double *)P.point, *trial = (MS_GLOBAL double *)P.point_bk;
     const MS_GLOBAL uint8_t *pfix = (const MS_GLOBAL uint8_t *)P.point_fixed;
+    const int nrounds = ONE ? 1 : (n_point + nslot - 1) / nslot;
     int seq = 0;
     for (int i = gl; i < 7 * P.n_pose; i += team * OP_NT) P.pose[i] = P.pose0[i];
     if (lds_poses) for (int i = tid; i < 7 * P.n_pose; i += OP_NT) op_lds[i] = P.pose0[i];
-    for (int l = slot; l < n_point; l += nslot) if (sub == 0) { point[3 * (size_t)l] = P.point0[3 * (size_t)l]; point[3 * (size_t)l + 1] = P.point0[3 * (size_t)l + 1]; point[3 * (size_t)l + 2] = P.point0[3 * (size_t)l + 2]; }
+    OpPoint ps;
+    double Xt[3] = {0, 0, 0};                                             // ONE: the trial point
+    auto point_begin = [&](int l, bool from_point0) {                     // the point's observation range, its flag and its position
+        ps.i0 = ps.i1 = 0; ps.pfree = false; ps.nf = 0; ps.X[0] = ps.X[1] = ps.X[2] = 0;
+        if (l < n_point) {
+            ps.i0 = pt_start[l]; ps.i1 = pt_start[l + 1]; ps.pfree = !(pfix && pfix[l]);
+            const MS_GLOBAL double *src = from_point0 ? (const MS_GLOBAL double *)P.point0 : point;
+            ps.X[0] = src[3 * (size_t)l]; ps.X[1] = src[3 * (size_t)l + 1]; ps.X[2] = src[3 * (size_t)l + 2];
+        }
+    };
+    if (ONE) point_begin(slot, true);
+    else for (int l = slot; l < n_point; l += nslot) if (sub == 0) { point[3 * (size_t)l] = P.point0[3 * (size_t)l]; point[3 * (size_t)l + 1] = P.point0[3 * (size_t)l + 1]; point[3 * (size_t)l + 2] = P.point0[3 * (size_t)l + 2]; }
     if (tid < OP_NV) s_acc[tid] = 0;
     if (tid < 24) s_Hc[tid] = 0;
     if (tid == 0) { s_ne = 0; s_const = 0; }
@@ -2832,27 +2883,29 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     }
     __syncthreads();
     const int ne = rank == 0 ? s_ne : 0;
-    // ---- sums over the team.  vec: the LDS accumulators s_acc[0 .. nv) (atomic contributions of this workgroup) -> s_sum[0 .. nv), the same bits in every
-    //      workgroup (partials combined in rank order); slot 63 is combined as a maximum (non-negative doubles order like their bit patterns)
-    auto vec_reduce = [&](int nv, bool with_max) {
+    // ---- sums over the team: the LDS accumulators s_acc[lo .. hi) (contributions of this workgroup) -> s_sum[lo .. hi), the same bits in every
+    //      workgroup (partials combined in rank order); slot OP_MAX is combined as a maximum
+    auto vec_reduce = [&](int lo, int hi, bool with_max) {
         __syncthreads();
-        double mine = 0, mx = 0;
-        if (tid < nv) { mine = s_acc[tid]; s_acc[tid] = 0; }
-        if (with_max && tid == OP_NV - 1) { mx = s_acc[OP_NV - 1]; s_acc[OP_NV - 1] = 0; }
+        const bool mine_slot = (tid >= lo && tid < hi) || (with_max && tid == OP_MAX);
+        double mine = 0;
+        if (mine_slot) { mine = s_acc[tid]; s_acc[tid] = 0; }
         if (team > 1) {
             double *part = P.op_red + (size_t)(seq & 1) * team * OP_NV;
-            if (tid < nv) part[(size_t)rank * OP_NV + tid] = mine;
-            if (with_max && tid == OP_NV - 1) part[(size_t)rank * OP_NV + OP_NV - 1] = mx;
+            if (mine_slot) part[(size_t)rank * OP_NV + tid] = mine;
             team_sync(P);
-            if (tid < nv) { double t = part[tid]; for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid]; mine = t; }
-            if (with_max && tid == OP_NV - 1) { double t = part[OP_NV - 1]; for (int r = 1; r < team; ++r) t = fmax(t, part[(size_t)r * OP_NV + OP_NV - 1]); mx = t; }
+            if (mine_slot) {
+                double t = part[tid];
+                if (tid == OP_MAX) { for (int r = 1; r < team; ++r) t = fmax(t, part[(size_t)r * OP_NV + tid]); }
+                else for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid];
+                mine = t;
+            }
         }
         ++seq;
-        if (tid < nv) s_sum[tid] = mine;
-        if (with_max && tid == OP_NV - 1) s_sum[OP_NV - 1] = mx;
+        if (mine_slot) s_sum[tid] = mine;
         __syncthreads();
     };
-    // two plain sums (fixed order: lanes, waves, ranks) -> s_sum[32], s_sum[33]
+    // two plain sums (fixed order: lanes, waves, ranks) -> s_sum[28], s_sum[29]
     auto pair_reduce = [&](double a, double b) {
         a = wave_sum_d(a); b = wave_sum_d(b);
         __syncthreads();
@@ -2867,206 +2920,263 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
             if (tid < 2) { double t = part[tid]; for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid]; mine = t; }
         }
         ++seq;
-        if (tid < 2) s_sum[32 + tid] = mine;
+        if (tid < 2) s_sum[28 + tid] = mine;
         __syncthreads();
     };
     auto load_pose = [&](int pc, const double (&cur)[7], double (&pz)[7]) {
         if (pc == pi) {
 #pragma unroll
             for (int a = 0; a < 7; ++a) pz[a] = cur[a];
-        } else {
+        } else if (lds_poses) {                                           // (explicit address spaces: a flat load would wait for the prefetched global data as well)
+            const MS_LDS double *q = (const MS_LDS double *)op_lds + 7 * pc;
 #pragma unroll
-            for (int a = 0; a < 7; ++a) pz[a] = ptab[7 * (size_t)pc + a];
+            for (int a = 0; a < 7; ++a) pz[a] = q[a];
+        } else {
+            const MS_GLOBAL double *q = (const MS_GLOBAL double *)P.pose0 + 7 * (size_t)pc;
+#pragma unroll
+            for (int a = 0; a < 7; ++a) pz[a] = q[a];
         }
     };
-    // ---- robust chi2 of the group's share of point l's observations with the point at X and the free pose at `cur`
-    auto chi2_share = [&](int l, const double (&X)[3], const double (&cur)[7], bool store) {
-        double acc = 0;
-        const int iend = pt_start[l + 1];
-        int ii = pt_start[l] + sub, pn = 0;
+    // ---- robust chi2 of this lane's share of the observations [i0, i1) of a point at X, with the free pose at `cur`
+    auto chi2_share = [&](int i0, int i1, const double (&X)[3], const double (&cur)[7], bool store) {
+        double sum = 0;
+        int ii = i0 + sub, pn = 0;
         double un = 0, vn = 0, fn = 0;
-        if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
-        while (ii < iend) {
-            const int pc = pn, i0 = ii;
+        if (ii < i1) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+        while (ii < i1) {
+            const int pc = pn, icur = ii;
             const double uvc[2] = {un, vn}, infc = fn;
             ii += G;
-            if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+            if (ii < i1) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
             double pz[7], e[2], r, w;
             load_pose(pc, cur, pz);
             proj_edge<false>(pz, X, uvc, e, nullptr, nullptr);
             const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
             huber(chi2, P.huber, r, w);
-            if (store) P.chi2_obs[o_idx[i0]] = chi2;
-            acc += r;
+            if (store) P.chi2_obs[o_idx[icur]] = chi2;
+            sum += r;
         }
-        return acc;
+        return sum;
     };
     // the SE3 edges at the free pose `cur` (lanes < ne of the team's first workgroup): chi2, and with lin the gradient into the accumulators
     auto edge_part = [&](const double (&cur)[7], bool lin) {
-        double acc = 0;
+        double sum = 0;
         if (tid < ne) {
             double Bm[7], e[6], We[6];
             if (s_eSide[tid] == 0) se3_mul(s_eC[tid], cur, Bm);
             else { double Tjinv[7], A2[7]; se3_inv(cur, Tjinv); se3_mul(Tjinv, s_eM[tid], A2); se3_mul(A2, s_eC[tid], Bm); }
             se3_log(Bm, e);
             for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[tid][6 * i + j] * e[j]; We[i] = v; }
-            for (int i = 0; i < 6; ++i) acc += e[i] * We[i];
-            if (lin) for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[tid][6 * a + c] * e[c]; lds_addd((MS_LDS double *)&s_acc[21 + a], v); }
+            for (int i = 0; i < 6; ++i) sum += e[i] * We[i];
+            if (lin) for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[tid][6 * a + c] * e[c]; lds_addd(acc + 21 + a, v); }
         }
-        if (rank == 0 && tid == 0) acc += s_const;
-        return acc;
+        if (rank == 0 && tid == 0) sum += s_const;
+        return sum;
     };
-    auto total_chi2 = [&](const double (&cur)[7], bool trial_points, bool store, double extra) {
-        double acc = 0;
-        for (int l = slot; l < n_point; l += nslot) {
-            const MS_GLOBAL double *src = trial_points ? trial : point;
-            const double X[3] = {src[3 * (size_t)l], src[3 * (size_t)l + 1], src[3 * (size_t)l + 2]};
-            acc += chi2_share(l, X, cur, store);
+    auto total_chi2 = [&](const double (&cur)[7], bool store) {          // at the accepted state
+        double sum = 0;
+        for (int rnd = 0; rnd < nrounds; ++rnd) {
+            if (!ONE) point_begin(slot + rnd * nslot, false);
+            sum += chi2_share(ps.i0, ps.i1, ps.X, cur, store);
         }
-        acc += edge_part(cur, false);
-        pair_reduce(acc, extra);
-        return s_sum[32];
+        sum += edge_part(cur, false);
+        pair_reduce(sum, 0.0);
+        return s_sum[28];
     };
-    // ---- the point's part of the damped system: S -= W (Hll + lambda I)^-1 W^T (upper triangle, 21), y -= W (Hll + lambda I)^-1 bl (6), into the accumulators
-    auto schur_point = [&](const double (&H)[6], const double (&bl)[3], const double (&Wm)[18], double lambda) {
+    // ---- the point's part of the damped system: -W (Hll + lambda I)^-1 W^T (upper triangle, 21) and -W (Hll + lambda I)^-1 bl (6)
+    auto schur_point = [&](double lambda, double (&Sv)[27]) {
         Chol3 c;
-        if (!chol3(H, lambda, c)) lds_addd((MS_LDS double *)&s_acc[27], 1.0);
-        const double u0 = bl[0] * c.i11, u1 = (bl[1] - c.l21 * u0) * c.i22, u2 = (bl[2] - c.l31 * u0 - c.l32 * u1) * c.i33;
+        const bool sound = chol3(ps.H, lambda, c);
+        const double u0 = ps.bl[0] * c.i11, u1 = (ps.bl[1] - c.l21 * u0) * c.i22, u2 = (ps.bl[2] - c.l31 * u0 - c.l32 * u1) * c.i33;
         double Z[18];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const double z0 = Wm[3 * r] * c.i11, z1 = (Wm[3 * r + 1] - z0 * c.l21) * c.i22, z2 = (Wm[3 * r + 2] - z0 * c.l31 - z1 * c.l32) * c.i33;
+            const double z0 = ps.W[3 * r] * c.i11, z1 = (ps.W[3 * r + 1] - z0 * c.l21) * c.i22, z2 = (ps.W[3 * r + 2] - z0 * c.l31 - z1 * c.l32) * c.i33;
             Z[3 * r] = z0; Z[3 * r + 1] = z1; Z[3 * r + 2] = z2;
-            lds_addd((MS_LDS double *)&s_acc[21 + r], -(z0 * u0 + z1 * u1 + z2 * u2));
+            Sv[21 + r] = -(z0 * u0 + z1 * u1 + z2 * u2);
         }
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b2 = a; b2 < 6; ++b2) { lds_addd((MS_LDS double *)&s_acc[k], -(Z[3 * a] * Z[3 * b2] + Z[3 * a + 1] * Z[3 * b2 + 1] + Z[3 * a + 2] * Z[3 * b2 + 2])); ++k; }
+            for (int b2 = a; b2 < 6; ++b2) { Sv[k] = -(Z[3 * a] * Z[3 * b2] + Z[3 * a + 1] * Z[3 * b2 + 1] + Z[3 * a + 2] * Z[3 * b2 + 2]); ++k; }
+        return sound;
+    };
+    // one point's Schur terms into the accumulators (the group's first lane contributes); wave-uniform call
+    auto schur_stage = [&](bool live, double lambda) {
+        double Sv[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) Sv[k] = 0;
+        bool contributes = false;
+        if (live && sub == 0 && ps.pfree) {
+            if (ps.nf > 0) { contributes = true; if (!schur_point(lambda, Sv)) lds_addd(acc + OP_BAD, 1.0); }
+            else { Chol3 c; if (!chol3(ps.H, lambda, c)) lds_addd(acc + OP_BAD, 1.0); }
+        }
+        const unsigned long long m = __ballot(contributes);
+        if (contributes) slab_put(slab, cap, acc + OP_S0, lanes_below(m), Sv);
+        slab_sum(slab, cap, acc + OP_S0, (int)__popcll(m), lane);
+    };
+    auto rec_store = [&](int l) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rec[(size_t)q * n_point + l] = ps.H[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rec[(size_t)(6 + q) * n_point + l] = ps.bl[q];
+        if (ps.nf > 0) {
+#pragma unroll
+            for (int q = 0; q < 18; ++q) rec[(size_t)(9 + q) * n_point + l] = ps.W[q];
+        }
+        rec[(size_t)27 * n_point + l] = ps.pfree ? (double)ps.nf : -1.0;
+    };
+    auto rec_load = [&](int l) {
+        const double nfv = rec[(size_t)27 * n_point + l];
+        ps.nf = nfv > 0 ? (int)nfv : 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ps.H[q] = rec[(size_t)q * n_point + l];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ps.bl[q] = rec[(size_t)(6 + q) * n_point + l];
+        if (nfv > 0) {
+#pragma unroll
+            for (int q = 0; q < 18; ++q) ps.W[q] = rec[(size_t)(9 + q) * n_point + l];
+        }
     };
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, stop = 0;
-    const double chi2_init = total_chi2(pose, false, false, 0.0);
+    long long cyc[6] = {0, 0, 0, 0, 0, 0}, tq = clock64();                 // 0 chi2 sweeps, 1 linearise (+ Schur terms), 2 the reduction after it, 3 6 x 6 solve, 4 points + trial chi2, 5 the reduction after it
+    const long long t_begin = tq;
+#define OP_LAP(i) do { const long long t_ = clock64(); cyc[i] += t_ - tq; tq = t_; } while (0)
+    const double chi2_init = total_chi2(pose, false);
+    OP_LAP(0);
     double chi2_carried = chi2_init;
     for (it = 0; it < P.max_iters; ++it) {
         double current = chi2_carried, temp = current;
-        // ---- linearisation: per point Hll, bl, W into its record; the free pose's block and gradient into the accumulators 0..20 / 21..26
+        // ---- linearisation: per point Hll, bl, W; the free pose's block and gradient (A: 21 + 6, this lane's part).  From the second iteration on lambda is
+        //      known and the points' Schur terms follow in the same pass: one reduction instead of two
         double md = 0;
-        for (int l = slot; l < n_point; l += nslot) {
-            const bool pfree = !(pfix && pfix[l]);
-            const double X[3] = {point[3 * (size_t)l], point[3 * (size_t)l + 1], point[3 * (size_t)l + 2]};
-            double H[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0}, Wm[18];
+        for (int rnd = 0; rnd < nrounds; ++rnd) {
+            const int l = slot + rnd * nslot;
+            const bool live = l < n_point;
+            if (!ONE) point_begin(l, false);
 #pragma unroll
-            for (int q = 0; q < 18; ++q) Wm[q] = 0;
-            int nf = 0;
-            const int iend = pt_start[l + 1];
-            int ii = pt_start[l] + sub, pn = 0;
-            double un = 0, vn = 0, fn = 0;
-            if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
-            while (ii < iend) {
-                const int pc = pn;
-                const double uvc[2] = {un, vn}, infc = fn;
-                ii += G;
-                if (ii < iend) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
-                double pz[7], e[2], Jp[12], Jl[6], r, w;
-                load_pose(pc, pose, pz);
-                proj_edge<true>(pz, X, uvc, e, Jp, Jl);
-                const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
-                huber(chi2, P.huber, r, w);
-                const double wi = w * infc;
-                if (pfree) {
-                    H[0] += wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); H[1] += wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); H[2] += wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
-                    H[3] += wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); H[4] += wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); H[5] += wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+            for (int q = 0; q < 6; ++q) ps.H[q] = 0;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) bl[c] -= wi * (Jl[c] * e[0] + Jl[3 + c] * e[1]);
+            for (int q = 0; q < 3; ++q) ps.bl[q] = 0;
+#pragma unroll
+            for (int q = 0; q < 18; ++q) ps.W[q] = 0;
+            const int i1 = ps.i1;
+            int jj = i1;                                                 // this lane's first observation in the free keyframe
+            if (ps.pfree) {                                              // the point's own block and gradient: every observation of the share
+                int ii = ps.i0 + sub, pn = 0;
+                double un = 0, vn = 0, fn = 0;
+                if (ii < i1) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+                while (ii < i1) {
+                    const int pc = pn;
+                    const double uvc[2] = {un, vn}, infc = fn;
+                    if (pc == pi && jj == i1) jj = ii;
+                    ii += G;
+                    if (ii < i1) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
+                    double pz[7], e[2], Jp[12], Jl[6], r, w;
+                    load_pose(pc, pose, pz);
+                    proj_edge<true>(pz, ps.X, uvc, e, Jp, Jl);
+                    const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
+                    huber(chi2, P.huber, r, w);
+                    const double wi = w * infc;
+                    ps.H[0] += wi * (Jl[0] * Jl[0] + Jl[3] * Jl[3]); ps.H[1] += wi * (Jl[0] * Jl[1] + Jl[3] * Jl[4]); ps.H[2] += wi * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+                    ps.H[3] += wi * (Jl[1] * Jl[1] + Jl[4] * Jl[4]); ps.H[4] += wi * (Jl[1] * Jl[2] + Jl[4] * Jl[5]); ps.H[5] += wi * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ps.bl[c] -= wi * (Jl[c] * e[0] + Jl[3 + c] * e[1]);
                 }
-                if (pc == pi) {
+            } else { jj = ps.i0 + sub; while (jj < i1 && o_pose[jj] != pi) jj += G; }
+            // the observations in the free keyframe once more (one lane in four has one; a wave-uniform loop): the pose's block and gradient go straight into the
+            // wave's slab, W = Jp^T w Jl stays with the point -- keeping 27 more sums in registers through the loop above made the kernel spill
+            int nf = 0, cnt = 0;
+            for (;;) {
+                const bool has = jj < i1;
+                const unsigned long long m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    const double uvc[2] = {o_uvi[3 * (size_t)jj], o_uvi[3 * (size_t)jj + 1]}, infc = o_uvi[3 * (size_t)jj + 2];
+                    double e[2], Jp[12], Jl[6], r, w, A[27];
+                    proj_edge<true>(pose, ps.X, uvc, e, Jp, Jl);
+                    const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
+                    huber(chi2, P.huber, r, w);
+                    const double wi = w * infc;
                     int k = 0;
 #pragma unroll
                     for (int a = 0; a < 6; ++a) {
-                        lds_addd((MS_LDS double *)&s_acc[21 + a], -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi);
+                        A[21 + a] = -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi;
 #pragma unroll
-                        for (int b2 = a; b2 < 6; ++b2) { lds_addd((MS_LDS double *)&s_acc[k], wi * (Jp[a] * Jp[b2] + Jp[6 + a] * Jp[6 + b2])); ++k; }
+                        for (int b2 = a; b2 < 6; ++b2) { A[k] = wi * (Jp[a] * Jp[b2] + Jp[6 + a] * Jp[6 + b2]); ++k; }
                     }
-                    if (pfree) {
+                    slab_put(slab, cap, acc, cnt + lanes_below(m), A);
+                    if (ps.pfree) {
                         ++nf;
 #pragma unroll
                         for (int r2 = 0; r2 < 6; ++r2)
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) Wm[3 * r2 + c] += wi * (Jp[r2] * Jl[c] + Jp[6 + r2] * Jl[3 + c]);
+                            for (int c = 0; c < 3; ++c) ps.W[3 * r2 + c] += wi * (Jp[r2] * Jl[c] + Jp[6 + r2] * Jl[3 + c]);
                     }
+                    jj += G;
+                    while (jj < i1 && o_pose[jj] != pi) jj += G;
                 }
+                cnt += (int)__popcll(m);
             }
-            nf = group_sum_i(nf, lgG);
+            slab_sum(slab, cap, acc, cnt, lane);
+            ps.nf = group_sum_i(nf, lgG);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) H[q] = group_sum_d(H[q], lgG);
+            for (int q = 0; q < 6; ++q) ps.H[q] = group_sum_d(ps.H[q], lgG);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bl[q] = group_sum_d(bl[q], lgG);
-            if (nf > 0) {
+            for (int q = 0; q < 3; ++q) ps.bl[q] = group_sum_d(ps.bl[q], lgG);
+            if (ps.nf > 0) {
 #pragma unroll
-                for (int q = 0; q < 18; ++q) Wm[q] = group_sum_d(Wm[q], lgG);
+                for (int q = 0; q < 18; ++q) ps.W[q] = group_sum_d(ps.W[q], lgG);
             }
-            if (sub == 0) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) rec[(size_t)q * n_point + l] = H[q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) rec[(size_t)(6 + q) * n_point + l] = bl[q];
-                if (nf > 0) {
-#pragma unroll
-                    for (int q = 0; q < 18; ++q) rec[(size_t)(9 + q) * n_point + l] = Wm[q];
-                }
-                rec[(size_t)27 * n_point + l] = pfree ? (double)nf : -1.0;
-                if (pfree) md = fmax(md, fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5]))));
+            if (live && sub == 0) {
+                if (!ONE) rec_store(l);
+                if (ps.pfree) md = fmax(md, fmax(fabs(ps.H[0]), fmax(fabs(ps.H[3]), fabs(ps.H[5]))));
             }
+            if (it > 0) schur_stage(live, lambda);
         }
         (void)edge_part(pose, true);
-        if (rank == 0 && tid < 21) lds_addd((MS_LDS double *)&s_acc[tid], s_Hc[tid]);      // the edges' constant J^T W J: into the sums, so that every workgroup of the team gets it
+        OP_LAP(1);
+        if (rank == 0 && tid < 21) lds_addd(acc + tid, s_Hc[tid]);          // the edges' constant J^T W J: into the sums, so that every workgroup of the team gets it
         if (it == 0) {
             for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
-            if (lane == 0) (void)atomicMax(reinterpret_cast<unsigned long long *>(&s_acc[OP_NV - 1]), (unsigned long long)__double_as_longlong(md));
+            if (lane == 0) (void)atomicMax(reinterpret_cast<unsigned long long *>(&s_acc[OP_MAX]), (unsigned long long)__double_as_longlong(md));
         }
-        vec_reduce(27, it == 0);
-        double Hp[21], bp[6];
-#pragma unroll
-        for (int a = 0; a < 21; ++a) Hp[a] = s_sum[a];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) bp[a] = s_sum[21 + a];
+        vec_reduce(0, it == 0 ? 27 : OP_BAD + 1, it == 0);
+        OP_LAP(2);
+        const double *Hp = s_sum, *bp = s_sum + 21;                         // (they stay in LDS: 27 doubles in every thread's registers were a part of the kernel's spills)
         if (it == 0) {                                                       // computeLambdaInit: 1e-5 x the largest diagonal entry of the whole system
             const double mdp = fmax(fmax(fmax(fabs(Hp[0]), fabs(Hp[6])), fmax(fabs(Hp[11]), fabs(Hp[15]))), fmax(fabs(Hp[18]), fabs(Hp[20])));
-            lambda = 1e-5 * fmax(mdp, s_sum[OP_NV - 1]); ni = 2;
+            lambda = 1e-5 * fmax(mdp, s_sum[OP_MAX]); ni = 2;
         }
         double rho = 0;
         int qmax = 0;
+        bool have_schur = it > 0;                                            // the Schur terms at this lambda are in s_sum already
         do {
-            // ---- the points' Schur terms at this lambda
-            for (int l = slot; l < n_point; l += nslot) {
-                if (sub != 0) continue;
-                const double nfv = rec[(size_t)27 * n_point + l];
-                if (nfv < 0) continue;                                       // a fixed point
-                double H[6], bl[3], Wm[18];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) H[q] = rec[(size_t)q * n_point + l];
-                if (nfv > 0) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) bl[q] = rec[(size_t)(6 + q) * n_point + l];
-#pragma unroll
-                    for (int q = 0; q < 18; ++q) Wm[q] = rec[(size_t)(9 + q) * n_point + l];
-                    schur_point(H, bl, Wm, lambda);
-                } else { Chol3 c; if (!chol3(H, lambda, c)) lds_addd((MS_LDS double *)&s_acc[27], 1.0); }
+            if (!have_schur) {
+                for (int rnd = 0; rnd < nrounds; ++rnd) {
+                    const int l = slot + rnd * nslot;
+                    const bool live = l < n_point;
+                    if (!ONE) { ps.pfree = false; ps.nf = 0; if (live && sub == 0) { ps.pfree = !(pfix && pfix[l]); if (ps.pfree) rec_load(l); } }
+                    schur_stage(live, lambda);
+                }
+                OP_LAP(1);
+                vec_reduce(OP_S0, OP_BAD + 1, false);
+                OP_LAP(2);
             }
-            vec_reduce(28, false);
+            have_schur = false;
             // (S + lambda I) dp = y: the 6 x 6 Cholesky by every thread for itself, as in k_ba_pose_only
             double Lm[21], dpv[6], yv[6];
-            bool ok2 = s_sum[27] == 0.0;
+            bool ok2 = s_sum[OP_BAD] == 0.0;
             {
                 int k = 0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
 #pragma unroll
-                    for (int c = a; c < 6; ++c) { Lm[c * (c + 1) / 2 + a] = Hp[k] + s_sum[k] + (a == c ? lambda : 0.0); ++k; }
+                    for (int c = a; c < 6; ++c) { Lm[c * (c + 1) / 2 + a] = Hp[k] + s_sum[OP_S0 + k] + (a == c ? lambda : 0.0); ++k; }
 #pragma unroll
-                for (int a = 0; a < 6; ++a) yv[a] = bp[a] + s_sum[21 + a];
+                for (int a = 0; a < 6; ++a) yv[a] = bp[a] + s_sum[OP_S0 + 21 + a];
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -3104,44 +3214,42 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
             double trial_pose[7];
 #pragma unroll
             for (int a = 0; a < 7; ++a) trial_pose[a] = pose[a];
+            OP_LAP(3);
             if (ok2) {
-                double ex[7], sc = 0, acc = 0;
+                double ex[7], sc = 0, sum = 0;
                 se3_exp(dpv, ex);
                 se3_mul(ex, pose, trial_pose);
                 if (gl == 0) { for (int a = 0; a < 6; ++a) sc += dpv[a] * (lambda * dpv[a] + bp[a]); }
                 // ---- the points follow: dl = (Hll + lambda I)^-1 (bl - W^T dp), the trial point, its share of the gain denominator and the chi2 of its observations
-                for (int l = slot; l < n_point; l += nslot) {
-                    double X[3] = {point[3 * (size_t)l], point[3 * (size_t)l + 1], point[3 * (size_t)l + 2]};
-                    const double nfv = rec[(size_t)27 * n_point + l];
-                    if (nfv >= 0) {
-                        double H[6], bl[3];
+                for (int rnd = 0; rnd < nrounds; ++rnd) {
+                    const int l = slot + rnd * nslot;
+                    const bool live = l < n_point;
+                    if (!ONE) { point_begin(l, false); if (live && ps.pfree) rec_load(l); }
+                    double Xn[3] = {ps.X[0], ps.X[1], ps.X[2]};
+                    if (live && ps.pfree) {
+                        double r0 = ps.bl[0], r1 = ps.bl[1], r2 = ps.bl[2];
+                        if (ps.nf > 0) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) H[q] = rec[(size_t)q * n_point + l];
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) bl[q] = rec[(size_t)(6 + q) * n_point + l];
-                        double r0 = bl[0], r1 = bl[1], r2 = bl[2];
-                        if (nfv > 0) {
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) {
-                                const double w0 = rec[(size_t)(9 + 3 * a) * n_point + l], w1 = rec[(size_t)(10 + 3 * a) * n_point + l], w2 = rec[(size_t)(11 + 3 * a) * n_point + l];
-                                r0 -= w0 * dpv[a]; r1 -= w1 * dpv[a]; r2 -= w2 * dpv[a];
-                            }
+                            for (int a = 0; a < 6; ++a) { r0 -= ps.W[3 * a] * dpv[a]; r1 -= ps.W[3 * a + 1] * dpv[a]; r2 -= ps.W[3 * a + 2] * dpv[a]; }
                         }
                         Chol3 c;
-                        (void)chol3(H, lambda, c);
+                        (void)chol3(ps.H, lambda, c);
                         const double v0 = r0 * c.i11, v1 = (r1 - c.l21 * v0) * c.i22, v2 = (r2 - c.l31 * v0 - c.l32 * v1) * c.i33;       // L^-1 r
-                        const double d2 = v2 * c.i33, d1 = (v1 - c.l32 * d2) * c.i22, d0 = (v0 - c.l21 * d1 - c.l31 * d2) * c.i11;         // L^-T ...
-                        if (sub == 0) sc += d0 * (lambda * d0 + bl[0]) + d1 * (lambda * d1 + bl[1]) + d2 * (lambda * d2 + bl[2]);
-                        X[0] += d0; X[1] += d1; X[2] += d2;
+                        const double d2 = v2 * c.i33, d1 = (v1 - c.l32 * d2) * c.i22, d0 = (v0 - c.l21 * d1 - c.l31 * d2) * c.i11;         // L^-T (L^-1 r)
+                        if (sub == 0) sc += d0 * (lambda * d0 + ps.bl[0]) + d1 * (lambda * d1 + ps.bl[1]) + d2 * (lambda * d2 + ps.bl[2]);
+                        Xn[0] += d0; Xn[1] += d1; Xn[2] += d2;
                     }
-                    if (sub == 0) { trial[3 * (size_t)l] = X[0]; trial[3 * (size_t)l + 1] = X[1]; trial[3 * (size_t)l + 2] = X[2]; }
-                    acc += chi2_share(l, X, trial_pose, false);
+                    if (ONE) { Xt[0] = Xn[0]; Xt[1] = Xn[1]; Xt[2] = Xn[2]; }
+                    else if (live && sub == 0) { trial[3 * (size_t)l] = Xn[0]; trial[3 * (size_t)l + 1] = Xn[1]; trial[3 * (size_t)l + 2] = Xn[2]; }
+                    sum += chi2_share(ps.i0, ps.i1, Xn, trial_pose, false);
                 }
-                acc += edge_part(trial_pose, false);
-                pair_reduce(acc, sc);
-                temp = s_sum[32];
+                sum += edge_part(trial_pose, false);
+                OP_LAP(4);
+                pair_reduce(sum, sc);
+                OP_LAP(5);
+                temp = s_sum[28];
             } else temp = DBL_MAX;
-            const double scale = (ok2 ? s_sum[33] : 0.0) + 1e-3;
+            const double scale = (ok2 ? s_sum[29] : 0.0) + 1e-3;
             rho = (current - temp) / scale;
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
@@ -3150,9 +3258,12 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
                 ni = 2; current = temp; chi2_carried = temp;
 #pragma unroll
                 for (int a = 0; a < 7; ++a) pose[a] = trial_pose[a];
-                for (int l = slot; l < n_point; l += nslot)
-                    if (sub == 0) { point[3 * (size_t)l] = trial[3 * (size_t)l]; point[3 * (size_t)l + 1] = trial[3 * (size_t)l + 1]; point[3 * (size_t)l + 2] = trial[3 * (size_t)l + 2]; }
-                __syncthreads();                                            // the group's other lanes read the moved points next
+                if (ONE) { ps.X[0] = Xt[0]; ps.X[1] = Xt[1]; ps.X[2] = Xt[2]; }
+                else {
+                    for (int l = slot; l < n_point; l += nslot)
+                        if (sub == 0) { point[3 * (size_t)l] = trial[3 * (size_t)l]; point[3 * (size_t)l + 1] = trial[3 * (size_t)l + 1]; point[3 * (size_t)l + 2] = trial[3 * (size_t)l + 2]; }
+                    __syncthreads();                                        // the group's other lanes read the moved points next
+                }
             } else {
                 lambda *= ni; ni *= 2;
                 if (!isfinite(lambda)) break;
@@ -3161,14 +3272,19 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         } while (rho < 0 && qmax < 10);
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) { stop = 1; ++it; break; }
     }
-    const double chi2_final = total_chi2(pose, false, true, 0.0);
+    tq = clock64();
+    const double chi2_final = total_chi2(pose, true);
+    OP_LAP(0);
+    if (ONE && slot < n_point && sub == 0) { point[3 * (size_t)slot] = ps.X[0]; point[3 * (size_t)slot + 1] = ps.X[1]; point[3 * (size_t)slot + 2] = ps.X[2]; }
     if (gl == 0) {
         const bool hung = team > 1 && P.flag[1] != 0;                      // a team barrier gave up: the result is not to be trusted
         for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
         P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = hung ? 1 : 0;
-        for (int k = 8; k < 16; ++k) P.stats[k] = 0;
+        P.stats[8] = (double)cyc[0]; P.stats[9] = (double)cyc[1]; P.stats[10] = (double)cyc[2]; P.stats[11] = (double)cyc[3]; P.stats[12] = (double)cyc[4];
+        P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5]; P.stats[15] = 0;
     }
+#undef OP_LAP
 }
 
 }  // namespace
@@ -3741,7 +3857,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose), hipFuncAttributeMaxDynamicSharedMemorySize, 7 * OP_MAX_LDS_POSES * (int)sizeof(double)) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) {
         ms_ba_destroy(B);
         return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
     }
@@ -3815,10 +3932,13 @@ int ms_ba_solve(ms_ba *B) {
         if (const char *e = std::getenv("MS_BA_ONE_POSE_LANES")) { const int g = std::atoi(e); lgG = g >= 8 ? 3 : g >= 4 ? 2 : g >= 2 ? 1 : 0; }
         else while (lgG < 3 && (long long)(team * OP_NT >> (lgG + 1)) >= most_points) ++lgG;
     }
-    const size_t op_lds_bytes = most_poses <= OP_MAX_LDS_POSES ? 7 * (size_t)most_poses * sizeof(double) : 0;
+    const int op_pose_doubles = most_poses <= OP_MAX_LDS_POSES ? (7 * most_poses + 1) & ~1 : 0;
     auto launch_lm = [&](int tm) {
-        if (one_pose) hipLaunchKernelGGL(k_ba_one_pose, dim3(B->n * tm), dim3(OP_NT), op_lds_bytes, c->stream, B->d_probs, tm, lgG);
-        else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, c->stream, B->d_probs, tm);
+        if (one_pose) {
+            const size_t lds = ((size_t)op_pose_doubles + (size_t)OP_NW * 27 * op_slab_cap(lgG)) * sizeof(double);
+            if ((long long)(tm * OP_NT >> lgG) >= most_points) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n * tm), dim3(OP_NT), lds, c->stream, B->d_probs, tm, lgG, op_pose_doubles);
+            else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n * tm), dim3(OP_NT), lds, c->stream, B->d_probs, tm, lgG, op_pose_doubles);
+        } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, c->stream, B->d_probs, tm);
     };
     B->last_one_pose = one_pose; B->one_pose_lg = lgG;
     // the distributed factorisation is barrier-bound on banded systems: it gets one workgroup per 16 row tiles a panel touches
@@ -3899,9 +4019,12 @@ static int ba_relaunch_single(ms_ba *B) {
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
     MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
     if (B->last_one_pose) {
-        int most_poses = 0;
-        for (const auto &h : B->host) most_poses = std::max(most_poses, h.n_pose);
-        hipLaunchKernelGGL(k_ba_one_pose, dim3(B->n), dim3(OP_NT), most_poses <= OP_MAX_LDS_POSES ? 7 * (size_t)most_poses * sizeof(double) : 0, c->stream, B->d_probs, 1, 0);
+        int most_poses = 0, most_points = 0;
+        for (const auto &h : B->host) { most_poses = std::max(most_poses, h.n_pose); most_points = std::max(most_points, h.n_point); }
+        const int pd = most_poses <= OP_MAX_LDS_POSES ? (7 * most_poses + 1) & ~1 : 0;
+        const size_t lds = ((size_t)pd + (size_t)OP_NW * 27 * op_slab_cap(0)) * sizeof(double);
+        if (most_points <= OP_NT) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n), dim3(OP_NT), lds, c->stream, B->d_probs, 1, 0, pd);
+        else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n), dim3(OP_NT), lds, c->stream, B->d_probs, 1, 0, pd);
     } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
     MS_KERNEL_CHECK(c, "k_ba_lm");
     MS_HIP(c, hipStreamSynchronize(c->stream));

@@ -34,7 +34,10 @@ def main():
         for lanes in (1, 2, 4, 8):
             os.environ["MS_BA_ONE_POSE_LANES"] = str(lanes)
             one.set_team(team)
-            print("one-pose kernel, team %2d, %d lanes per point: %.3f ms" % (team, lanes, timed(ctx, one)))
+            ms = timed(ctx, one)
+            ph = one.download(0)["stats"]["phase_cycles"]      # k_ba_one_pose: chi2 sweeps | linearise (+ Schur terms) | reduction | 6 x 6 solve | points + trial chi2 | total | reduction
+            print("one-pose kernel, team %2d, %d lanes per point: %.3f ms   kcycles: chi2 %d, linearise %d, reduce %d, solve %d, trial %d, reduce %d, total %d" %
+                  (team, lanes, ms, ph["eval"] / 1e3, ph["linearise"] / 1e3, ph["schur"] / 1e3, ph["cholesky"] / 1e3, ph["points_update"] / 1e3, ph["schur_init"] / 1e3, ph["total"] / 1e3))
     del os.environ["MS_BA_ONE_POSE_LANES"]
     t0 = time.perf_counter()
     for _ in range(10):
