@@ -366,13 +366,16 @@ __device__ __forceinline__ void team_heartbeat(const BaProb &P) {
     if (P.team > 1) (void)__hip_atomic_fetch_add(P.bar + kBeatWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// FENCES = false: no agent-scope release / acquire (no L2 write-back, no invalidate) -- for a kernel whose workgroups exchange NOTHING but values written and
+// read with agent-scope atomics (k_ba_one_pose: the partial sums); the barrier then only orders those: every wave's stores are acknowledged (vmcnt 0) before
+// its workgroup arrives, and the values are loaded after the arrival counter was seen complete
+template <bool FENCES = true>
 __device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, uint32_t T) {
     if (T == 1) { __syncthreads(); return; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FENCES) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         const uint32_t a = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t target = (a / T + 1u) * T;
         uint32_t seen = a + 1u, beat = __hip_atomic_load(P.bar + kBeatWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -390,12 +393,12 @@ __device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, u
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FENCES) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }
     __syncthreads();
 }
 __device__ __noinline__ void team_sync(const BaProb &P) { group_sync(P, P.bar, (uint32_t)P.team); }
+__device__ __noinline__ void team_sync_light(const BaProb &P, int team) { group_sync<false>(P, P.bar, (uint32_t)team); }
 // barrier of the first P.chol_team workgroups only (the distributed factorisation), on a counter of its own (P.bar + 32: another 128-byte line)
 __device__ __noinline__ void chol_sync(const BaProb &P) { group_sync(P, P.bar + 32, (uint32_t)P.chol_team); }
 
@@ -2746,8 +2749,12 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
 // restore pass.  Observation data comes from copies sorted by point (pose index, u, v, information side by side: one round trip instead of three dependent
 // ones), the poses from an LDS table.  Same LM schedule and the same arithmetic per edge as k_ba_lm.
 constexpr int OP_NT = 512, OP_NW = OP_NT / 64, OP_NV = 64, OP_MAX_LDS_POSES = 512;
+#ifndef OP_PROF_GL
+#define OP_PROF_GL 0
+#endif
 constexpr int OP_S0 = 32, OP_BAD = 59, OP_MAX = 63;          // accumulators: 0..20 Hpp, 21..26 bp | 32..52 Schur matrix terms, 53..58 rhs terms, 59 unsound point blocks | 63 largest diagonal entry
 __host__ __device__ constexpr int op_slab_cap(int lgG) { return lgG == 0 ? 64 : 32; }     // entries of a wave's staging slab
+constexpr size_t kOpLdsBytes = (((size_t)7 * OP_MAX_LDS_POSES + 2) + (size_t)OP_NW * 27 * 64) * sizeof(double);     // dynamic LDS at most: the pose table + the slabs (136 KB; ~11 KB are static)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_d(double v) {
@@ -2817,7 +2824,7 @@ struct OpPoint { double X[3], H[6], bl[3], W[18]; int nf, i0, i1; bool pfree; };
 template <bool ONE>     // ONE: the launch has a lane group per point -- the point's record lives in registers for the whole solve
 __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int team, int lgG, int pose_doubles) {
     extern __shared__ __attribute__((aligned(16))) double op_lds[];      // [7 n_pose] the poses (when they fit), then the waves' staging slabs [8][27][cap]
-    __shared__ double s_acc[OP_NV], s_sum[OP_NV], s_w[OP_NW * 2];
+    __shared__ double s_acc[OP_NV], s_sum[OP_NV], s_w[OP_NW * 2], s_part[OP_NW * OP_NV];
     __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
     __shared__ int s_eSide[PO_MAXE], s_ne;
     const BaProb &P = probs[blockIdx.x / (unsigned)team];
@@ -2855,9 +2862,12 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     double pose[7];
 #pragma unroll
     for (int a = 0; a < 7; ++a) pose[a] = P.pose0[7 * (size_t)pi + a];
-    // ---- the SE3 edges (the team's first workgroup): an edge between fixed poses is a constant, one that touches the free pose leaves its fixed side's
-    //      transform, -J^T W and J^T W J in LDS (its Jacobian does not depend on the free pose), exactly as in k_ba_pose_only
-    if (rank == 0 && tid < P.n_edge) {
+    // ---- the SE3 edges: an edge between fixed poses is a constant, one that touches the free pose leaves its fixed side's transform, -J^T W and J^T W J
+    //      in LDS (its Jacobian does not depend on the free pose), exactly as in k_ba_pose_only.  They belong to the LAST wave of the team's LAST workgroup:
+    //      an edge is ~1 700 dependent instructions (quaternion products, the SE3 logarithm) in one lane, 17 k cycles per sweep, and on the team's first wave
+    //      it sat in front of that wave's points -- the last lanes of a launch have the fewest points (none when the lanes outnumber them)
+    const bool edge_wg = rank == team - 1;
+    if (edge_wg && tid < P.n_edge) {
         const int k = tid, vi = P.edge_i[k], vj = P.edge_j[k];
         const double *W = P.edge_info + 36 * (size_t)k;
         double e[6], Ji[36], Jj[36];
@@ -2882,9 +2892,29 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         }
     }
     __syncthreads();
-    const int ne = rank == 0 ? s_ne : 0;
+    const int ne = edge_wg ? s_ne : 0, et = tid - (OP_NT - 64);             // lane et of the last wave takes edge et
+    // The workgroups of a team exchange nothing but their partial sums (points, records and trial points belong to the workgroup that owns the lane group):
+    // these go through agent-scope atomic stores and loads, which are coherent across the XCDs' L2s by themselves, so the team barriers carry no L2 write-back
+    // and no invalidate (team_sync_light) -- the observation data stays in the caches from sweep to sweep
+    auto put = [](double *q, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(q), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto get = [](const double *q) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
     // ---- sums over the team: the LDS accumulators s_acc[lo .. hi) (contributions of this workgroup) -> s_sum[lo .. hi), the same bits in every
     //      workgroup (partials combined in rank order); slot OP_MAX is combined as a maximum
+    // after the barrier every thread fetches one or two of the partials (value tid & 63 of ranks tid >> 6, + 8: the loads of one thread wait for each other),
+    // the eight rows meet in LDS
+    auto team_combine = [&](const double *part, double mine, bool mine_slot) {
+        const int k = tid & 63, r0 = tid >> 6;
+        double v = 0;
+        for (int r = r0; r < team; r += OP_NW) { const double x = get(part + (size_t)r * OP_NV + k); v = k == OP_MAX ? fmax(v, x) : v + x; }
+        s_part[r0 * OP_NV + k] = v;
+        __syncthreads();
+        if (mine_slot) {
+            double t = s_part[tid];
+            for (int r = 1; r < OP_NW; ++r) t = tid == OP_MAX ? fmax(t, s_part[r * OP_NV + tid]) : t + s_part[r * OP_NV + tid];
+            mine = t;
+        }
+        return mine;
+    };
     auto vec_reduce = [&](int lo, int hi, bool with_max) {
         __syncthreads();
         const bool mine_slot = (tid >= lo && tid < hi) || (with_max && tid == OP_MAX);
@@ -2892,14 +2922,9 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         if (mine_slot) { mine = s_acc[tid]; s_acc[tid] = 0; }
         if (team > 1) {
             double *part = P.op_red + (size_t)(seq & 1) * team * OP_NV;
-            if (mine_slot) part[(size_t)rank * OP_NV + tid] = mine;
-            team_sync(P);
-            if (mine_slot) {
-                double t = part[tid];
-                if (tid == OP_MAX) { for (int r = 1; r < team; ++r) t = fmax(t, part[(size_t)r * OP_NV + tid]); }
-                else for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid];
-                mine = t;
-            }
+            if (mine_slot) put(part + (size_t)rank * OP_NV + tid, mine);
+            team_sync_light(P, team);
+            mine = team_combine(part, mine, mine_slot);
         }
         ++seq;
         if (mine_slot) s_sum[tid] = mine;
@@ -2912,15 +2937,16 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         if (lane == 0) { s_w[2 * wave] = a; s_w[2 * wave + 1] = b; }
         __syncthreads();
         double mine = 0;
-        if (tid < 2) { for (int w = 0; w < OP_NW; ++w) mine += s_w[2 * w + tid]; }
+        const bool mine_slot = tid == 28 || tid == 29;
+        if (mine_slot) { for (int w = 0; w < OP_NW; ++w) mine += s_w[2 * w + tid - 28]; }
         if (team > 1) {
             double *part = P.op_red + (size_t)(seq & 1) * team * OP_NV;
-            if (tid < 2) part[(size_t)rank * OP_NV + tid] = mine;
-            team_sync(P);
-            if (tid < 2) { double t = part[tid]; for (int r = 1; r < team; ++r) t += part[(size_t)r * OP_NV + tid]; mine = t; }
+            if (mine_slot) put(part + (size_t)rank * OP_NV + tid, mine);
+            team_sync_light(P, team);
+            mine = team_combine(part, mine, mine_slot);
         }
         ++seq;
-        if (tid < 2) s_sum[28 + tid] = mine;
+        if (mine_slot) s_sum[tid] = mine;
         __syncthreads();
     };
     auto load_pose = [&](int pc, const double (&cur)[7], double (&pz)[7]) {
@@ -2959,18 +2985,24 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         return sum;
     };
     // the SE3 edges at the free pose `cur` (lanes < ne of the team's first workgroup): chi2, and with lin the gradient into the accumulators
+    // (an edge's error at the accepted pose is the error of the trial that was accepted: it is kept, e_acc, and the linearisation only multiplies it)
+    double e_acc[6] = {0, 0, 0, 0, 0, 0}, e_try[6] = {0, 0, 0, 0, 0, 0};
     auto edge_part = [&](const double (&cur)[7], bool lin) {
         double sum = 0;
-        if (tid < ne) {
-            double Bm[7], e[6], We[6];
-            if (s_eSide[tid] == 0) se3_mul(s_eC[tid], cur, Bm);
-            else { double Tjinv[7], A2[7]; se3_inv(cur, Tjinv); se3_mul(Tjinv, s_eM[tid], A2); se3_mul(A2, s_eC[tid], Bm); }
-            se3_log(Bm, e);
-            for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[tid][6 * i + j] * e[j]; We[i] = v; }
-            for (int i = 0; i < 6; ++i) sum += e[i] * We[i];
-            if (lin) for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[tid][6 * a + c] * e[c]; lds_addd(acc + 21 + a, v); }
+        if (et >= 0 && et < ne) {
+            if (lin) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[et][6 * a + c] * e_acc[c]; lds_addd(acc + 21 + a, v); }
+            } else {
+                double Bm[7], We[6];
+                if (s_eSide[et] == 0) se3_mul(s_eC[et], cur, Bm);
+                else { double Tjinv[7], A2[7]; se3_inv(cur, Tjinv); se3_mul(Tjinv, s_eM[et], A2); se3_mul(A2, s_eC[et], Bm); }
+                se3_log(Bm, e_try);
+                for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[et][6 * i + j] * e_try[j]; We[i] = v; }
+                for (int i = 0; i < 6; ++i) sum += e_try[i] * We[i];
+            }
         }
-        if (rank == 0 && tid == 0) sum += s_const;
+        if (!lin && edge_wg && tid == 0) sum += s_const;
         return sum;
     };
     auto total_chi2 = [&](const double (&cur)[7], bool store) {          // at the accepted state
@@ -3045,6 +3077,8 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     const long long t_begin = tq;
 #define OP_LAP(i) do { const long long t_ = clock64(); cyc[i] += t_ - tq; tq = t_; } while (0)
     const double chi2_init = total_chi2(pose, false);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) e_acc[a] = e_try[a];
     OP_LAP(0);
     double chi2_carried = chi2_init;
     for (it = 0; it < P.max_iters; ++it) {
@@ -3063,7 +3097,10 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
 #pragma unroll
             for (int q = 0; q < 18; ++q) ps.W[q] = 0;
             const int i1 = ps.i1;
-            int jj = i1;                                                 // this lane's first observation in the free keyframe
+            int jj = i1, jj2 = i1;                                       // this lane's first and second observation in the free keyframe
+            bool more = false;                                           // ... and there are further ones (found by scanning: never in a SLAM window, where a keyframe sees a point once)
+            double fu = 0, fv = 0, finf = 0;                             // the first one's measurement stays in registers (a reload after the loop is a round trip to L2)
+            bool fkept = false;
             if (ps.pfree) {                                              // the point's own block and gradient: every observation of the share
                 int ii = ps.i0 + sub, pn = 0;
                 double un = 0, vn = 0, fn = 0;
@@ -3071,7 +3108,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
                 while (ii < i1) {
                     const int pc = pn;
                     const double uvc[2] = {un, vn}, infc = fn;
-                    if (pc == pi && jj == i1) jj = ii;
+                    if (pc == pi) { if (jj == i1) { jj = ii; fu = un; fv = vn; finf = fn; fkept = true; } else if (jj2 == i1) jj2 = ii; else more = true; }
                     ii += G;
                     if (ii < i1) { pn = o_pose[ii]; un = o_uvi[3 * (size_t)ii]; vn = o_uvi[3 * (size_t)ii + 1]; fn = o_uvi[3 * (size_t)ii + 2]; }
                     double pz[7], e[2], Jp[12], Jl[6], r, w;
@@ -3085,7 +3122,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) ps.bl[c] -= wi * (Jl[c] * e[0] + Jl[3 + c] * e[1]);
                 }
-            } else { jj = ps.i0 + sub; while (jj < i1 && o_pose[jj] != pi) jj += G; }
+            } else { jj = ps.i0 + sub; while (jj < i1 && o_pose[jj] != pi) jj += G; more = true; }     // (a fixed point: its share is scanned)
             // the observations in the free keyframe once more (one lane in four has one; a wave-uniform loop): the pose's block and gradient go straight into the
             // wave's slab, W = Jp^T w Jl stays with the point -- keeping 27 more sums in registers through the loop above made the kernel spill
             int nf = 0, cnt = 0;
@@ -3094,7 +3131,9 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
                 const unsigned long long m = __ballot(has);
                 if (m == 0) break;
                 if (has) {
-                    const double uvc[2] = {o_uvi[3 * (size_t)jj], o_uvi[3 * (size_t)jj + 1]}, infc = o_uvi[3 * (size_t)jj + 2];
+                    if (!fkept) { fu = o_uvi[3 * (size_t)jj]; fv = o_uvi[3 * (size_t)jj + 1]; finf = o_uvi[3 * (size_t)jj + 2]; }
+                    fkept = false;
+                    const double uvc[2] = {fu, fv}, infc = finf;
                     double e[2], Jp[12], Jl[6], r, w, A[27];
                     proj_edge<true>(pose, ps.X, uvc, e, Jp, Jl);
                     const double chi2 = infc * (e[0] * e[0] + e[1] * e[1]);
@@ -3115,8 +3154,8 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
 #pragma unroll
                             for (int c = 0; c < 3; ++c) ps.W[3 * r2 + c] += wi * (Jp[r2] * Jl[c] + Jp[6 + r2] * Jl[3 + c]);
                     }
-                    jj += G;
-                    while (jj < i1 && o_pose[jj] != pi) jj += G;
+                    if (more && jj2 == i1) { jj += G; while (jj < i1 && o_pose[jj] != pi) jj += G; }      // the rare cases: scan on
+                    else { jj = jj2; jj2 = i1; }
                 }
                 cnt += (int)__popcll(m);
             }
@@ -3138,7 +3177,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         }
         (void)edge_part(pose, true);
         OP_LAP(1);
-        if (rank == 0 && tid < 21) lds_addd(acc + tid, s_Hc[tid]);          // the edges' constant J^T W J: into the sums, so that every workgroup of the team gets it
+        if (edge_wg && tid < 21) lds_addd(acc + tid, s_Hc[tid]);          // the edges' constant J^T W J: into the sums, so that every workgroup of the team gets it
         if (it == 0) {
             for (int off = 32; off > 0; off >>= 1) md = fmax(md, __shfl_xor(md, off, 64));
             if (lane == 0) (void)atomicMax(reinterpret_cast<unsigned long long *>(&s_acc[OP_MAX]), (unsigned long long)__double_as_longlong(md));
@@ -3258,6 +3297,8 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
                 ni = 2; current = temp; chi2_carried = temp;
 #pragma unroll
                 for (int a = 0; a < 7; ++a) pose[a] = trial_pose[a];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) e_acc[a] = e_try[a];
                 if (ONE) { ps.X[0] = Xt[0]; ps.X[1] = Xt[1]; ps.X[2] = Xt[2]; }
                 else {
                     for (int l = slot; l < n_point; l += nslot)
@@ -3281,8 +3322,11 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
         for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
         P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = hung ? 1 : 0;
+        P.stats[15] = 0;
+    }
+    if (gl == (OP_PROF_GL < team * OP_NT ? OP_PROF_GL : 0)) {              // the phase stamps of one wave (-DOP_PROF_GL=<global lane>: another wave than the first)
         P.stats[8] = (double)cyc[0]; P.stats[9] = (double)cyc[1]; P.stats[10] = (double)cyc[2]; P.stats[11] = (double)cyc[3]; P.stats[12] = (double)cyc[4];
-        P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5]; P.stats[15] = 0;
+        P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5];
     }
 #undef OP_LAP
 }
@@ -3857,8 +3901,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     }
     if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOpLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOpLdsBytes) != hipSuccess) {
         ms_ba_destroy(B);
         return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
     }
@@ -3925,7 +3969,7 @@ int ms_ba_solve(ms_ba *B) {
     for (const auto &h : B->host) { most_obs = std::max(most_obs, h.n_obs); most_points = std::max(most_points, h.n_point); most_poses = std::max(most_poses, h.n_pose); }
     // stage 1 of localBundleAdjust (one free pose, free points): a kernel of its own, with or without a team
     const bool one_pose = B->one_pose && !std::getenv("MS_BA_NO_ONE_POSE_KERNEL");
-    int team = B->team == 0 ? (one_pose ? std::min(16, std::max(1, most_obs / 1024)) : std::min(32, std::max(1, most_obs / 512))) : B->team;      // small problems are latency-bound on the barriers
+    int team = B->team == 0 ? (one_pose ? std::min(8, std::max(1, most_obs / 2048)) : std::min(32, std::max(1, most_obs / 512))) : B->team;      // small problems are latency-bound on the barriers
     team = std::max(1, std::min(team, B->cus / std::max(B->n, 1)));
     int lgG = 0;                                                          // lanes per point: as many as the launch has to spare, at most 8
     if (one_pose) {
