@@ -878,6 +878,16 @@ __device__ __forceinline__ int wave_sum(int v) {      // DPP inclusive scan, tot
 constexpr int kDescPerWave = 1;
 
 struct DescKp { int x, y, oct, tid_out; float ox, oy; bool valid; };
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// r[m] in lane row q (the wave's four rows of 16 lanes)  ->  r[q] of lane row m: the 2 x 2 blocks trade places across the wave's halves
+// (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second), then each block is transposed across neighbouring rows
+// (v_permlane16_swap: odd rows of the first <-> even rows of the second); lane maps checked on the device by tools/mfma_i8_probe.hip
+__device__ __forceinline__ void transpose4_rows(uint32_t (&r)[4]) {
+    auto s = __builtin_amdgcn_permlane32_swap(r[0], r[2], false, false); r[0] = s[0]; r[2] = s[1];
+    s = __builtin_amdgcn_permlane32_swap(r[1], r[3], false, false); r[1] = s[0]; r[3] = s[1];
+    s = __builtin_amdgcn_permlane16_swap(r[0], r[1], false, false); r[0] = s[0]; r[1] = s[1];
+    s = __builtin_amdgcn_permlane16_swap(r[2], r[3], false, false); r[2] = s[0]; r[3] = s[1];
+}
 
 __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
                                                   const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
@@ -930,7 +940,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     // vertical pass on packed 16-bit lanes, horizontal pass with v_dot2 and one rounding -- and the blurred pyramid is no longer
     // written and read back for every frame (2 P bytes and a 0.49 ms kernel per 256-frame step; round 1 fetched 31 x 32 B of the level plus
     // 39 x 40 B of its blurred twin = 70 row pieces per keypoint, now 45).  k_blur still exists: ImagePyramid::getBlurredLevel runs it on demand.
-    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kDescPerWave][45 * 12 + 32 * 8 + 39 * 10];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kDescPerWave][45 * 12 + 32 * 8 + 39 * 10 + 2];   // (+ 2: a wave's slab is a whole number of 16-byte units -- the window rows are read as ds_read_b128)
     const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
@@ -965,29 +975,61 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
             const uint32_t v = i < 31 * 8 ? win[(r + 7) * 12 + c4 + 2] : 0u;
             pu[i] = v & dmask[t];
         }
-        {   // blurred patch rows y-19 .. y+19 (output row ro <- window rows ro .. ro+6), columns x-19 .. x+19 = window bytes 4 .. 42.
-            // lane = 12 * rg + dc: dword column dc of the window, output rows 8 rg .. 8 rg + 7; neighbours dc +- 1 are lanes +- 1 (DPP)
-            const int rg = lane / 12, dc = lane - 12 * rg;
-            uint32_t e[14], o[14];
+        {   // blurred patch rows y-19 .. y+19 (output row ro <- window rows ro .. ro+6), columns x-19 .. x+19 = window bytes 4 .. 42, ON THE MATRIX CORES (round 3):
+            // a separable 7-tap filter is two products with banded constant matrices, out = V (P Hh), and every quantity of k_blur's fixed-point arithmetic is an
+            // integer that i8 operands with i32 accumulators carry exactly.
+            //   pass 1   T' = (P - 128) Hh: A = window rows as they lie in LDS (lane (i, kg): row 16 m + i, bytes 16 kg .. + 15, one ds_read_b128, xor 0x80 = -128
+            //            as signed bytes; the bytes past column 47 and the rows past 44 meet zero weights), B = the taps by column (host table).  T' = T - 32768 fits 16 bits
+            //   between  T' leaves the accumulators as its high and low bytes (4 v_perm per tile for both planes); the C layout holds 4 consecutive ROWS of a column per
+            //            lane, the next A operand wants 16 -- a 4 x 4 transpose of dwords across the wave's four 16-lane rows: two v_permlane32_swap + two
+            //            v_permlane16_swap per plane and column tile, no trip through LDS
+            //   pass 2   out^T = T'^T V^T as 256 x (high bytes) + (low bytes - 128): two chained products per 16 x 16 tile (the first starts from 33024 =
+            //            (rounding + the offsets' share) / 256, is shifted up by 8 and becomes the second's C), byte 2 of each sum is the blurred pixel; the
+            //            C layout now holds 4 consecutive pixels of a ROW per lane = one dword of the patch
+            // 27 v_mfma_i32_16x16x64_i8 + ~150 vector instructions per keypoint, where the packed-16-bit form (k_blur's, 60 lanes x 8 rows) took ~350: the kernel sits at
+            // the VALU issue limit and the matrix pipe was idle.
+            const int n = lane & 15, q = lane >> 4;
+            const uint4 *bt = moment_tab + 64;
+            v4i_t Hb[3], Vb[3];
 #pragma unroll
-            for (int r = 0; r < 14; ++r) {
-                const uint32_t d = win[min(8 * rg + r, 44) * 12 + dc];
-                e[r] = __builtin_amdgcn_perm(0u, d, 0x0C020C00u);       // bytes 0, 2 as two 16-bit lanes (one op instead of and / shift + and)
-                o[r] = __builtin_amdgcn_perm(0u, d, 0x0C030C01u);       // bytes 1, 3
+            for (int t = 0; t < 3; ++t) { Hb[t] = __builtin_bit_cast(v4i_t, bt[t * 64 + lane]); Vb[t] = __builtin_bit_cast(v4i_t, bt[(3 + t) * 64 + lane]); }
+            v4i_t T[3][3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                uint4 a4 = *reinterpret_cast<const uint4 *>(win + (16 * m + n) * 12 + 4 * q);
+                a4.x ^= 0x80808080u; a4.y ^= 0x80808080u; a4.z ^= 0x80808080u; a4.w ^= 0x80808080u;
+                const v4i_t a = __builtin_bit_cast(v4i_t, a4), zero = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) T[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, Hb[t], zero, 0, 0, 0);
+            }
+            v4i_t A2h[3], A2l[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                uint32_t hd[4], ld[4];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const uint32_t x01 = __builtin_amdgcn_perm((uint32_t)T[m][t][1], (uint32_t)T[m][t][0], 0x04000501u);      // [r0.b1, r1.b1, r0.b0, r1.b0]
+                    const uint32_t x23 = __builtin_amdgcn_perm((uint32_t)T[m][t][3], (uint32_t)T[m][t][2], 0x04000501u);
+                    hd[m] = __builtin_amdgcn_perm(x23, x01, 0x05040100u);
+                    ld[m] = __builtin_amdgcn_perm(x23, x01, 0x07060302u) ^ 0x80808080u;
+                }
+                hd[3] = 0; ld[3] = 0;                                   // rows 48 .. 63: zero weights AND zero data
+                transpose4_rows(hd); transpose4_rows(ld);
+                A2h[t] = v4i_t{(int)hd[0], (int)hd[1], (int)hd[2], (int)hd[3]};
+                A2l[t] = v4i_t{(int)ld[0], (int)ld[1], (int)ld[2], (int)ld[3]};
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t Ce = vsum7(e + j), Co = vsum7(o + j);            // columns (x, x+2) and (x+1, x+3) of the dword
-                const uint32_t Le = wave_from_prev(Ce), Lo = wave_from_prev(Co);
-                const uint32_t Re = wave_from_next(Ce), Ro = wave_from_next(Co);
-                uint32_t o0 = dot2(Lo, 18, 48, 32768u); o0 = dot2(Le, 0, 34, o0); o0 = dot2(Ce, 56, 34, o0); o0 = dot2(Co, 48, 18, o0);
-                uint32_t o1 = dot2(Le, 0, 18, 32768u); o1 = dot2(Lo, 0, 34, o1); o1 = dot2(Ce, 48, 48, o1); o1 = dot2(Co, 56, 34, o1); o1 = dot2(Re, 18, 0, o1);
-                uint32_t o2 = dot2(Lo, 0, 18, 32768u); o2 = dot2(Ce, 34, 56, o2); o2 = dot2(Co, 48, 48, o2); o2 = dot2(Re, 34, 0, o2); o2 = dot2(Ro, 18, 0, o2);
-                uint32_t o3 = dot2(Ce, 18, 48, 32768u); o3 = dot2(Co, 34, 56, o3); o3 = dot2(Re, 48, 18, o3); o3 = dot2(Ro, 34, 0, o3);
-                const int ro = 8 * rg + j;
-                if (lane < 60 && dc >= 1 && dc <= 10 && ro < 39)
-                    pb[ro * 10 + (dc - 1)] = __builtin_amdgcn_perm(o1, o0, 0x0C0C0602u) | __builtin_amdgcn_perm(o3, o2, 0x06020C0Cu);   // byte 2 of each sum (the sums stay below 2^24)
-            }
+            for (int yt = 0; yt < 3; ++yt)
+#pragma unroll
+                for (int xt = 0; xt < 3; ++xt) {
+                    v4i_t acc = {33024, 33024, 33024, 33024};
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2h[xt], Vb[yt], acc, 0, 0, 0);
+                    acc <<= 8;
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2l[xt], Vb[yt], acc, 0, 0, 0);
+                    const int y = 16 * yt + n;
+                    if (y < 39 && 4 * xt + q < 10)                      // lane (n, q): pixels 16 xt + 4 q .. + 3 of patch row y (byte 2 of each sum; the sums stay below 2^24)
+                        pb[y * 10 + 4 * xt + q] = __builtin_amdgcn_perm((uint32_t)acc[1], (uint32_t)acc[0], 0x0C0C0602u) | __builtin_amdgcn_perm((uint32_t)acc[3], (uint32_t)acc[2], 0x06020C0Cu);
+                }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1255,6 +1297,23 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
                     if (u <= kHalfPatch && std::abs(u) <= G.umax[std::abs(v)]) mt[lane * 4 + t] |= 0xFFu << (8 * b);
                 }
             }
+        // behind it, k_describe's blur as matrix operands (B of v_mfma_i32_16x16x64_i8: lane (n, kg) holds rows k = 16 kg .. + 15 of column n, one byte each): the taps
+        // 18 34 48 56 48 34 18 by patch column x -- window byte k contributes to x when 0 <= k - x - 1 <= 6 -- and by patch row y (window row k, 0 <= k - y <= 6);
+        // columns / rows past 38 are zero.  [table 0 = horizontal, 1 = vertical][tile 0..2][lane][4 dwords]
+        {
+            static const int w7[7] = {18, 34, 48, 56, 48, 34, 18};
+            mt.resize(64 * 4 + 6 * 64 * 4, 0u);
+            for (int tab = 0; tab < 2; ++tab)
+                for (int tile = 0; tile < 3; ++tile)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = lane & 15, kg = lane >> 4, xy = 16 * tile + n;
+                        for (int j = 0; j < 16; ++j) {
+                            const int k = 16 * kg + j, tap = tab == 0 ? k - xy - 1 : k - xy;
+                            const uint32_t v = (xy <= 38 && tap >= 0 && tap <= 6) ? (uint32_t)w7[tap] : 0u;
+                            mt[64 * 4 + ((tab * 3 + tile) * 64 + lane) * 4 + j / 4] |= v << (8 * (j % 4));
+                        }
+                    }
+        }
         std::vector<float> pf(1024);
         for (int i = 0; i < 1024; ++i) pf[i] = (float)pattern[i];
         if (hipMalloc(reinterpret_cast<void **>(&o->d_moment_tab), mt.size() * 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&o->d_pattern_f), pf.size() * 4) != hipSuccess ||
