@@ -1198,6 +1198,11 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch(args, argv))                  # the parent never touches the GPU
+    if not args.plumbing:
+        # before the first HIP call of this rank: one hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's
+        # default of 4 queues a sequence's 10 us front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
+        import mi355slam
+        mi355slam.prepare_process(N_SEQ)
     R = Rank(args)
     if R.world != args.gpus and R.rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d; reporting n_gpus = WORLD_SIZE\n" % (args.gpus, R.world))

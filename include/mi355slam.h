@@ -48,6 +48,13 @@ typedef struct ms_orb ms_orb;
 /* ---------------------------------------------------------------------------------------------
  * Context
  * ------------------------------------------------------------------------------------------- */
+/* Optional, once per process, BEFORE the first HIP call of the process (ms_ctx_create included): tells the runtime how many contexts (= sequences, each
+ * with its own stream) will drive the same GPU at the same time.  The HIP runtime maps streams onto a handful of hardware queues (4 by default), and kernels
+ * of streams that share a queue run one after the other -- a 1.8 ms local-BA launch of one sequence then holds up the 10 us front-end kernels of another:
+ * eight sequences on one GPU measured 4 300 frames/s with 4 queues and 6 100 with 8 (tools/c5_probe.py).  Sets GPU_MAX_HW_QUEUES to
+ * max(4, min(concurrent_contexts, 16)) unless the variable is already set; has no effect once the runtime is initialised.  (The reference has no counterpart:
+ * its back end is one CPU thread per sequence, mapper.cpp:268-269.) */
+int ms_prepare_process(int concurrent_contexts);
 int ms_ctx_create(int device, ms_ctx **out);
 void ms_ctx_destroy(ms_ctx *ctx);
 int ms_ctx_sync(ms_ctx *ctx);                 /* hipStreamSynchronize on the context stream */

@@ -5,6 +5,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+#include <string>
+#include <algorithm>
 
 namespace {
 std::atomic<int> g_ranges_on{0};
@@ -70,6 +72,12 @@ int ms_set_trace_ranges(int on) {
 
 void ms_trace_range_push(const char *name) { ms_range_push(name ? name : ""); }
 void ms_trace_range_pop(void) { ms_range_pop(); }
+
+int ms_prepare_process(int concurrent_contexts) {
+    if (concurrent_contexts < 1) return MS_ERR_INVALID;
+    const int q = std::max(4, std::min(concurrent_contexts, 16));
+    return setenv("GPU_MAX_HW_QUEUES", std::to_string(q).c_str(), 0 /* keep the caller's own setting */) == 0 ? MS_OK : MS_ERR_INVALID;
+}
 
 int ms_ctx_create(int device, ms_ctx **out) {
     if (!out) return MS_ERR_INVALID;

@@ -62,6 +62,13 @@ def lib():
     return _lib
 
 
+def prepare_process(concurrent_contexts):
+    """ms_prepare_process: before the first HIP call of the process -- as many hardware queues as there will be contexts driving the GPU at once."""
+    rc = lib().ms_prepare_process(int(concurrent_contexts))
+    if rc != 0:
+        raise MsError("ms_prepare_process(%d) failed with %d" % (concurrent_contexts, rc))
+
+
 def _vp(x):
     """device pointer / numpy array / None -> c_void_p"""
     if x is None:

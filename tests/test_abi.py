@@ -122,3 +122,25 @@ def test_keypoint_records_unpack_in_serialize_order():
     rec[1, 16] ^= 1                                                    # second copy of octave differs: corrupt record
     with pytest.raises(mi355slam.MsError):
         mi355slam.unpack_keypoints(rec)
+
+
+def test_prepare_process_sets_the_queue_count_once():
+    """ms_prepare_process: GPU_MAX_HW_QUEUES = clamp(contexts, 4, 16) unless the caller's environment already has a value; no HIP call involved."""
+    import ctypes as C
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(%r, "slam-module_amd"))
+import mi355slam
+L = mi355slam.lib()
+libc = C.CDLL("libc.so.6"); libc.getenv.restype = C.c_char_p
+assert L.ms_prepare_process(0) != 0
+want = os.environ.get("GPU_MAX_HW_QUEUES")
+assert L.ms_prepare_process(int(sys.argv[1])) == 0
+print(libc.getenv(b"GPU_MAX_HW_QUEUES").decode())
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    run = lambda n, e: subprocess.run([sys.executable, "-c", code, str(n)], env=e, capture_output=True, text=True, check=True).stdout.strip()
+    assert run(8, env) == "8" and run(2, env) == "4" and run(40, env) == "16"
+    assert run(8, dict(env, GPU_MAX_HW_QUEUES="2")) == "2"               # the caller's own setting wins
