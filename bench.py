@@ -824,8 +824,9 @@ def bench_ba_two_stage(R, ctx, args, probs):
     n_new = 6
     for i in range(n_new):
         a, b = st[i % len(st)]
-        h1 = mi355slam.BundleAdjuster(ctx, [a], max_iters=iters); h2 = mi355slam.BundleAdjuster(ctx, [b], max_iters=iters)
-        h1.solve(); h2.copy_state_from(h1, extra[:1]); h2.solve(); h2.download(0); h1.close(); h2.close()
+        h1 = mi355slam.BundleAdjuster(ctx, [a], max_iters=iters); h1.solve()                  # stage 1 runs while the host builds stage 2's index structures (the order of the host mirror)
+        h2 = mi355slam.BundleAdjuster(ctx, [b], max_iters=iters)
+        h2.copy_state_from(h1, extra[:1]); h2.solve(); h2.download(0); h1.close(); h2.close()
     new_ms = (time.perf_counter() - t1) / n_new * 1e3
     b1.close(); b2.close()
     return {"schedule": "stage 1: current keyframe + all points free, %d iterations; stage 2: every keyframe free + orientation prior edge, %d iterations (bundle_adjuster.cpp:156,322-373)" % (iters, iters),

@@ -139,8 +139,8 @@ inline BaOutcome localBundleAdjust(Context &ctx, BaWindow &w, int problemMaxSize
     ms_ba_problem p2 = detail::as_problem(w2, fixed2, nullptr, iterations);
     struct Handle { ms_ba *h = nullptr; ~Handle() { ms_ba_destroy(h); } } b1, b2;
     ctx.check(ms_ba_create(ctx.get(), &p1, 1, &b1.h), "ms_ba_create");
-    ctx.check(ms_ba_create(ctx.get(), &p2, 1, &b2.h), "ms_ba_create");
-    ctx.check(ms_ba_solve(b1.h), "ms_ba_solve");
+    ctx.check(ms_ba_solve(b1.h), "ms_ba_solve");                               // stage 1 runs on the device (k_ba_one_pose, ~0.3 ms) ...
+    ctx.check(ms_ba_create(ctx.get(), &p2, 1, &b2.h), "ms_ba_create");         // ... while the host builds stage 2's index structures (~0.3 ms)
     const std::int32_t cur = w.currentKeyframe;
     ctx.check(ms_ba_copy_state(b2.h, b1.h, &cur), "ms_ba_copy_state");
     ctx.check(ms_ba_solve(b2.h), "ms_ba_solve");

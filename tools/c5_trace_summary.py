@@ -1,6 +1,6 @@
 """Condenses a rocprofv3 --kernel-trace CSV of tools/c5_probe.py: per kernel name count / total / mean duration, the span of the trace, the time during which
 at least one kernel ran, and the average number of kernels in flight.   python tools/c5_trace_summary.py <kernel_trace.csv>"""
-import csv, sys
+import csv, re, sys
 from collections import defaultdict
 
 
@@ -9,7 +9,8 @@ def main():
     ev, per = [], defaultdict(lambda: [0, 0.0])
     for r in rows:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        name = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+        m = re.search(r"k_\w+", r["Kernel_Name"])
+        name = m.group(0) if m else r["Kernel_Name"][:40]
         per[name][0] += 1; per[name][1] += (e - s) / 1e3
         ev.append((s, 1)); ev.append((e, -1))
     ev.sort()
