@@ -247,6 +247,11 @@ class Rank:
         self.deferred = []                             # rank 0: (object, fn) -- CPU baselines, run after every GPU leg and after the process group is gone
         self.device = "cpu" if args.plumbing else "cuda"
         if not args.plumbing:
+            # before the first HIP call of this rank (and AFTER `import torch`, whose own copy of the HIP runtime has to be the one the process loads): one
+            # hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's default of 4 queues a sequence's 10 us
+            # front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
+            import mi355slam
+            mi355slam.prepare_process(N_SEQ)
             torch.cuda.set_device(self.local_rank)
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1199,11 +1204,6 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch(args, argv))                  # the parent never touches the GPU
-    if not args.plumbing:
-        # before the first HIP call of this rank: one hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's
-        # default of 4 queues a sequence's 10 us front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
-        import mi355slam
-        mi355slam.prepare_process(N_SEQ)
     R = Rank(args)
     if R.world != args.gpus and R.rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d; reporting n_gpus = WORLD_SIZE\n" % (args.gpus, R.world))
