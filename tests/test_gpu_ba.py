@@ -447,3 +447,13 @@ def test_one_pose_kernel_equals_the_general_solver_and_the_oracle(oracle, ctx, m
     one = mi355slam.BundleAdjuster(ctx, [probs[6]], max_iters=iters); one.solve()
     _check(probs[6], one.download(0), wants[6])
     one.close()
+    # more keyframes than the LDS pose table takes (512): the poses are read from memory; more lanes than points on one workgroup (a lane group per point
+    # without a team); and a window whose points outnumber the lanes of its team (several points per group, records in memory)
+    long_w = ba_synth.make_problem(530, 120, 4, seed=21, z_drift=0.004)
+    for k in ("edge_i", "edge_j", "edge_meas", "edge_info"): long_w[k] = long_w[k][-100:]
+    long_w = _stage1(long_w, 529)
+    small = _stage1(ba_synth.make_problem(5, 40, 4, seed=22), 2)
+    for q, team in ((long_w, 1), (long_w, 3), (small, 1), (probs[6], 2)):
+        b = mi355slam.BundleAdjuster(ctx, [q], max_iters=4); b.set_team(team); b.solve()
+        _check(q, b.download(0), oracle.ba_solve(q, 4, False))
+        b.close()

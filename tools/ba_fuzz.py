@@ -1,5 +1,5 @@
 """Differential fuzz of the bundle adjuster against the CPU oracle: N random windows (2..70 keyframes, ragged visibility, fixed poses and
-points, outliers, loop-closure edges, pose-only cases), solved alone / in a batch / on teams; residuals within 1e-7 (north_star: 1e-5; observed 2e-10 over 8000 windows), LM trajectory equal.
+points, outliers, loop-closure edges, pose-only cases, stage-1 shaped batches with one free keyframe), solved alone / in a batch / on teams; residuals within 1e-7 (north_star: 1e-5; observed 2e-10 over 8000 windows), LM trajectory equal.
 usage: python tools/ba_fuzz.py [N] [seed]"""
 import os, sys
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 ctx = mi355slam.Context(0)
 
 
-def random_problem():
+def random_problem(one_pose=False):
     n_pose = int(rng.integers(2, 71)); n_point = int(rng.integers(5, 900)); run = int(rng.integers(2, min(n_pose, 14) + 1))
     p = ba_synth.make_problem(n_pose, n_point, run, seed=int(rng.integers(0, 1 << 30)), outlier_frac=float(rng.choice([0, 0, 0.05, 0.15])),
                               fix_first=bool(rng.integers(0, 2)))
@@ -26,7 +26,9 @@ def random_problem():
     p["pose_fixed"] = p["pose_fixed"].copy()
     for i in rng.choice(n_pose, size=int(rng.integers(0, max(n_pose // 4, 1))), replace=False): p["pose_fixed"][i] = 1
     if p["pose_fixed"].all(): p["pose_fixed"][int(rng.integers(0, n_pose))] = 0
-    kind = int(rng.integers(0, 6))
+    if one_pose:                                                                              # stage 1 of localBundleAdjust: ONE free keyframe (any position), the points free or partly fixed
+        p["pose_fixed"][:] = 1; p["pose_fixed"][int(rng.integers(0, n_pose))] = 0
+    kind = int(rng.integers(1 if one_pose else 0, 6))
     if kind == 0: p["point_fixed"] = np.ones(n_point, np.uint8)                               # pose-only
     elif kind == 1: p["point_fixed"] = (rng.random(n_point) < 0.3).astype(np.uint8)
     if n_pose > 6 and rng.random() < 0.4:                                                     # a loop-closure edge between far keyframes
@@ -40,7 +42,8 @@ def random_problem():
 bad = done = 0
 worst = 0.0
 while done < N:
-    probs = [random_problem() for _ in range(int(rng.integers(1, 5)))]
+    one_pose = rng.random() < 0.25                                       # the whole batch in the shape k_ba_one_pose takes (teams, lanes per point and rounds by the sizes drawn)
+    probs = [random_problem(one_pose) for _ in range(int(rng.integers(1, 5)))]
     iters = int(rng.integers(1, 9)); team = int(rng.choice([0, 1, 2, 5, 16]))
     want = [mso.ba_solve(p, iters, False) for p in probs]
     ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=iters); ba.set_team(team); ba.solve()
