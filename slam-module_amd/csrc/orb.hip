@@ -901,6 +901,13 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     // A keypoint is a chain of dependent memory round trips (its slot -> coordinates -> patch -> angle -> BRIEF samples) and the
     // everything that does not depend on the keypoint is requested up front -- the lane's patch-offset table and the counts of
     // ALL levels in one batch (not one load per loop trip).
+    // What does not depend on the keypoint and is needed late -- the blur's tap operands (right before the blur) and the 256 BRIEF point pairs (after the
+    // orientation) -- was fetched from global memory where it was needed, behind the LDS fences no load may cross: two exposed round trips in the middle of every
+    // wave's chain, and this kernel is bound by the LENGTH of that chain (ablation: prologue + window fetch alone 0.35 of 0.60 ms, no prologue chain -0.07 ms,
+    // a quarter fewer vector instructions 0.00 ms).  They are block-wide tables in LDS now, loaded first thing, under the count loads.
+    __shared__ uint4 s_tab[64 + 256];                        // [0..31] horizontal taps (dt, n), [32..63] vertical taps, [64..319] the point pairs [q][lane]
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = moment_tab[64 + threadIdx.x];
+    s_tab[64 + threadIdx.x] = reinterpret_cast<const uint4 *>(pattern_f)[threadIdx.x];
     const uint4 dm = moment_tab[lane];                       // disc mask of the lane's four patch dwords
     const uint32_t dmask[4] = {dm.x, dm.y, dm.z, dm.w};
     int cnt[MS_MAX_LEVELS];
@@ -912,6 +919,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
 #pragma unroll
     for (int l = 0; l < MS_MAX_LEVELS; ++l) total += cnt[l];
     if (slot0 == 0 && lane == 0) out_count[f] = total;
+    __syncthreads();                                         // the tables are in LDS (every wave of the block is still here)
     if (slot0 >= total) return;
     DescKp K[kDescPerWave];
 #pragma unroll
@@ -940,14 +948,14 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     // vertical pass on packed 16-bit lanes, horizontal pass with v_dot2 and one rounding -- and the blurred pyramid is no longer
     // written and read back for every frame (2 P bytes and a 0.49 ms kernel per 256-frame step; round 1 fetched 31 x 32 B of the level plus
     // 39 x 40 B of its blurred twin = 70 row pieces per keypoint, now 45).  k_blur still exists: ImagePyramid::getBlurredLevel runs it on demand.
-    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kDescPerWave][45 * 12 + 32 * 8 + 39 * 10 + 2];   // (+ 2: a wave's slab is a whole number of 16-byte units -- the window rows are read as ds_read_b128)
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[4][kDescPerWave][45 * 12 + 32 * 8 + 4];   // window + orientation patch (a whole number of 16-byte units: the window rows are read as ds_read_b128); the blurred patch takes the window's place
     const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
         int pitch;
         const uint8_t *img = level_ptr(src, g, f, K[k].oct, pitch);
         const int w = g->L[K[k].oct].w, h = g->L[K[k].oct].h, kx = K[k].x, ky = K[k].y;
-        uint32_t *win = &s_patch[wv][k][0], *pu = win + 45 * 12, *pb = pu + 32 * 8;
+        uint32_t *win = &s_patch[wv][k][0], *pu = win + 45 * 12, *pb = win;      // (pass 1 of the blur has read the whole window into registers before pass 2 writes the first blurred dword)
         if (kx >= 23 && kx + 24 < w && ky >= 22 && ky + 22 < h) {          // wave-uniform: the whole window lies inside the level
             const uint8_t *corner = img + (int64_t)(ky - 22) * pitch + (kx - 23);
 #pragma unroll
@@ -989,10 +997,15 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
             // 27 v_mfma_i32_16x16x64_i8 + ~150 vector instructions per keypoint, where the packed-16-bit form (k_blur's, 60 lanes x 8 rows) took ~350: the kernel sits at
             // the VALU issue limit and the matrix pipe was idle.
             const int n = lane & 15, q = lane >> 4;
-            const uint4 *bt = moment_tab + 64;
-            v4i_t Hb[3], Vb[3];
+            v4i_t Hb[3], Vb[3];                              // B operands of tile t: lane (n, kg) holds rows 16 kg .. + 15 of column 16 t + n -- non-zero only for kg - t = 0 or 1, and for columns <= 38
 #pragma unroll
-            for (int t = 0; t < 3; ++t) { Hb[t] = __builtin_bit_cast(v4i_t, bt[t * 64 + lane]); Vb[t] = __builtin_bit_cast(v4i_t, bt[(3 + t) * 64 + lane]); }
+            for (int t = 0; t < 3; ++t) {
+                const int dt = q - t;
+                const bool on = (dt == 0 || dt == 1) && (t < 2 || n <= 6);
+                const uint4 zero4 = {0u, 0u, 0u, 0u};
+                Hb[t] = __builtin_bit_cast(v4i_t, on ? s_tab[(dt & 1) * 16 + n] : zero4);
+                Vb[t] = __builtin_bit_cast(v4i_t, on ? s_tab[32 + (dt & 1) * 16 + n] : zero4);
+            }
             v4i_t T[3][3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -1063,11 +1076,11 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     unsigned long long bits[kDescPerWave][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 pt = pattern_f[q * 64 + lane];             // the test's two points, already float
+        const float4 pt = __builtin_bit_cast(float4, s_tab[64 + q * 64 + lane]);             // the test's two points, already float
         const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
 #pragma unroll
         for (int k = 0; k < kDescPerWave; ++k) {
-            const uint8_t *pb = reinterpret_cast<const uint8_t *>(&s_patch[wv][k][45 * 12 + 32 * 8]);
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(&s_patch[wv][k][0]);
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa[k]), __fmul_rn(y1, ca[k])));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca[k]), __fmul_rn(y1, sa[k])));
             const int r2 = __float2int_rn(__fadd_rn(__fmul_rn(x2, sa[k]), __fmul_rn(y2, ca[k])));
@@ -1297,22 +1310,20 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
                     if (u <= kHalfPatch && std::abs(u) <= G.umax[std::abs(v)]) mt[lane * 4 + t] |= 0xFFu << (8 * b);
                 }
             }
-        // behind it, k_describe's blur as matrix operands (B of v_mfma_i32_16x16x64_i8: lane (n, kg) holds rows k = 16 kg .. + 15 of column n, one byte each): the taps
-        // 18 34 48 56 48 34 18 by patch column x -- window byte k contributes to x when 0 <= k - x - 1 <= 6 -- and by patch row y (window row k, 0 <= k - y <= 6);
-        // columns / rows past 38 are zero.  [table 0 = horizontal, 1 = vertical][tile 0..2][lane][4 dwords]
+        // behind it, k_describe's blur as matrix operands (B of v_mfma_i32_16x16x64_i8: lane (n, kg) holds rows k = 16 kg .. + 15 of column 16 t + n, one byte each): the taps
+        // 18 34 48 56 48 34 18 by patch column x -- window byte k contributes to x when 0 <= k - x - 1 <= 6 -- and by patch row y (window row k, 0 <= k - y <= 6).  Only
+        // dt = kg - t = 0 and 1 can be non-zero, and the pattern depends on (dt, n) alone: [table 0 = horizontal, 1 = vertical][dt][n][4 dwords]
         {
             static const int w7[7] = {18, 34, 48, 56, 48, 34, 18};
-            mt.resize(64 * 4 + 6 * 64 * 4, 0u);
+            mt.resize(64 * 4 + 64 * 4, 0u);
             for (int tab = 0; tab < 2; ++tab)
-                for (int tile = 0; tile < 3; ++tile)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int n = lane & 15, kg = lane >> 4, xy = 16 * tile + n;
+                for (int dt = 0; dt < 2; ++dt)
+                    for (int n = 0; n < 16; ++n)
                         for (int j = 0; j < 16; ++j) {
-                            const int k = 16 * kg + j, tap = tab == 0 ? k - xy - 1 : k - xy;
-                            const uint32_t v = (xy <= 38 && tap >= 0 && tap <= 6) ? (uint32_t)w7[tap] : 0u;
-                            mt[64 * 4 + ((tab * 3 + tile) * 64 + lane) * 4 + j / 4] |= v << (8 * (j % 4));
+                            const int tap = 16 * dt + j - n - (tab == 0 ? 1 : 0);
+                            const uint32_t v = (tap >= 0 && tap <= 6) ? (uint32_t)w7[tap] : 0u;
+                            mt[64 * 4 + ((tab * 2 + dt) * 16 + n) * 4 + j / 4] |= v << (8 * (j % 4));
                         }
-                    }
         }
         std::vector<float> pf(1024);
         for (int i = 0; i < 1024; ++i) pf[i] = (float)pattern[i];
