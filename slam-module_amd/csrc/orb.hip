@@ -63,7 +63,7 @@ __device__ __forceinline__ int tile_level(const TileMap &tm, int levels, int t) 
 
 // What the tiled kernels (k_blur, k_fast) need about a level, also BY VALUE in the kernel arguments: one batch of scalar loads from the
 // kernel-argument segment once the block knows its level, instead of a chain of dependent loads from the geometry table behind branches.
-struct TileLevel { int32_t w, h, pitch, btiles_x, ftiles_x, cand_cap; uint32_t btiles_inv, ftiles_inv; uint64_t img_off, blur_off, cand_off; };
+struct TileLevel { int32_t w, h, pitch, btiles_x, ftiles_x, cand_cap; uint32_t btiles_inv, ftiles_inv; uint64_t img_off, blur_off, cand_off; float scale; int32_t det_base; };
 struct TileLevels { TileLevel L[MS_MAX_LEVELS]; uint64_t slab_stride, cand_stride; int32_t levels, fast_threshold; };
 
 struct FrameSrc {          // where pyramid level 0 lives for this call
@@ -869,6 +869,22 @@ __device__ __forceinline__ int wave_sum(int v) {      // DPP inclusive scan, tot
     return __builtin_amdgcn_readlane(wave_scan_add(v), 63);
 }
 
+// Output slot -> detection, one dword per slot (x | y << 12 | level << 24), and the frame's keypoint total: k_describe's waves found their keypoint through a chain
+// of dependent loads (the counts of all levels -> a 16-step search for the level -> the level's base in the geometry table -> the coordinates), ~150 scalar
+// instructions and three round trips in front of the window fetch of EVERY wave.  One block per (level, frame) writes the level's run of the table once.
+__global__ __launch_bounds__(256) void k_slots(const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
+                                               const int32_t *__restrict__ trk_count, uint32_t *__restrict__ slot_tab, int32_t *__restrict__ out_count,
+                                               TileLevels TL, int det_stride, int capacity) {
+    const int l = blockIdx.x, f = blockIdx.y;
+    int base = trk_count[f];
+    for (int k = 0; k < l; ++k) base += det_count[f * TL.levels + k];
+    const int cnt = det_count[f * TL.levels + l];
+    const uint64_t s0 = (uint64_t)f * det_stride + TL.L[l].det_base;
+    for (int i = threadIdx.x; i < cnt; i += 256)
+        if (base + i < capacity) slot_tab[(uint64_t)f * capacity + base + i] = (uint32_t)(uint16_t)det_x[s0 + i] | ((uint32_t)(uint16_t)det_y[s0 + i] << 12) | ((uint32_t)l << 24);
+    if (l == TL.levels - 1 && threadIdx.x == 0) out_count[f] = min(base + cnt, capacity);
+}
+
 // Keypoints a wave works on at once.  k_describe is bound by the memory system's throughput of scattered partial-line fetches: 2.0 GB
 // of HBM traffic per 256-frame launch for 0.87 GB of patch bytes, in 0.53 ms = 3.8 TB/s.  Measured without effect on its time: 6, 7
 // or 8 waves per SIMD; two keypoints side by side in a wave (0.64 ms, register pressure) or four one after another with the next
@@ -889,13 +905,13 @@ __device__ __forceinline__ void transpose4_rows(uint32_t (&r)[4]) {
     s = __builtin_amdgcn_permlane16_swap(r[2], r[3], false, false); r[2] = s[0]; r[3] = s[1];
 }
 
-__global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
-                                                  const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
+__global__ __launch_bounds__(256) void k_describe(FrameSrc src, TileLevels TL, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
+                                                  const uint32_t *__restrict__ slot_tab, int capacity, int max_tracks, int lk_level,
                                                   const int16_t *__restrict__ trk_x, const int16_t *__restrict__ trk_y, const float *__restrict__ trk_px,
                                                   const float *__restrict__ trk_py, const int32_t *__restrict__ trk_id, const int32_t *__restrict__ trk_count,
                                                   float *__restrict__ out_x, float *__restrict__ out_y, float *__restrict__ out_angle,
                                                   int32_t *__restrict__ out_octave, uint32_t *__restrict__ out_desc, int32_t *__restrict__ out_track,
-                                                  int32_t *__restrict__ out_count, int levels) {
+                                                  const int32_t *__restrict__ out_count) {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int slot0 = (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * kDescPerWave;   // wave-uniform: everything derived from it is scalar
     // A keypoint is a chain of dependent memory round trips (its slot -> coordinates -> patch -> angle -> BRIEF samples) and the
@@ -910,15 +926,9 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     s_tab[64 + threadIdx.x] = reinterpret_cast<const uint4 *>(pattern_f)[threadIdx.x];
     const uint4 dm = moment_tab[lane];                       // disc mask of the lane's four patch dwords
     const uint32_t dmask[4] = {dm.x, dm.y, dm.z, dm.w};
-    int cnt[MS_MAX_LEVELS];
-#pragma unroll
-    for (int l = 0; l < MS_MAX_LEVELS; ++l) cnt[l] = l < levels ? det_count[f * levels + l] : 0;
-    // segment table of this frame: [tracks][level 0][level 1]...
-    const int nt = trk_count[f];
-    int total = nt;
-#pragma unroll
-    for (int l = 0; l < MS_MAX_LEVELS; ++l) total += cnt[l];
-    if (slot0 == 0 && lane == 0) out_count[f] = total;
+    // the frame's keypoint total and this wave's table entry (k_slots): both addresses are known from the block index, one round trip
+    const int total = out_count[f], nt = trk_count[f];
+    const uint32_t ent = slot_tab[(uint64_t)f * capacity + min(slot0, capacity - 1)];
     __syncthreads();                                         // the tables are in LDS (every wave of the block is still here)
     if (slot0 >= total) return;
     DescKp K[kDescPerWave];
@@ -928,17 +938,14 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
         K[k].valid = slot < total;
         const int sl = K[k].valid ? slot : slot0;            // an absent second keypoint mirrors the first (its results are not stored)
         if (sl < nt) {
-            const uint64_t s2 = (uint64_t)f * g->max_tracks + sl;
-            K[k].x = trk_x[s2]; K[k].y = trk_y[s2]; K[k].ox = trk_px[s2]; K[k].oy = trk_py[s2]; K[k].oct = g->lk_level; K[k].tid_out = trk_id[s2];
+            const uint64_t s2 = (uint64_t)f * max_tracks + sl;
+            K[k].x = trk_x[s2]; K[k].y = trk_y[s2]; K[k].ox = trk_px[s2]; K[k].oy = trk_py[s2]; K[k].oct = lk_level; K[k].tid_out = trk_id[s2];
         } else {
-            int level = -1, idx = sl - nt;
-#pragma unroll
-            for (int l = 0; l < MS_MAX_LEVELS; ++l)
-                if (level < 0 && l < levels) { if (idx < cnt[l]) level = l; else idx -= cnt[l]; }
-            const uint64_t s2 = (uint64_t)f * g->det_stride + g->L[level].det_base + idx;
-            K[k].x = det_x[s2]; K[k].y = det_y[s2]; K[k].oct = level; K[k].tid_out = -1;
-            K[k].ox = __fmul_rn((float)K[k].x, g->L[level].scale);     // orb_extractor.cpp:156
-            K[k].oy = __fmul_rn((float)K[k].y, g->L[level].scale);
+            const uint32_t e2 = k == 0 ? ent : slot_tab[(uint64_t)f * capacity + sl];
+            const int level = (int)(e2 >> 24);
+            K[k].x = (int)(e2 & 0xFFFu); K[k].y = (int)((e2 >> 12) & 0xFFFu); K[k].oct = level; K[k].tid_out = -1;
+            K[k].ox = __fmul_rn((float)K[k].x, TL.L[level].scale);     // orb_extractor.cpp:156
+            K[k].oy = __fmul_rn((float)K[k].y, TL.L[level].scale);
         }
     }
     // ONE window of the (unblurred) level is copied into the wave's LDS slab with coalesced row loads: 45 rows x 48 B around the keypoint
@@ -952,9 +959,10 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
     const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
-        int pitch;
-        const uint8_t *img = level_ptr(src, g, f, K[k].oct, pitch);
-        const int w = g->L[K[k].oct].w, h = g->L[K[k].oct].h, kx = K[k].x, ky = K[k].y;
+        const TileLevel GL = TL.L[K[k].oct];               // (kernel arguments: no load from the geometry table behind the level)
+        const int pitch = K[k].oct == 0 ? src.lvl0_pitch : GL.pitch;
+        const uint8_t *img = K[k].oct == 0 ? src.lvl0 + (uint64_t)f * src.lvl0_frame_stride : src.slab + (uint64_t)f * TL.slab_stride + GL.img_off;
+        const int w = GL.w, h = GL.h, kx = K[k].x, ky = K[k].y;
         uint32_t *win = &s_patch[wv][k][0], *pu = win + 45 * 12, *pb = win;      // (pass 1 of the blur has read the whole window into registers before pass 2 writes the first blurred dword)
         if (kx >= 23 && kx + 24 < w && ky >= 22 && ky + 22 < h) {          // wave-uniform: the whole window lies inside the level
             const uint8_t *corner = img + (int64_t)(ky - 22) * pitch + (kx - 23);
@@ -1091,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, const PyrGeom *g
 #pragma unroll
     for (int k = 0; k < kDescPerWave; ++k) {
         if (!K[k].valid) continue;                              // wave-uniform
-        const uint64_t o = (uint64_t)f * g->capacity + slot0 + k;
+        const uint64_t o = (uint64_t)f * capacity + slot0 + k;
         if (lane < 8) out_desc[o * 8 + lane] = (uint32_t)(bits[k][lane >> 1] >> ((lane & 1) * 32));
         if (lane == 0) { out_x[o] = K[k].ox; out_y[o] = K[k].oy; out_angle[o] = angle_deg[k]; out_octave[o] = K[k].oct; out_track[o] = K[k].tid_out; }
     }
@@ -1121,6 +1129,7 @@ struct ms_orb {
     // outputs
     float *d_x = nullptr, *d_y = nullptr, *d_angle = nullptr;
     int32_t *d_octave = nullptr, *d_track = nullptr, *d_count = nullptr;
+    uint32_t *d_slot_tab = nullptr;           // k_slots: output slot -> x | y << 12 | level << 24
     uint32_t *d_desc = nullptr;
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
@@ -1231,7 +1240,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     G.capacity = G.det_stride + cfg->max_tracks;
     for (int l = 0; l < cfg->levels; ++l) {
         const LevelGeom &L = G.L[l];
-        o->tile_levels.L[l] = TileLevel{L.w, L.h, L.pitch, L.btiles_x, L.ftiles_x, L.cand_cap, L.btiles_inv, L.ftiles_inv, L.img_off, L.blur_off, L.cand_off};
+        o->tile_levels.L[l] = TileLevel{L.w, L.h, L.pitch, L.btiles_x, L.ftiles_x, L.cand_cap, L.btiles_inv, L.ftiles_inv, L.img_off, L.blur_off, L.cand_off, L.scale, L.det_base};
     }
     for (int l = 0; l <= MS_MAX_LEVELS; ++l) {
         o->blur_tiles.base[l] = l < cfg->levels ? G.L[l].btile_base : bt;
@@ -1259,7 +1268,7 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     A(dev_calloc(ctx, &o->d_trk_id, B * T)); A(dev_calloc(ctx, &o->d_track_xy, B * T * 2));
     A(dev_calloc(ctx, &o->d_track_id, B * T)); A(dev_calloc(ctx, &o->d_n_tracks, B));
     A(dev_calloc(ctx, &o->d_x, B * cap)); A(dev_calloc(ctx, &o->d_y, B * cap)); A(dev_calloc(ctx, &o->d_angle, B * cap));
-    A(dev_calloc(ctx, &o->d_octave, B * cap)); A(dev_calloc(ctx, &o->d_track, B * cap)); A(dev_calloc(ctx, &o->d_count, B));
+    A(dev_calloc(ctx, &o->d_octave, B * cap)); A(dev_calloc(ctx, &o->d_track, B * cap)); A(dev_calloc(ctx, &o->d_count, B)); A(dev_calloc(ctx, &o->d_slot_tab, B * cap));
     A(dev_calloc(ctx, &o->d_desc, B * cap * 8));
     if (rc == MS_OK && hipMemcpyAsync(o->d_geom, &o->geom, sizeof(PyrGeom), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
     for (int l = 1; l < cfg->levels && rc == MS_OK; ++l) {
@@ -1352,7 +1361,7 @@ void ms_orb_destroy(ms_orb *o) {
     (void)hipStreamSynchronize(o->ctx->stream);
     void *ptrs[] = {o->d_geom, o->d_slab, o->d_cand, o->d_cand_count, o->d_det_count, o->d_trk_count, o->d_det_x, o->d_det_y,
                     o->d_det_score, o->d_mask, o->d_trk_x, o->d_trk_y, o->d_trk_px, o->d_trk_py, o->d_trk_id, o->d_track_xy,
-                    o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc};
+                    o->d_track_id, o->d_n_tracks, o->d_x, o->d_y, o->d_angle, o->d_octave, o->d_track, o->d_count, o->d_desc, o->d_slot_tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (o->d_moment_tab) (void)hipFree(o->d_moment_tab);
     if (o->d_pattern_f) (void)hipFree(o->d_pattern_f);
@@ -1484,9 +1493,11 @@ static int orb_enqueue_kernels(ms_orb *o, FrameSrc src, int f0, int nf, bool hav
     detect_range.end();
     MsRange describe_range("describe");
     const size_t C = (size_t)G.capacity;
-    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), nf), dim3(256), 0, st, src, o->d_geom, o->d_moment_tab, o->d_pattern_f, det_x, det_y,
-                       det_count, o->d_trk_x + F * T, o->d_trk_y + F * T, o->d_trk_px + F * T, o->d_trk_py + F * T, o->d_trk_id + F * T, trk_count, o->d_x + F * C, o->d_y + F * C,
-                       o->d_angle + F * C, o->d_octave + F * C, o->d_desc + F * C * 8, o->d_track + F * C, o->d_count + F, G.levels);
+    hipLaunchKernelGGL(k_slots, dim3(G.levels, nf), dim3(256), 0, st, det_x, det_y, det_count, trk_count, o->d_slot_tab + F * C, o->d_count + F, o->tile_levels, G.det_stride, G.capacity);
+    MS_KERNEL_CHECK(c, "k_slots");
+    hipLaunchKernelGGL(k_describe, dim3(ms_div_up(G.capacity, 4 * kDescPerWave), nf), dim3(256), 0, st, src, o->tile_levels, o->d_moment_tab, o->d_pattern_f,
+                       o->d_slot_tab + F * C, G.capacity, G.max_tracks, G.lk_level, o->d_trk_x + F * T, o->d_trk_y + F * T, o->d_trk_px + F * T, o->d_trk_py + F * T, o->d_trk_id + F * T, trk_count, o->d_x + F * C, o->d_y + F * C,
+                       o->d_angle + F * C, o->d_octave + F * C, o->d_desc + F * C * 8, o->d_track + F * C, o->d_count + F);
     MS_KERNEL_CHECK(c, "k_describe");
     MS_STAGE_MARK();
 #undef MS_STAGE_MARK
