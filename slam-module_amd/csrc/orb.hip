@@ -893,6 +893,9 @@ __global__ __launch_bounds__(256) void k_slots(const int16_t *__restrict__ det_x
 // instructions (the moment sums below and the degree -> radian product).
 constexpr int kDescPerWave = 1;
 
+#ifndef MS_DESC_WAVES
+#define MS_DESC_WAVES 8       // waves per SIMD the register allocation of k_describe aims at (the kernel is bound by how many keypoints are in flight)
+#endif
 struct DescKp { int x, y, oct, tid_out; float ox, oy; bool valid; };
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 // r[m] in lane row q (the wave's four rows of 16 lanes)  ->  r[q] of lane row m: the 2 x 2 blocks trade places across the wave's halves
@@ -905,7 +908,7 @@ __device__ __forceinline__ void transpose4_rows(uint32_t (&r)[4]) {
     s = __builtin_amdgcn_permlane16_swap(r[2], r[3], false, false); r[2] = s[0]; r[3] = s[1];
 }
 
-__global__ __launch_bounds__(256) void k_describe(FrameSrc src, TileLevels TL, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_DESC_WAVES, 8))) void k_describe(FrameSrc src, TileLevels TL, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
                                                   const uint32_t *__restrict__ slot_tab, int capacity, int max_tracks, int lk_level,
                                                   const int16_t *__restrict__ trk_x, const int16_t *__restrict__ trk_y, const float *__restrict__ trk_px,
                                                   const float *__restrict__ trk_py, const int32_t *__restrict__ trk_id, const int32_t *__restrict__ trk_count,
@@ -1005,52 +1008,48 @@ __global__ __launch_bounds__(256) void k_describe(FrameSrc src, TileLevels TL, c
             // 27 v_mfma_i32_16x16x64_i8 + ~150 vector instructions per keypoint, where the packed-16-bit form (k_blur's, 60 lanes x 8 rows) took ~350: the kernel sits at
             // the VALU issue limit and the matrix pipe was idle.
             const int n = lane & 15, q = lane >> 4;
-            v4i_t Hb[3], Vb[3];                              // B operands of tile t: lane (n, kg) holds rows 16 kg .. + 15 of column 16 t + n -- non-zero only for kg - t = 0 or 1, and for columns <= 38
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            // B operands of tile t: lane (n, kg) holds rows 16 kg .. + 15 of column 16 t + n -- non-zero only for kg - t = 0 or 1, and for columns <= 38
+            auto taps = [&](int base, int t) {
                 const int dt = q - t;
                 const bool on = (dt == 0 || dt == 1) && (t < 2 || n <= 6);
                 const uint4 zero4 = {0u, 0u, 0u, 0u};
-                Hb[t] = __builtin_bit_cast(v4i_t, on ? s_tab[(dt & 1) * 16 + n] : zero4);
-                Vb[t] = __builtin_bit_cast(v4i_t, on ? s_tab[32 + (dt & 1) * 16 + n] : zero4);
-            }
-            v4i_t T[3][3];
+                return __builtin_bit_cast(v4i_t, on ? s_tab[base + (dt & 1) * 16 + n] : zero4);
+            };
+            v4i_t Aw[3], Vb[3];                              // the window rows as pass 1's A operands (read BEFORE the first blurred dword takes the window's place), the vertical taps
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 uint4 a4 = *reinterpret_cast<const uint4 *>(win + (16 * m + n) * 12 + 4 * q);
                 a4.x ^= 0x80808080u; a4.y ^= 0x80808080u; a4.z ^= 0x80808080u; a4.w ^= 0x80808080u;
-                const v4i_t a = __builtin_bit_cast(v4i_t, a4), zero = {0, 0, 0, 0};
-#pragma unroll
-                for (int t = 0; t < 3; ++t) T[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, Hb[t], zero, 0, 0, 0);
+                Aw[m] = __builtin_bit_cast(v4i_t, a4);
+                Vb[m] = taps(32, m);
             }
-            v4i_t A2h[3], A2l[3];
+            // one column tile at a time (pass 1 -> bytes -> transposes -> pass 2 -> store): the three tiles' intermediates side by side cost the kernel its eighth wave per SIMD
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
+                const v4i_t Hb = taps(0, t), zero = {0, 0, 0, 0};
                 uint32_t hd[4], ld[4];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    const uint32_t x01 = __builtin_amdgcn_perm((uint32_t)T[m][t][1], (uint32_t)T[m][t][0], 0x04000501u);      // [r0.b1, r1.b1, r0.b0, r1.b0]
-                    const uint32_t x23 = __builtin_amdgcn_perm((uint32_t)T[m][t][3], (uint32_t)T[m][t][2], 0x04000501u);
+                    const v4i_t T = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[m], Hb, zero, 0, 0, 0);
+                    const uint32_t x01 = __builtin_amdgcn_perm((uint32_t)T[1], (uint32_t)T[0], 0x04000501u);      // [r0.b1, r1.b1, r0.b0, r1.b0]
+                    const uint32_t x23 = __builtin_amdgcn_perm((uint32_t)T[3], (uint32_t)T[2], 0x04000501u);
                     hd[m] = __builtin_amdgcn_perm(x23, x01, 0x05040100u);
                     ld[m] = __builtin_amdgcn_perm(x23, x01, 0x07060302u) ^ 0x80808080u;
                 }
                 hd[3] = 0; ld[3] = 0;                                   // rows 48 .. 63: zero weights AND zero data
                 transpose4_rows(hd); transpose4_rows(ld);
-                A2h[t] = v4i_t{(int)hd[0], (int)hd[1], (int)hd[2], (int)hd[3]};
-                A2l[t] = v4i_t{(int)ld[0], (int)ld[1], (int)ld[2], (int)ld[3]};
-            }
+                const v4i_t A2h = {(int)hd[0], (int)hd[1], (int)hd[2], (int)hd[3]}, A2l = {(int)ld[0], (int)ld[1], (int)ld[2], (int)ld[3]};
 #pragma unroll
-            for (int yt = 0; yt < 3; ++yt)
-#pragma unroll
-                for (int xt = 0; xt < 3; ++xt) {
+                for (int yt = 0; yt < 3; ++yt) {
                     v4i_t acc = {33024, 33024, 33024, 33024};
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2h[xt], Vb[yt], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2h, Vb[yt], acc, 0, 0, 0);
                     acc <<= 8;
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2l[xt], Vb[yt], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2l, Vb[yt], acc, 0, 0, 0);
                     const int y = 16 * yt + n;
-                    if (y < 39 && 4 * xt + q < 10)                      // lane (n, q): pixels 16 xt + 4 q .. + 3 of patch row y (byte 2 of each sum; the sums stay below 2^24)
-                        pb[y * 10 + 4 * xt + q] = __builtin_amdgcn_perm((uint32_t)acc[1], (uint32_t)acc[0], 0x0C0C0602u) | __builtin_amdgcn_perm((uint32_t)acc[3], (uint32_t)acc[2], 0x06020C0Cu);
+                    if (y < 39 && 4 * t + q < 10)                       // lane (n, q): pixels 16 t + 4 q .. + 3 of patch row y (byte 2 of each sum; the sums stay below 2^24)
+                        pb[y * 10 + 4 * t + q] = __builtin_amdgcn_perm((uint32_t)acc[1], (uint32_t)acc[0], 0x0C0C0602u) | __builtin_amdgcn_perm((uint32_t)acc[3], (uint32_t)acc[2], 0x06020C0Cu);
                 }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
