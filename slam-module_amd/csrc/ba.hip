@@ -2841,7 +2841,9 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     const MS_GLOBAL uint8_t *pfix = (const MS_GLOBAL uint8_t *)P.point_fixed;
     const int nrounds = ONE ? 1 : (n_point + nslot - 1) / nslot;
     int seq = 0;
-    for (int i = gl; i < 7 * P.n_pose; i += team * OP_NT) P.pose[i] = P.pose0[i];
+    // (the free pose's seven entries are written ONCE, at the end, by the launch's first lane: the team's barriers carry no cache maintenance, and two workgroups on
+    //  different XCDs writing the same line -- one here, one at the end -- would leave the order of the two write-backs to chance)
+    for (int i = gl; i < 7 * P.n_pose; i += team * OP_NT) if (i / 7 != pi) P.pose[i] = P.pose0[i];
     if (lds_poses) for (int i = tid; i < 7 * P.n_pose; i += OP_NT) op_lds[i] = P.pose0[i];
     OpPoint ps;
     double Xt[3] = {0, 0, 0};                                             // ONE: the trial point
@@ -3318,7 +3320,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     OP_LAP(0);
     if (ONE && slot < n_point && sub == 0) { point[3 * (size_t)slot] = ps.X[0]; point[3 * (size_t)slot + 1] = ps.X[1]; point[3 * (size_t)slot + 2] = ps.X[2]; }
     if (gl == 0) {
-        const bool hung = team > 1 && P.flag[1] != 0;                      // a team barrier gave up: the result is not to be trusted
+        const bool hung = team > 1 && __hip_atomic_load(P.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;      // a team barrier gave up: the result is not to be trusted
         for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
         P.stats[6] = (isfinite(chi2_final) && !hung) ? 1 : 0; P.stats[7] = hung ? 1 : 0;
