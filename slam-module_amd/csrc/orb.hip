@@ -869,11 +869,11 @@ __device__ __forceinline__ int wave_sum(int v) {      // DPP inclusive scan, tot
     return __builtin_amdgcn_readlane(wave_scan_add(v), 63);
 }
 
-// Output slot -> detection, one dword per slot (x | y << 12 | level << 24), and the frame's keypoint total: k_describe's waves found their keypoint through a chain
+// Output slot -> detection, two dwords per slot (x | y << 16, level: coordinates up to the 32767 ms_orb_create admits), and the frame's keypoint total: k_describe's waves found their keypoint through a chain
 // of dependent loads (the counts of all levels -> a 16-step search for the level -> the level's base in the geometry table -> the coordinates), ~150 scalar
 // instructions and three round trips in front of the window fetch of EVERY wave.  One block per (level, frame) writes the level's run of the table once.
 __global__ __launch_bounds__(256) void k_slots(const int16_t *__restrict__ det_x, const int16_t *__restrict__ det_y, const int32_t *__restrict__ det_count,
-                                               const int32_t *__restrict__ trk_count, uint32_t *__restrict__ slot_tab, int32_t *__restrict__ out_count,
+                                               const int32_t *__restrict__ trk_count, uint2 *__restrict__ slot_tab, int32_t *__restrict__ out_count,
                                                TileLevels TL, int det_stride, int capacity) {
     const int l = blockIdx.x, f = blockIdx.y;
     int base = trk_count[f];
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_slots(const int16_t *__restrict__ det_x
     const int cnt = det_count[f * TL.levels + l];
     const uint64_t s0 = (uint64_t)f * det_stride + TL.L[l].det_base;
     for (int i = threadIdx.x; i < cnt; i += 256)
-        if (base + i < capacity) slot_tab[(uint64_t)f * capacity + base + i] = (uint32_t)(uint16_t)det_x[s0 + i] | ((uint32_t)(uint16_t)det_y[s0 + i] << 12) | ((uint32_t)l << 24);
+        if (base + i < capacity) slot_tab[(uint64_t)f * capacity + base + i] = uint2{(uint32_t)(uint16_t)det_x[s0 + i] | ((uint32_t)(uint16_t)det_y[s0 + i] << 16), (uint32_t)l};
     if (l == TL.levels - 1 && threadIdx.x == 0) out_count[f] = min(base + cnt, capacity);
 }
 
@@ -909,7 +909,7 @@ __device__ __forceinline__ void transpose4_rows(uint32_t (&r)[4]) {
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_DESC_WAVES, 8))) void k_describe(FrameSrc src, TileLevels TL, const uint4 *__restrict__ moment_tab, const float4 *__restrict__ pattern_f,
-                                                  const uint32_t *__restrict__ slot_tab, int capacity, int max_tracks, int lk_level,
+                                                  const uint2 *__restrict__ slot_tab, int capacity, int max_tracks, int lk_level,
                                                   const int16_t *__restrict__ trk_x, const int16_t *__restrict__ trk_y, const float *__restrict__ trk_px,
                                                   const float *__restrict__ trk_py, const int32_t *__restrict__ trk_id, const int32_t *__restrict__ trk_count,
                                                   float *__restrict__ out_x, float *__restrict__ out_y, float *__restrict__ out_angle,
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_DESC_WAV
     const uint32_t dmask[4] = {dm.x, dm.y, dm.z, dm.w};
     // the frame's keypoint total and this wave's table entry (k_slots): both addresses are known from the block index, one round trip
     const int total = out_count[f], nt = trk_count[f];
-    const uint32_t ent = slot_tab[(uint64_t)f * capacity + min(slot0, capacity - 1)];
+    const uint2 ent = slot_tab[(uint64_t)f * capacity + min(slot0, capacity - 1)];
     __syncthreads();                                         // the tables are in LDS (every wave of the block is still here)
     if (slot0 >= total) return;
     DescKp K[kDescPerWave];
@@ -944,9 +944,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MS_DESC_WAV
             const uint64_t s2 = (uint64_t)f * max_tracks + sl;
             K[k].x = trk_x[s2]; K[k].y = trk_y[s2]; K[k].ox = trk_px[s2]; K[k].oy = trk_py[s2]; K[k].oct = lk_level; K[k].tid_out = trk_id[s2];
         } else {
-            const uint32_t e2 = k == 0 ? ent : slot_tab[(uint64_t)f * capacity + sl];
-            const int level = (int)(e2 >> 24);
-            K[k].x = (int)(e2 & 0xFFFu); K[k].y = (int)((e2 >> 12) & 0xFFFu); K[k].oct = level; K[k].tid_out = -1;
+            const uint2 e2 = k == 0 ? ent : slot_tab[(uint64_t)f * capacity + sl];
+            const int level = (int)e2.y;
+            K[k].x = (int)(e2.x & 0xFFFFu); K[k].y = (int)(e2.x >> 16); K[k].oct = level; K[k].tid_out = -1;
             K[k].ox = __fmul_rn((float)K[k].x, TL.L[level].scale);     // orb_extractor.cpp:156
             K[k].oy = __fmul_rn((float)K[k].y, TL.L[level].scale);
         }
@@ -1128,7 +1128,7 @@ struct ms_orb {
     // outputs
     float *d_x = nullptr, *d_y = nullptr, *d_angle = nullptr;
     int32_t *d_octave = nullptr, *d_track = nullptr, *d_count = nullptr;
-    uint32_t *d_slot_tab = nullptr;           // k_slots: output slot -> x | y << 12 | level << 24
+    uint2 *d_slot_tab = nullptr;              // k_slots: output slot -> (x | y << 16, level)
     uint32_t *d_desc = nullptr;
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
