@@ -44,7 +44,10 @@ constexpr int kMaxFreePosesTeam = 2048;   // ... and the factorisation is spread
 constexpr int kMaxTeam = 64;         // workgroups that may share one problem
 constexpr size_t kBaCacheSlack = 8;  // a kept device block serves a request of at least 1/8 of its size
 constexpr size_t kBaCacheMaxBytes = (size_t)1 << 30;   // blocks kept per context for the next ms_ba_create: 1 GiB in total, larger ones are freed at destroy
-constexpr size_t kLdsBytes = 150 * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
+#ifndef MS_BA_LDS_KB
+#define MS_BA_LDS_KB 150                  // -DMS_BA_LDS_KB=78 -DMS_FS_OB=32 -DMS_BA_WAVES_PER_EU=4: the two-windows-per-CU build of tools/ba_occupancy_probe.py
+#endif
+constexpr size_t kLdsBytes = (size_t)MS_BA_LDS_KB * 1024;  // max(Schur staging 8 x 9 KB, Cholesky panel (n+1) x 16 doubles + x (n doubles))
 
 // One set of passes of the fused Schur phase.  A pass owns the free-pose rows [row0, row1) of S: their envelope part lives in an
 // LDS tile while every point that observes one of these poses adds its block products; points are packed into batches of
@@ -57,7 +60,8 @@ struct FsSet {
     const int32_t *b_fmt;                    // [n_batch] 0: the batch's pairs are chunks of 8; n > 0: n single pairs, one per lane (batches with <= 64 pairs);
                                              // < 0: G points with the SAME k poses, lane = point * k + pose slot -- no pair list in memory, the kernel enumerates the pairs
                                              // (slot a >= a0, slot b <= a, all points) itself: -1 - fmt = G | k << 7 | a0 << 12 (a0: first slot inside the pass's rows)
-    const int32_t *pobs;                     // per lane slot: observation, pose vertex, point, free pose index (int4)
+    const int32_t *pobs;                     // per lane slot: observation, pose vertex, point, free pose index (int4); a batch owns FS_OB slots, the unused ones hold observation -1
+    const double *puv;                       // per lane slot: u, v, information, 0 (the observation's constants side by side: two 16-byte loads at an address that needs no index)
     const uint16_t *pairs;                   // chunks of 8 pairs (a_lane | b_lane << 8, 0xFFFF = none): the pairs of a chunk fall into the same block (pose a,
                                              // pose b); a batch's chunks are sorted by block
     const int32_t *rowoff;                   // per pass, concatenated: offset (doubles) of pose row r0 + i inside the pass's tile
@@ -129,6 +133,14 @@ typedef double d2_t __attribute__((ext_vector_type(2)));   // builtin vectors: l
 typedef int i2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+// A pointer that is the same in every lane, as an SGPR pair in the global address space: loads through it are global_load with a scalar base (no 64-bit vector
+// address arithmetic, and -- unlike the flat loads a plain pointer read out of BaProb turns into -- they count on vmcnt only, so an LDS wait does not wait for them)
+template <class T>
+__device__ __forceinline__ const MS_GLOBAL T *uglobal(const T *p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (const MS_GLOBAL T *)(((uint64_t)hi << 32) | lo);
+}
 
 // ---------------------------------------------------------------- SE3 helpers (g2o / Eigen conventions)
 __device__ __forceinline__ void q_normalize(double *q) {
@@ -794,7 +806,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             __builtin_amdgcn_wave_barrier();
         }
     } else {
-        constexpr int EB = 128, ES = 80;                                          // edges per round; doubles per edge: e 6 | Ji 36 | Jj 36 | pad
+        constexpr int ES = 80, EB = kLdsBytes >= 128 * ES * 8 ? 128 : 64;                                          // edges per round; doubles per edge: e 6 | Ji 36 | Jj 36 | pad
         MS_LDS double *eb = (MS_LDS double *)lds_;
         const int rounds = (P.n_edge + EB - 1) / EB;
         for (int rd = rank_; rd < rounds; rd += T_) {
@@ -1022,40 +1034,74 @@ __device__ __noinline__ void schur_segments(const BaProb &P_, double *lds_) {
 // slab, then the lanes take the batch's (a, b) pairs and subtract Z_a Z_b^T (= W_a (Hll + lambda I)^-1 W_b^T) from block
 // (pose a, pose b) of the tile with LDS atomics.  Per damped solve the pass reads the 32 bytes of every observation (once per
 // pass its point touches) instead of 288 bytes per PAIR.  The sums are no longer in a fixed order (LDS atomics), like the SE3-edge sums.
-constexpr int FS_OB = 64;                                        // observations (lanes) per batch
-constexpr int kFsStageDoubles = NW * FS_OB * 18;                 // Z slabs of the 8 waves: 73,728 B
+#ifndef MS_FS_OB
+#define MS_FS_OB 64
+#endif
+constexpr int FS_OB = MS_FS_OB;                                  // observations (lanes) per batch
+constexpr int FS_ZD = 14;                                        // doubles per slab entry: Z_a = Jp_a^T G_a is kept as its factors, G (2 x 3) and the 8 entries of Jp that are neither zero nor repeated
+constexpr int kFsStageDoubles = NW * FS_OB * FS_ZD;              // slabs of the 8 waves: 57,344 B
 constexpr int kFsMetaDoubles = NW * FS_OB / 2;                   // free-pose index per lane: 2,048 B
-constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles;     // 9,728 doubles = 76 KB
+constexpr int kFsPoseTab = 128;                                  // poses (all vertices, free or fixed) whose 7 doubles each sit in LDS during the pass; a window with more reads them from memory
+constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles - 7 * kFsPoseTab;     // 10,880 doubles = 85 KB
 
 __device__ __forceinline__ void lds_sub(MS_LDS double *p, double v) {
     (void)__hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // ds_add_f64
 }
 
 constexpr int FS_RUN = 3;                                        // consecutive batches a wave takes at a time
+// Stamps inside schur_fused (build with BA_EXTRA=-DMS_FS_PROF, read with tools/ba_schur_prof.py): per-wave cycle sums of workgroup 0, kept in registers and written once per call:
+// 0 hand-out, 1 top of the batch (index loads issued), 2 Jacobians + slab stores, 3 pair products, 4 last flush, 5 batches, 6 next batch's lane values requested, 7 single pairs / enumerated pairs
+#ifdef MS_FS_PROF
+__device__ long long g_fsprof[NW * 8];
+extern "C" int ms_debug_fsprof(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fsprof), sizeof(g_fsprof)); }
+#define FSP_DECL long long fst = clock64(), fsacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FSP(i) do { const long long _t = clock64(); fsacc[i] += _t - fst; fst = _t; } while (0)
+#if MS_FS_PROF > 1
+#define FSP_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")      /* -DMS_FS_PROF=2: the wait for the batch's loads gets a stamp of its own (and is forced to sit there) */
+#else
+#define FSP_WAIT_VM do { } while (0)
+#endif
+#define FSP_FLUSH do { if (blockIdx.x == 0 && lane == 0) { for (int i = 0; i < 8; ++i) g_fsprof[wave * 8 + i] += fsacc[i]; } } while (0)
+#else
+#define FSP_DECL
+#define FSP(i) do { } while (0)
+#define FSP_WAIT_VM do { } while (0)
+#define FSP_FLUSH do { } while (0)
+#endif
 #ifndef MS_FS_PROCEDURAL
 #define MS_FS_PROCEDURAL 1
 #endif
+#ifndef MS_FS_ABL
+#define MS_FS_ABL 0
+#endif
 constexpr bool kProceduralPairs = MS_FS_PROCEDURAL != 0;         // batches of equal pose sets carry no pair list (-DMS_FS_PROCEDURAL=0: lists for every batch, for A/B runs)
-template <bool PROCEDURAL>    // PROCEDURAL: the pass set has batches without pair lists (fmt < 0).  Two copies of the function: the enumeration code in the pair loop cost the
+template <bool PROCEDURAL, bool POSE_LDS>    // PROCEDURAL: the pass set has batches without pair lists (fmt < 0).  Two copies of the function: the enumeration code in the pair loop cost the
                               // list-only launches (256 windows, one workgroup each) 5 % through register allocation alone, whether or not it ever ran
+                              // POSE_LDS: every pose vertex of the window fits the LDS table (n_pose <= kFsPoseTab).  A template parameter, not a branch: where a value may come from
+                              // LDS or from memory the compiler's wait for it covers both counters in full, and with them every load that was meant to stay in flight
 __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double *lds_, long long *cyc) {
     __shared__ int s_fs_next;
     const BaProb &P = P_;
     BA_IDS
     const int n = P.n6;
     const FsSet &F = P.fs[T_ > 1 ? 1 : 0];
-    MS_LDS double *stage = (MS_LDS double *)lds_ + (size_t)wave * (FS_OB * 18);
+    MS_LDS double *stage = (MS_LDS double *)lds_ + (size_t)wave * (FS_OB * FS_ZD);
     MS_LDS int32_t *meta = (MS_LDS int32_t *)((MS_LDS double *)lds_ + kFsStageDoubles) + wave * FS_OB;
-    MS_LDS double *tile = (MS_LDS double *)lds_ + kFsStageDoubles + kFsMetaDoubles;
-    const MS_GLOBAL int32_t *cs = (const MS_GLOBAL int32_t *)P.fs_cs, *env = (const MS_GLOBAL int32_t *)P.env16;
-    const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)F.pobs;
-    const MS_GLOBAL u4_t *chunks = (const MS_GLOBAL u4_t *)F.pairs;
-    const MS_GLOBAL uint16_t *pairs16 = (const MS_GLOBAL uint16_t *)F.pairs;
-    const MS_GLOBAL int32_t *b_fmt = (const MS_GLOBAL int32_t *)F.b_fmt;
-    const MS_GLOBAL int32_t *b_obs = (const MS_GLOBAL int32_t *)F.b_obs_start, *b_run = (const MS_GLOBAL int32_t *)F.b_run_start;
-    const MS_GLOBAL double *Hpp = (const MS_GLOBAL double *)P.Hpp;
+    MS_LDS double *ptab = (MS_LDS double *)lds_ + kFsStageDoubles + kFsMetaDoubles;          // [7 n_pose] when n_pose <= kFsPoseTab
+    MS_LDS double *tile = ptab + 7 * kFsPoseTab;
+    constexpr bool pose_lds = POSE_LDS;
+    const MS_GLOBAL int32_t *cs = uglobal(P.fs_cs), *env = uglobal(P.env16);
+    const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)uglobal(F.pobs);
+    const MS_GLOBAL u4_t *chunks = (const MS_GLOBAL u4_t *)uglobal(F.pairs);
+    const MS_GLOBAL uint16_t *pairs16 = uglobal(F.pairs);
+    const MS_GLOBAL int32_t *b_fmt = uglobal(F.b_fmt);
+    const MS_GLOBAL int32_t *b_run = uglobal(F.b_run_start);
+    const MS_GLOBAL d2_t *puv = (const MS_GLOBAL d2_t *)uglobal(F.puv);
+    const MS_GLOBAL double *Hpp = uglobal(P.Hpp);
+    const MS_GLOBAL double *gpose = uglobal(P.pose), *gpoint = uglobal(P.point);
     MS_GLOBAL double *Sg = (MS_GLOBAL double *)P.S;
     const bool by_pts = F.by_points != 0;
+    const double huber_delta = P.huber;
     if (by_pts) {
         // the passes own points, not rows: S <- Hpp + lambda I (envelope part; zeros from the 16-row block's envelope up to it) and y <- bp first, by the whole
         // team, then every pass takes its points' products off them with atomics
@@ -1068,6 +1114,27 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
         }
         for (int i = gt; i < n; i += GT) P.y[i] = P.bp[i];
         team_sync(P);
+    }
+    // One workgroup per window: the 3 x 3 factor Hll + lambda I = L L^T and L^-1 bl once per POINT (into Hinv / dl, both unused by the fused path at this point; the
+    // first pass's barrier below orders them) instead of once per observation inside the batches -- three square roots and three divisions, ~80 dependent
+    // instructions that every one of a point's ~10 lanes repeated.  A team keeps them in the lanes: its passes would need a team barrier in between.
+    const bool pre = T_ == 1;
+    if (pre) {
+        for (int l = tid; l < P.n_point; l += NT) {
+            if (P.point_fixed && P.point_fixed[l]) continue;
+            double H[6];
+            load6(P.Hll + 6 * (size_t)l, H);
+            const double b0 = P.bl[3 * (size_t)l], b1 = P.bl[3 * (size_t)l + 1], b2 = P.bl[3 * (size_t)l + 2];
+            const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
+            const double l11 = sqrt(a), i11 = 1.0 / l11, l21 = H[1] * i11, l31 = H[2] * i11;
+            const double d2 = d - l21 * l21, l22 = sqrt(d2), i22 = 1.0 / l22, l32 = (H[4] - l31 * l21) * i22;
+            const double d3 = f - l31 * l31 - l32 * l32, l33 = sqrt(d3), i33 = 1.0 / l33;
+            if (!(a > 0) || !(d2 > 0) || !(d3 > 0) || !isfinite(i11 * i22 * i33)) P.flag[0] = 0;
+            const double u0 = b0 * i11, u1 = (b1 - l21 * u0) * i22, u2 = (b2 - l31 * u0 - l32 * u1) * i33;
+            const double Li[6] = {i11, l21, l31, i22, l32, i33};
+            store6(P.Hinv + 6 * (size_t)l, Li);
+            P.dl[3 * (size_t)l] = u0; P.dl[3 * (size_t)l + 1] = u1; P.dl[3 * (size_t)l + 2] = u2;
+        }
     }
     for (int pass = rank_; pass < F.n_pass; pass += T_) {
         const int r0 = F.row0[pass], r1 = F.row1[pass], yoff = F.yoff[2 * pass];
@@ -1082,6 +1149,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             else for (int c = lane; c < len; c += 64) trow[c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
         }
         for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = by_pts ? 0.0 : P.bp[6 * r0 + i];
+        if (pose_lds) for (int i = tid; i < 7 * P.n_pose; i += NT) ptab[i] = gpose[i];
         if (tid == 0) s_fs_next = 0;
         __syncthreads();
         const long long tp1 = clock64();
@@ -1100,62 +1168,118 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
         // runs per hand-out: a row pass of a team has ~75 batches per workgroup (runs of 1 / 2 / 3 / 4 / 5 / 7 gave 2.22 / 2.08 / 2.00 / 1.99 / 1.96 / 1.98 ms per C4 window:
         // fewer block flushes against a longer tail); a pass that owns points has ~10, one at a time
         const int fs_run = by_pts ? 1 : (T_ > 1 ? 5 : FS_RUN);
-        for (;;) {
-        int b_lo = 0;
-        if (lane == 0) b_lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
-        b_lo = __builtin_amdgcn_readfirstlane(b_lo);
-        if (b_lo >= pb1) break;
-        const int b_hi = min(b_lo + fs_run, pb1);
-        i4_t rec = {0, 0, 0, -1};
-        int o0 = 0, nobs = 0;
-        { o0 = b_obs[b_lo]; nobs = b_obs[b_lo + 1] - o0; if (lane < nobs) rec = pobs4[o0 + lane]; }
-        for (int b = b_lo; b < b_hi; ++b) {
-            const bool act = lane < nobs;
-            const int o = rec.x, pi = rec.y, l = rec.z, fa = rec.w;
-            double pose[7], X[3], uv[2], H[6], blv[3], info = 0;
-            if (act) {
+        FSP_DECL
+        // One stream of batches per wave, every batch's operands requested while the batch before it is worked on (round 4: with everything fetched at the top of
+        // a batch a wave of the 256-window launch waited 5.2 k cycles per batch for memory -- 270 MB of windows stream from HBM in every pass --, 29 % of the pass):
+        // the hand-out of the next run, the next batch's lane records and run table entry go out before the Jacobians, its point and observation values
+        // (15 doubles per lane) before the pair products.  A batch owns FS_OB lane slots of pobs / puv whatever it holds (padding: observation -1), so no
+        // address in this chain depends on a loaded value.
+        struct LaneData { double X[3], bl[3], H[6], uv[2], info; };
+        const MS_GLOBAL double *hsrc = uglobal(pre ? P.Hinv : P.Hll), *blsrc = uglobal(pre ? P.dl : P.bl);
+        auto fetch_lane = [&](const i4_t &r, int slot, LaneData &d) {
+            if (r.x >= 0) {
+                const int l = r.z;
 #pragma unroll
-                for (int q = 0; q < 7; ++q) pose[q] = P.pose[7 * (size_t)pi + q];
+                for (int q = 0; q < 3; ++q) { d.X[q] = gpoint[3 * l + q]; d.bl[q] = blsrc[3 * l + q]; }
+                const MS_GLOBAL d2_t *h2 = (const MS_GLOBAL d2_t *)(hsrc + 6 * l);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { X[q] = P.point[3 * (size_t)l + q]; blv[q] = P.bl[3 * (size_t)l + q]; }
-                load6(P.Hll + 6 * (size_t)l, H);
-                uv[0] = P.obs_uv[2 * (size_t)o]; uv[1] = P.obs_uv[2 * (size_t)o + 1]; info = P.obs_info[o];
+                for (int q = 0; q < 3; ++q) { const d2_t u = h2[q]; d.H[2 * q] = u.x; d.H[2 * q + 1] = u.y; }
+                const d2_t a = puv[2 * slot];
+                d.uv[0] = a.x; d.uv[1] = a.y; d.info = ((const MS_GLOBAL double *)puv)[4 * slot + 2];       // (8 bytes, not the whole 16: a destination register nobody reads is re-used at once, and that write waits for the load)
             }
-            // behind the gathers: this batch's run table entry and first pair chunk, the next batch's lane records
-            const int fmt = b_fmt[b], run_lo = b_run[b] >> 3, run_hi = fmt ? run_lo : (b_run[b + 1] >> 3);
+        };
+        int b = 0, b_hi = 0;
+        {
+            int lo = 0;
+            if (lane == 0) lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
+            b = __builtin_amdgcn_readfirstlane(lo); b_hi = min(b + fs_run, pb1);
+        }
+        i4_t rec = {-1, 0, 0, -1};
+        LaneData cur = {};
+        int fmt = 0, run0 = 0, run1 = 0;
+        if (b < pb1) { rec = pobs4[FS_OB * b + lane]; fmt = b_fmt[b]; run0 = b_run[b]; run1 = b_run[b + 1]; fetch_lane(rec, FS_OB * b + lane, cur); }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), as an instruction the compiler's counter tracking sees: otherwise the loop's first use of run0 waits for "everything" in EVERY
+                                                                   // iteration (the first batch's lane values are younger than it), and with it for the loads the loop has just issued
+        FSP(0);
+        while (b < pb1) {
+            // this batch's lane values were requested before the previous batch's pair products: they are here.  Saying so BEFORE the next loads go out keeps the compiler's
+            // wait in front of the Jacobians from covering those as well (the loads below sit in branches, so it would wait for "all of them")
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            const bool act = rec.x >= 0;
+            const int pi = rec.y, fa = rec.w;
+            int bn = b + 1, bn_hi = b_hi;
+            if (bn >= b_hi) {                                      // (uniform) the wave's next run
+                int lo = 0;
+                if (lane == 0) lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
+                bn = __builtin_amdgcn_readfirstlane(lo); bn_hi = min(bn + fs_run, pb1);
+            }
+            double pose[7];
+            if (act) {
+                if constexpr (pose_lds) {
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) pose[q] = ptab[7 * pi + q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) pose[q] = gpose[7 * pi + q];
+                }
+            }
+            const int run_lo = run0 >> 3, run_hi = fmt ? run_lo : (run1 >> 3);
             u4_t pk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (run_lo + lane < run_hi) pk = chunks[run_lo + lane];
             unsigned single = 0xFFFFu;
-            if (fmt > 0 && lane < fmt) single = pairs16[b_run[b] + lane];
-            i4_t rec_n = {0, 0, 0, -1};
-            int o0_n = 0, nobs_n = 0;
-            if (b + 1 < b_hi) { o0_n = b_obs[b + 1]; nobs_n = b_obs[b + 2] - o0_n; if (lane < nobs_n) rec_n = pobs4[o0_n + lane]; }
+            if (fmt > 0 && lane < fmt) single = pairs16[run0 + lane];
+            i4_t rec_n = {-1, 0, 0, -1};
+            int fmt_n = 0, run0_n = 0, run1_n = 0;
+            if (bn < pb1) { rec_n = pobs4[FS_OB * bn + lane]; fmt_n = b_fmt[bn]; run0_n = b_run[bn]; run1_n = b_run[bn + 1]; }
+            FSP_WAIT_VM; FSP(1);
+            const double (&X)[3] = cur.X, (&blv)[3] = cur.bl, (&H)[6] = cur.H, (&uv)[2] = cur.uv;
+            const double info = cur.info;
             if (act) {
                 double e[2], Jp[12], Jl[6];
                 proj_edge<true>(pose, X, uv, e, Jp, Jl);
                 const double chi2 = info * (e[0] * e[0] + e[1] * e[1]);
                 double rho, w;
-                huber(chi2, P.huber, rho, w);
+                huber(chi2, huber_delta, rho, w);
                 const double wi = w * info;
-                // Hll + lambda I = L L^T
-                const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
-                const double l11 = sqrt(a), i11 = 1.0 / l11, l21 = H[1] * i11, l31 = H[2] * i11;
-                const double d2 = d - l21 * l21, l22 = sqrt(d2), i22 = 1.0 / l22, l32 = (H[4] - l31 * l21) * i22;
-                const double d3 = f - l31 * l31 - l32 * l32, l33 = sqrt(d3), i33 = 1.0 / l33;
-                if (!(a > 0) || !(d2 > 0) || !(d3 > 0) || !isfinite(i11 * i22 * i33)) P.flag[0] = 0;
-                const double u0 = blv[0] * i11, u1 = (blv[1] - l21 * u0) * i22, u2 = (blv[2] - l31 * u0 - l32 * u1) * i33;      // L^-1 bl
-                const bool mine = fa >= r0 && fa < r1;
+                // Hll + lambda I = L L^T: one workgroup per window has it from the pre-pass (H = the reciprocal diagonal and the off-diagonal entries of L, blv = L^-1 bl)
+                double i11, l21, l31, i22, l32, i33, u0, u1, u2;
+                if (pre) { i11 = H[0]; l21 = H[1]; l31 = H[2]; i22 = H[3]; l32 = H[4]; i33 = H[5]; u0 = blv[0]; u1 = blv[1]; u2 = blv[2]; }
+                else {
+                    const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
+                    const double l11 = sqrt(a);
+                    i11 = 1.0 / l11; l21 = H[1] * i11; l31 = H[2] * i11;
+                    const double d2 = d - l21 * l21, l22 = sqrt(d2);
+                    i22 = 1.0 / l22; l32 = (H[4] - l31 * l21) * i22;
+                    const double d3 = f - l31 * l31 - l32 * l32, l33 = sqrt(d3);
+                    i33 = 1.0 / l33;
+                    if (!(a > 0) || !(d2 > 0) || !(d3 > 0) || !isfinite(i11 * i22 * i33)) P.flag[0] = 0;
+                    u0 = blv[0] * i11; u1 = (blv[1] - l21 * u0) * i22; u2 = (blv[2] - l31 * u0 - l32 * u1) * i33;      // L^-1 bl
+                }
+                // Z = W L^-T with W = wi Jp^T Jl (6 x 3) has rank 2: Z = Jp^T G, G = wi Jl L^-T (2 x 3).  The slab keeps the factors -- 14 doubles per observation instead of
+                // 18, 18 operations here instead of 90 -- and a block product becomes Jp_a^T (G_a G_b^T) Jp_b: 92 multiply-adds instead of 108 (Jp has two structural zeros)
+                double G[6], sr[2];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const double w0 = wi * (Jp[r] * Jl[0] + Jp[6 + r] * Jl[3]), w1 = wi * (Jp[r] * Jl[1] + Jp[6 + r] * Jl[4]), w2 = wi * (Jp[r] * Jl[2] + Jp[6 + r] * Jl[5]);
-                    const double z0 = w0 * i11, z1 = (w1 - z0 * l21) * i22, z2 = (w2 - z0 * l31 - z1 * l32) * i33;               // row r of W L^-T
-                    stage[lane * 18 + 3 * r] = z0; stage[lane * 18 + 3 * r + 1] = z1; stage[lane * 18 + 3 * r + 2] = z2;
-                    if (mine) lds_sub(tile + yoff + 6 * (fa - r0) + r, z0 * u0 + z1 * u1 + z2 * u2);                            // W (Hll + lambda I)^-1 bl
+                for (int r = 0; r < 2; ++r) {
+                    const double w0 = wi * Jl[3 * r], w1 = wi * Jl[3 * r + 1], w2 = wi * Jl[3 * r + 2];
+                    const double g0 = w0 * i11, g1 = (w1 - g0 * l21) * i22, g2 = (w2 - g0 * l31 - g1 * l32) * i33;                     // row r of wi Jl L^-T
+                    G[3 * r] = g0; G[3 * r + 1] = g1; G[3 * r + 2] = g2;
+                    sr[r] = g0 * u0 + g1 * u1 + g2 * u2;
+                }
+                MS_LDS d2_t *ent = (MS_LDS d2_t *)(stage + lane * FS_ZD);
+                ent[0] = d2_t{G[0], G[1]}; ent[1] = d2_t{G[2], G[3]}; ent[2] = d2_t{G[4], G[5]};
+                ent[3] = d2_t{Jp[0], Jp[1]}; ent[4] = d2_t{Jp[2], Jp[3]}; ent[5] = d2_t{Jp[5], Jp[6]}; ent[6] = d2_t{Jp[8], Jp[11]};      // (Jp[4] = Jp[9] = 0, Jp[7] = -Jp[0], Jp[10] = Jp[3])
+                if (fa >= r0 && fa < r1) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) lds_sub(tile + yoff + 6 * (fa - r0) + r, Jp[r] * sr[0] + Jp[6 + r] * sr[1]);         // W (Hll + lambda I)^-1 bl = Jp^T (G L^-1 bl)
                 }
                 meta[lane] = fa;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            FSP(2);
+            LaneData nxt = {};
+            if (bn < pb1) fetch_lane(rec_n, FS_OB * bn + lane, nxt);
+            FSP(6);
             auto take_block = [&](unsigned ab) {                      // the block of pair ab becomes the lane's current one: the old sum goes out first
                 const int k2 = (meta[ab & 255u] << 16) | meta[ab >> 8];
                 if (k2 != key) {
@@ -1171,14 +1295,38 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
                 }
             };
             auto add_pair = [&](unsigned ab) {
-                const MS_LDS double *za = stage + (ab & 255u) * 18, *zb = stage + (ab >> 8) * 18;
-                double A[18], B[18];
+                const MS_LDS d2_t *za = (const MS_LDS d2_t *)(stage + (ab & 255u) * FS_ZD), *zb = (const MS_LDS d2_t *)(stage + (ab >> 8) * FS_ZD);
+                double A[FS_ZD], B[FS_ZD];
+#if MS_FS_ABL == 2          /* timing ablation (wrong results): no slab reads */
 #pragma unroll
-                for (int q = 0; q < 18; ++q) { A[q] = za[q]; B[q] = zb[q]; }
+                for (int q = 0; q < FS_ZD; ++q) { A[q] = acc[q] * 1e-300; B[q] = acc[q + 14] * 1e-300; }
+                (void)za; (void)zb;
+#else
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+                for (int q = 0; q < FS_ZD / 2; ++q) { const d2_t u = za[q], v = zb[q]; A[2 * q] = u.x; A[2 * q + 1] = u.y; B[2 * q] = v.x; B[2 * q + 1] = v.y; }
+#endif
+#if MS_FS_ABL == 1          /* timing ablation (wrong results): slab reads, no products */
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[6 * i + j] += A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+                for (int q = 0; q < FS_ZD; ++q) acc[q] += A[q] + B[q];
+                return;
+#endif
+                double M[4], T0[6], T1[6];                                 // M = G_a G_b^T, T = M Jp_b
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) M[2 * r + c] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
+                const double *qa = A + 6, *qb = B + 6;                     // Jp row 0 = (q0, q1, q2, q3, 0, q4), row 1 = (q5, -q0, q6, 0, q3, q7)
+                T0[0] = M[0] * qb[0] + M[1] * qb[5]; T0[1] = M[0] * qb[1] - M[1] * qb[0]; T0[2] = M[0] * qb[2] + M[1] * qb[6]; T0[3] = M[0] * qb[3]; T0[4] = M[1] * qb[3]; T0[5] = M[0] * qb[4] + M[1] * qb[7];
+                T1[0] = M[2] * qb[0] + M[3] * qb[5]; T1[1] = M[2] * qb[1] - M[3] * qb[0]; T1[2] = M[2] * qb[2] + M[3] * qb[6]; T1[3] = M[2] * qb[3]; T1[4] = M[3] * qb[3]; T1[5] = M[2] * qb[4] + M[3] * qb[7];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {                               // (chained: `acc += x + y` is a multiply, a multiply-add and an add -- contraction does not reassociate)
+                    acc[j] = fma(qa[0], T0[j], fma(qa[5], T1[j], acc[j]));
+                    acc[6 + j] = fma(qa[1], T0[j], fma(-qa[0], T1[j], acc[6 + j]));
+                    acc[12 + j] = fma(qa[2], T0[j], fma(qa[6], T1[j], acc[12 + j]));
+                    acc[18 + j] = fma(qa[3], T0[j], acc[18 + j]);
+                    acc[24 + j] = fma(qa[3], T1[j], acc[24 + j]);
+                    acc[30 + j] = fma(qa[4], T0[j], fma(qa[7], T1[j], acc[30 + j]));
+                }
             };
             if (PROCEDURAL && fmt < 0) {
                 // equal pose sets: block q of the batch is (slot a, slot b2), a0 <= a < k, b2 <= a, in that order; its G pairs (one per point) are cut into pieces of
@@ -1198,6 +1346,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
                 }
             }
             if (single != 0xFFFFu) { take_block(single); add_pair(single); }
+            FSP(7);
             for (int run = run_lo + lane; run < run_hi; run += 64) {
                 u4_t nx = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 if (run + 64 < run_hi) nx = chunks[run + 64];
@@ -1213,8 +1362,11 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            rec = rec_n; o0 = o0_n; nobs = nobs_n;
-        }
+            FSP(3);
+#ifdef MS_FS_PROF
+            fsacc[5] += 1;
+#endif
+            rec = rec_n; cur = nxt; fmt = fmt_n; run0 = run0_n; run1 = run1_n; b = bn; b_hi = bn_hi;
         }
         if (key >= 0) {
             const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
@@ -1224,6 +1376,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 #pragma unroll
                 for (int j = 0; j < 6; ++j) lds_sub(blk + i * len + j, acc[6 * i + j]);
         }
+        FSP(4); FSP_FLUSH;
         const long long tp2 = clock64();
         __syncthreads();
         cyc[6] += clock64() - tp2;
@@ -2335,7 +2488,11 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     const bool lead = P.team == 1 || blockIdx.x % (unsigned)P.team == 0;
     // P.flag[0] ("this damped solve is sound") is 1 on entry: the caller sets it behind a barrier that every reader of the previous value has passed
     const bool fused = P.fused != 0;
-    if (fused) { if (P.fs[P.team > 1 ? 1 : 0].by_points) schur_fused<true>(P, lambda, lds, cyc); else schur_fused<false>(P, lambda, lds, cyc); }
+    if (fused) {
+        const bool pl = P.n_pose <= kFsPoseTab;
+        if (P.fs[P.team > 1 ? 1 : 0].by_points) { if (pl) schur_fused<true, true>(P, lambda, lds, cyc); else schur_fused<true, false>(P, lambda, lds, cyc); }
+        else { if (pl) schur_fused<false, true>(P, lambda, lds, cyc); else schur_fused<false, false>(P, lambda, lds, cyc); }
+    }
     else {
         schur_prepare(P, lambda);
         { const long long t1 = clock64(); cyc[6] += t1 - t0; }
@@ -2402,7 +2559,12 @@ __global__ __launch_bounds__(256) void k_ba_copy_state(const BaProb *dst, const 
 }
 
 // grid = problems x team workgroups; workgroup b works on problem b / team
-__global__ __launch_bounds__(NT) void k_ba_lm(const BaProb *probs, int team) {
+#ifdef MS_BA_WAVES_PER_EU
+#define MS_BA_OCC __attribute__((amdgpu_waves_per_eu(MS_BA_WAVES_PER_EU, MS_BA_WAVES_PER_EU)))
+#else
+#define MS_BA_OCC
+#endif
+__global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int team) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s_red[NW];
     const BaProb &P = probs[blockIdx.x / (unsigned)team];      // fields stay in constant memory: uniform scalar loads, no private copy
@@ -3381,7 +3543,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     double tm_part[5] = {0, 0, 0, 0, 0}, tm_mark = tm0;                  // CSR + envelope | record-based Schur lists | Cholesky panel lists | fused Schur batches | windowed Cholesky tables
     auto tm_lap = [&](int k) { if (tm_on) { const double t = tm_now(); tm_part[k] += t - tm_mark; tm_mark = t; } };
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; bool by_points = false; };
+    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; std::vector<double> puv; bool by_points = false; };
     struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0;
                   bool one_pose = false; std::vector<int32_t> op_pose, op_o; std::vector<double> op_uvi; };
@@ -3389,7 +3551,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -3642,6 +3804,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                         }
                         while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF);
                     };
+                    auto pad_slots = [&]() {                              // a batch owns FS_OB lane slots (the kernel addresses batch b at slot FS_OB b): the rest hold "no observation"
+                        while ((F.pobs.size() / 4) % FS_OB) { F.pobs.push_back(-1); F.pobs.push_back(0); F.pobs.push_back(0); F.pobs.push_back(-1); }
+                    };
                     auto close_batch = [&](int pt_end) {
                         if (in_batch == 0) return;
                         int single_fmt = 0;
@@ -3654,6 +3819,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                             //  lists -- enumerating costs its Schur pass 4 %, 11.4 against 10.9 ms, and its handles are built once.  schur_fused<true> runs exactly these sets)
                             if (F.by_points && k <= 31 && G <= 127 && kProceduralPairs) {      // the kernel enumerates the pairs of such a batch itself: nothing to build, nothing to upload
                                 F.b_fmt.push_back(-1 - (G | (k << 7) | (a0 << 12)));
+                                pad_slots();
                                 F.b_obs_start.push_back((int32_t)(F.pobs.size() / 4)); F.b_run_start.push_back((int32_t)F.pairs.size());
                                 in_batch = 0;
                                 return;
@@ -3693,6 +3859,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                         }
                         while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF);
                         F.b_fmt.push_back(single_fmt);
+                        pad_slots();
                         F.b_obs_start.push_back((int32_t)(F.pobs.size() / 4)); F.b_run_start.push_back((int32_t)F.pairs.size());
                         in_batch = 0;
                     };
@@ -3714,6 +3881,11 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                     F.batch_start.push_back((int32_t)F.b_obs_start.size() - 1);
                 }
                 F.b_obs_start.push_back(F.b_obs_start.back());
+                F.puv.assign(F.pobs.size(), 0.0);                         // per lane slot: u, v, information, 0
+                for (size_t i = 0; i < F.pobs.size() / 4; ++i) {
+                    const int o = F.pobs[4 * i];
+                    if (o >= 0) { F.puv[4 * i] = Q.obs_uv[2 * (size_t)o]; F.puv[4 * i + 1] = Q.obs_uv[2 * (size_t)o + 1]; F.puv[4 * i + 2] = Q.obs_info[o]; }
+                }
             }
         }
         tm_lap(3);
@@ -3780,7 +3952,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int set = 0; set < 2; ++set) {
             const FsHost &F = R.fs[set];
             O.fs_row0[set] = bump(4 * F.row0.size()); O.fs_row1[set] = bump(4 * F.row1.size()); O.fs_batch[set] = bump(4 * F.batch_start.size());
-            O.fs_bobs[set] = bump(4 * F.b_obs_start.size()); O.fs_brun[set] = bump(4 * F.b_run_start.size()); O.fs_bfmt[set] = bump(4 * F.b_fmt.size()); O.fs_pobs[set] = bump(4 * F.pobs.size());
+            O.fs_bobs[set] = bump(4 * F.b_obs_start.size()); O.fs_brun[set] = bump(4 * F.b_run_start.size()); O.fs_bfmt[set] = bump(4 * F.b_fmt.size()); O.fs_pobs[set] = bump(4 * F.pobs.size()); O.fs_puv[set] = bump(8 * F.puv.size());
             O.fs_pairs[set] = bump(2 * F.pairs.size() + 16); O.fs_rowoff[set] = bump(4 * F.rowoff.size()); O.fs_yoff[set] = bump(4 * F.yoff.size());
         }
         O.op_pose = bump(4 * R.op_pose.size()); O.op_o = bump(4 * R.op_o.size()); O.op_uvi = bump(sizeof(double) * R.op_uvi.size());
@@ -3848,7 +4020,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             const FsHost &F = R.fs[set];
             up(O.fs_row0[set], F.row0.data(), 4 * F.row0.size()); up(O.fs_row1[set], F.row1.data(), 4 * F.row1.size()); up(O.fs_batch[set], F.batch_start.data(), 4 * F.batch_start.size());
             up(O.fs_bobs[set], F.b_obs_start.data(), 4 * F.b_obs_start.size()); up(O.fs_brun[set], F.b_run_start.data(), 4 * F.b_run_start.size()); up(O.fs_bfmt[set], F.b_fmt.data(), 4 * F.b_fmt.size());
-            up(O.fs_pobs[set], F.pobs.data(), 4 * F.pobs.size()); up(O.fs_pairs[set], F.pairs.data(), 2 * F.pairs.size());
+            up(O.fs_pobs[set], F.pobs.data(), 4 * F.pobs.size()); up(O.fs_puv[set], F.puv.data(), 8 * F.puv.size()); up(O.fs_pairs[set], F.pairs.data(), 2 * F.pairs.size());
             up(O.fs_rowoff[set], F.rowoff.data(), 4 * F.rowoff.size()); up(O.fs_yoff[set], F.yoff.data(), 4 * F.yoff.size());
         }
         up(O.op_pose, R.op_pose.data(), 4 * R.op_pose.size()); up(O.op_o, R.op_o.data(), 4 * R.op_o.size()); up(O.op_uvi, R.op_uvi.data(), sizeof(double) * R.op_uvi.size());
@@ -3881,7 +4053,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             if (set != R.fs_only) continue;
             F.n_pass = (int32_t)R.fs[set].row0.size();
             F.row0 = PTR(int32_t, fs_row0[set]); F.row1 = PTR(int32_t, fs_row1[set]); F.batch_start = PTR(int32_t, fs_batch[set]);
-            F.b_obs_start = PTR(int32_t, fs_bobs[set]); F.b_run_start = PTR(int32_t, fs_brun[set]); F.b_fmt = PTR(int32_t, fs_bfmt[set]); F.pobs = PTR(int32_t, fs_pobs[set]);
+            F.b_obs_start = PTR(int32_t, fs_bobs[set]); F.b_run_start = PTR(int32_t, fs_brun[set]); F.b_fmt = PTR(int32_t, fs_bfmt[set]); F.pobs = PTR(int32_t, fs_pobs[set]); F.puv = PTR(double, fs_puv[set]);
             F.pairs = PTR(uint16_t, fs_pairs[set]); F.rowoff = PTR(int32_t, fs_rowoff[set]); F.yoff = PTR(int32_t, fs_yoff[set]); F.by_points = R.fs[set].by_points ? 1 : 0;
         }
         if (R.fused) H.fs[1 - R.fs_only] = H.fs[R.fs_only];          // the set that was not built aliases the one that was
