@@ -251,7 +251,8 @@ class Rank:
             # hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's default of 4 queues a sequence's 10 us
             # front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
             import mi355slam
-            mi355slam.prepare_process(N_SEQ)
+            self.queues_prepared = mi355slam.prepare_process(N_SEQ)   # False: the runtime was up already (a profiler's preloaded tool): the queues are what the environment said then
+            self.hw_queues = mi355slam.hw_queues() if (self.queues_prepared or "GPU_MAX_HW_QUEUES" in os.environ) else 4
             torch.cuda.set_device(self.local_rank)
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1176,7 +1177,9 @@ def bench_c5(R, args):
             "driver": driver, "ba_team": ba_team or "library default (up to 32)",
             "scaling": "strong (8 sequences in total)", "frames_per_s": round(frames_total / dt_max, 1), "ba_per_s": round(ba_total / dt_max, 1),
             "seconds": round(dt_max, 4), "per_gpu": [round(v, 1) for v in R.gather(frames_mine / dt)],
-            "sequences_per_gpu": R.gather(len(mine)), "last_frame_matches": matches}
+            "sequences_per_gpu": R.gather(len(mine)), "last_frame_matches": matches,
+            # the hardware queues this rank's streams were mapped onto (ms_prepare_process; under a profiler that initialises the GPU first it is what the environment said)
+            "hw_queues": getattr(R, "hw_queues", None), "hw_queues_prepared_by_library": getattr(R, "queues_prepared", None)}
 
 
 def _c5_native_lib():

@@ -39,7 +39,8 @@ typedef enum {
     MS_ERR_NO_DEVICE = -2,    /* no gfx950 device, or HIP runtime failure at init */
     MS_ERR_HIP = -3,          /* a HIP call failed; see ms_last_error */
     MS_ERR_CAPACITY = -4,     /* a fixed capacity given at create time was exceeded */
-    MS_ERR_NUMERIC = -5       /* BA: non-finite state */
+    MS_ERR_NUMERIC = -5,      /* BA: non-finite state */
+    MS_ERR_TOO_LATE = -6      /* ms_prepare_process: the GPU runtime of this process is already up; the call can no longer have an effect */
 } ms_status;
 
 typedef struct ms_ctx ms_ctx;
@@ -52,8 +53,10 @@ typedef struct ms_orb ms_orb;
  * with its own stream) will drive the same GPU at the same time.  The HIP runtime maps streams onto a handful of hardware queues (4 by default), and kernels
  * of streams that share a queue run one after the other -- a 1.8 ms local-BA launch of one sequence then holds up the 10 us front-end kernels of another:
  * eight sequences on one GPU measured 4 300 frames/s with 4 queues and 6 100 with 8 (tools/c5_probe.py).  Sets GPU_MAX_HW_QUEUES to
- * max(4, min(concurrent_contexts, 16)) unless the variable is already set; has no effect once the runtime is initialised.  (The reference has no counterpart:
- * its back end is one CPU thread per sequence, mapper.cpp:268-269.) */
+ * max(4, min(concurrent_contexts, 16)) unless the variable is already set (the caller's own setting wins: MS_OK, nothing changed).  Once the runtime is
+ * initialised -- by this library or by anybody else in the process: the kernel driver's device node is open -- the variable has been read and the call returns
+ * MS_ERR_TOO_LATE without touching the environment, so a host that calls it late learns that it runs on the default number of queues.  (The reference has no
+ * counterpart: its back end is one CPU thread per sequence, mapper.cpp:268-269.) */
 int ms_prepare_process(int concurrent_contexts);
 int ms_ctx_create(int device, ms_ctx **out);
 void ms_ctx_destroy(ms_ctx *ctx);

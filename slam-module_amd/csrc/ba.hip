@@ -85,6 +85,8 @@ struct BaProb {
     const int32_t *pt_start, *pt_obs;        // observations grouped by point
     const int32_t *fstart, *fobs;            // observations grouped by FREE pose index; behind them, fobs[fstart[np_free] .. n_obs), those of the fixed poses
     const int32_t *free2pose;                // free index -> pose vertex
+    const int32_t *fo_lo;                    // the observations in fobs order as a stream: (point, observation) ...
+    const double *fo_uvi;                    // ... and (u, v, information, 0): coalesced loads at addresses that need no index (linearise_stream)
     // Schur work list: pairs (a,b) of observations of one free point with free poses fb <= fa, sorted by (fa,fb),
     // cut into chunks of CH items of the same pose pair (padding = -1); segments = runs of chunks of one pair
     int32_t n_chunks, n_seg;
@@ -510,7 +512,155 @@ __device__ __forceinline__ void poseobs_data(const BaProb &P, int o, int l, Pose
     }
 }
 
+// ---------------------------------------------------------------- linearisation of one workgroup's window from coalesced streams (round 4)
+// One workgroup per window (the chip-filling batch), point table in LDS.  Round 3's per-pose pass walked index chains -- list entry -> observation -> point ->
+// position, uv, information: per-lane gathers through flat loads, two deep -- and took 12 k cycles per 64 observations where its arithmetic is ~1.5 k: 256 windows
+// stream 270 MB per pass from HBM, and a wave had one or two gather groups in flight.  Here the observations of a pose are a static stream in pose order,
+// (point, observation) and (u, v, information) side by side: coalesced loads whose addresses depend on nothing, requested three and two steps ahead; only the
+// point's position is still a gather (one step ahead, from the 48 KB the window's points occupy).  Units of work are half poses, handed out from an LDS counter
+// (the waves of a SIMD do not run at the same speed); a unit's 27 sums leave with global atomics (Hpp's diagonal blocks and bp are zero at this point).
+__device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
+    __shared__ int s_ls_next;
+    const BaProb &P = *(const BaProb *)uglobal(&P_);
+    const int tid = threadIdx.x, lane = tid & 63;
+    MS_LDS double *ptab = (MS_LDS double *)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MS_LDS double *)lds_v);      // [n_point][H 6 | b 3]
+    const int n_point = P.n_point, np = P.np_free, n6 = P.n6, n_obs = P.n_obs;
+    const MS_GLOBAL i2_t *rec = (const MS_GLOBAL i2_t *)uglobal(P.fo_lo);
+    const MS_GLOBAL d2_t *uvi = (const MS_GLOBAL d2_t *)uglobal(P.fo_uvi);
+    const MS_GLOBAL double *gpoint = uglobal(P.point), *gpose = uglobal(P.pose);
+    const MS_GLOBAL uint8_t *pfix = P.point_fixed ? uglobal(P.point_fixed) : nullptr;
+    const MS_GLOBAL int32_t *fstart = uglobal(P.fstart), *free2pose = uglobal(P.free2pose), *obs_pose = uglobal(P.obs_pose);
+    MS_GLOBAL double *Hpp = (MS_GLOBAL double *)uglobal(P.Hpp), *bp = (MS_GLOBAL double *)uglobal(P.bp);
+    const double hub = P.huber;
+    for (int i = tid; i < 9 * n_point; i += NT) ptab[i] = 0;
+    if (tid == 0) s_ls_next = 0;
+    __syncthreads();
+    // one observation: residual, both Jacobians, Huber weight; the point's Hll / bl terms into the LDS table, the pose's terms into A / g when it is free
+    auto point_terms = [&](int l, const double (&Jl)[6], const double (&e)[2], double wi) {
+        if (pfix && pfix[l]) return;
+        double Jw[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jw[a] = wi * Jl[a];
+        MS_LDS double *t = ptab + 9 * l;
+#if MS_LIN_ABL == 1           /* timing ablation (wrong results): plain stores instead of LDS atomics */
+        t[0] = fma(Jw[0], Jl[0], Jw[3] * Jl[3]); t[1] = fma(Jw[0], Jl[1], Jw[3] * Jl[4]); t[2] = fma(Jw[0], Jl[2], Jw[3] * Jl[5]);
+        t[3] = fma(Jw[1], Jl[1], Jw[4] * Jl[4]); t[4] = fma(Jw[1], Jl[2], Jw[4] * Jl[5]); t[5] = fma(Jw[2], Jl[2], Jw[5] * Jl[5]);
+        for (int a = 0; a < 3; ++a) t[6 + a] = -fma(Jw[a], e[0], Jw[3 + a] * e[1]);
+        return;
+#endif
+        lds_addd(t + 0, fma(Jw[0], Jl[0], Jw[3] * Jl[3])); lds_addd(t + 1, fma(Jw[0], Jl[1], Jw[3] * Jl[4])); lds_addd(t + 2, fma(Jw[0], Jl[2], Jw[3] * Jl[5]));
+        lds_addd(t + 3, fma(Jw[1], Jl[1], Jw[4] * Jl[4])); lds_addd(t + 4, fma(Jw[1], Jl[2], Jw[4] * Jl[5])); lds_addd(t + 5, fma(Jw[2], Jl[2], Jw[5] * Jl[5]));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lds_addd(t + 6 + a, -fma(Jw[a], e[0], Jw[3 + a] * e[1]));
+    };
+    // the observations of FIXED poses (the tail of the stream): point terms only, a thread each
+    for (int ix = fstart[np] + tid; ix < n_obs; ix += NT) {
+        const i2_t r = rec[ix];
+        const d2_t uvv = uvi[2 * ix];
+        const double info = ((const MS_GLOBAL double *)uvi)[4 * ix + 2];
+        const int pi = obs_pose[r.y];
+        double pose[7], X[3], e[2], Jp[12], Jl[6];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) pose[q] = gpose[7 * pi + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) X[q] = gpoint[3 * r.x + q];
+        const double uv[2] = {uvv.x, uvv.y};
+        proj_edge<true>(pose, X, uv, e, Jp, Jl);
+        double rho, w;
+        huber(info * (e[0] * e[0] + e[1] * e[1]), hub, rho, w);
+        point_terms(r.x, Jl, e, w * info);
+    }
+    // the free poses, a wave each (handed out from a counter: the waves of a SIMD do not run at the same speed)
+    for (;;) {
+        int fp = 0;
+        if (lane == 0) fp = atomicAdd(&s_ls_next, 1);
+        fp = __builtin_amdgcn_readfirstlane(fp);
+        if (fp >= np) break;
+        const int pi = free2pose[fp];
+        double pose[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) pose[q] = gpose[7 * pi + q];
+        const int lo = fstart[fp], hi = fstart[fp + 1];
+        double A[21], g[6];
+#pragma unroll
+        for (int a = 0; a < 21; ++a) A[a] = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) g[a] = 0;
+        // every load of the pipeline is unconditional (indices clamped into the pose's run): a load inside a branch makes the compiler's wait for ANY later value a
+        // wait for everything in flight, and the pipeline collapses into one round trip per step
+        struct Ob { int l; double u, v, info; };
+        auto fetch_ob = [&](int ii, Ob &d) {
+            const int ic = min(ii, hi - 1);
+            d.l = rec[ic].x;
+            const d2_t a = uvi[2 * ic];
+            d.u = a.x; d.v = a.y; d.info = ((const MS_GLOBAL double *)uvi)[4 * ic + 2];
+        };
+        auto fetch_x = [&](int l, double (&X)[3]) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) X[q] = gpoint[3 * l + q];
+        };
+        if (hi > lo) {
+            Ob o0, o1, o2;
+            double X0[3], X1[3];
+            int ii = lo + lane;
+            fetch_ob(ii, o0); fetch_ob(ii + 64, o1); fetch_ob(ii + 128, o2);
+            fetch_x(o0.l, X0);
+            for (; ii - lane < hi; ii += 64) {
+                Ob o3;
+                fetch_ob(ii + 192, o3);
+                fetch_x(o1.l, X1);
+                if (ii < hi) {
+                    double e[2], Jp[12], Jl[6];
+                    const double uv[2] = {o0.u, o0.v};
+                    proj_edge<true>(pose, X0, uv, e, Jp, Jl);
+                    double rho, w;
+                    huber(o0.info * (e[0] * e[0] + e[1] * e[1]), hub, rho, w);
+                    const double wi = w * o0.info;
+                    double Jw[12];
+#pragma unroll
+                    for (int a = 0; a < 12; ++a) Jw[a] = wi * Jp[a];
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        g[a] = fma(-Jw[a], e[0], fma(-Jw[6 + a], e[1], g[a]));
+#pragma unroll
+                        for (int b = a; b < 6; ++b) { A[k] = fma(Jw[a], Jp[b], fma(Jw[6 + a], Jp[6 + b], A[k])); ++k; }
+                    }
+                    point_terms(o0.l, Jl, e, wi);
+                }
+                o0 = o1; o1 = o2; o2 = o3;
+                X0[0] = X1[0]; X0[1] = X1[1]; X0[2] = X1[2];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 21; ++a) A[a] = wave_sum_d(A[a]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) g[a] = wave_sum_d(g[a]);
+        if (lane == 0) {                                           // the pose's diagonal block and gradient: this wave alone writes them (plain stores)
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                bp[6 * fp + a] = g[a];
+#pragma unroll
+                for (int b = a; b < 6; ++b) { Hpp[(size_t)(6 * fp + a) * n6 + 6 * fp + b] = A[k]; Hpp[(size_t)(6 * fp + b) * n6 + 6 * fp + a] = A[k]; ++k; }
+            }
+        }
+    }
+    __syncthreads();
+    MS_GLOBAL double *Hll = (MS_GLOBAL double *)uglobal(P.Hll), *bl = (MS_GLOBAL double *)uglobal(P.bl);
+    for (int i = tid; i < 9 * n_point; i += NT) {                  // the point table leaves the LDS before the SE3 edges take it over
+        const int l = i / 9, c = i - 9 * l;
+        if (c < 6) Hll[6 * l + c] = ptab[i]; else bl[3 * l + c - 6] = ptab[i];
+    }
+}
+
 // ---------------------------------------------------------------- linearisation
+#ifndef MS_LIN_ABL
+#define MS_LIN_ABL 0
+#endif
+#ifndef MS_LIN_NO_STREAM
+#define MS_LIN_NO_STREAM 0          /* -DMS_LIN_NO_STREAM=1: round 3's per-pose pass over index chains (A/B runs) */
+#endif
 #ifdef MS_LIN_PROF
 __device__ long long g_lin[32 * 8 * 6];
 extern "C" int ms_debug_linprof(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin), sizeof(g_lin)); }
@@ -621,7 +771,9 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     // every observation twice: 260 k + 340 k cycles of a 760 k-cycle linearisation.
     const bool one_pass = T_ == 1 && !obs_par && P.fused && 9 * (size_t)P.n_point + 64 <= kLdsBytes / 8;
     MS_LDS double *ptab1 = (MS_LDS double *)lds_;
-    if (one_pass) {
+    const bool stream = one_pass && P.fo_lo != nullptr && !MS_LIN_NO_STREAM;
+    if (stream) linearise_stream(P, lds_);
+    if (one_pass && !stream) {
         for (int i = tid; i < 9 * P.n_point; i += NT) ptab1[i] = 0;
         __syncthreads();
         for (int ix = P.fstart[P.np_free] + tid; ix < P.n_obs; ix += NT) {      // observations whose pose is fixed (the tail of fobs): point terms only
@@ -694,7 +846,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     const int edge_waves = T_ > 1 ? min(P.n_edge, GW / 2) : 0;
     const int PW = GW - edge_waves, pw = gws - edge_waves;      // (gws: the edges land on the last waves of every workgroup, the point loop above kept the first ones busy)
     const int n_slice = T_ > 1 ? max(1, min(8, PW / max(P.np_free, 1))) : 1;
-    for (int u = pw; !obs_par && pw >= 0 && u < P.np_free * n_slice; u += PW) {
+    for (int u = pw; !obs_par && !stream && pw >= 0 && u < P.np_free * n_slice; u += PW) {
         const int fp = u / n_slice, sl = u - fp * n_slice;
         const int pi = P.free2pose[fp];
         double pose[7];
@@ -754,7 +906,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
         }
     }
     LINP(3);
-    if (one_pass) {                                                // the point table leaves the LDS before the SE3 edges take it over
+    if (one_pass && !stream) {                                     // the point table leaves the LDS before the SE3 edges take it over
         __syncthreads();
         for (int i = tid; i < 9 * P.n_point; i += NT) {
             const int l = i / 9, c = i - 9 * l;
@@ -1042,13 +1194,14 @@ constexpr int FS_ZD = 14;                                        // doubles per 
 constexpr int kFsStageDoubles = NW * FS_OB * FS_ZD;              // slabs of the 8 waves: 57,344 B
 constexpr int kFsMetaDoubles = NW * FS_OB / 2;                   // free-pose index per lane: 2,048 B
 constexpr int kFsPoseTab = 128;                                  // poses (all vertices, free or fixed) whose 7 doubles each sit in LDS during the pass; a window with more reads them from memory
-constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles - 7 * kFsPoseTab;     // 10,880 doubles = 85 KB
+constexpr int kFsRowTab = 320;                                   // pose rows a pass can hold at most (a row needs 42 doubles of the tile at least): their (first column, tile offset) pairs sit in LDS
+constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles - 7 * kFsPoseTab - kFsRowTab;     // 10,560 doubles = 82.5 KB
+static_assert(kFsTileDoubles / 42 <= kFsRowTab, "row table too small for the tile");
 
 __device__ __forceinline__ void lds_sub(MS_LDS double *p, double v) {
     (void)__hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // ds_add_f64
 }
 
-constexpr int FS_RUN = 3;                                        // consecutive batches a wave takes at a time
 // Stamps inside schur_fused (build with BA_EXTRA=-DMS_FS_PROF, read with tools/ba_schur_prof.py): per-wave cycle sums of workgroup 0, kept in registers and written once per call:
 // 0 hand-out, 1 top of the batch (index loads issued), 2 Jacobians + slab stores, 3 pair products, 4 last flush, 5 batches, 6 next batch's lane values requested, 7 single pairs / enumerated pairs
 #ifdef MS_FS_PROF
@@ -1079,16 +1232,21 @@ template <bool PROCEDURAL, bool POSE_LDS>    // PROCEDURAL: the pass set has bat
                               // list-only launches (256 windows, one workgroup each) 5 % through register allocation alone, whether or not it ever ran
                               // POSE_LDS: every pose vertex of the window fits the LDS table (n_pose <= kFsPoseTab).  A template parameter, not a branch: where a value may come from
                               // LDS or from memory the compiler's wait for it covers both counters in full, and with them every load that was meant to stay in flight
-__device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double *lds_, long long *cyc) {
-    __shared__ int s_fs_next;
-    const BaProb &P = P_;
+__device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, double *lds_v, long long *cyc) {
+    __shared__ unsigned long long s_fs_q[NW];              // per wave: its range of the pass's batches still to do, next | end << 32 (the owner takes from the front, a wave that has run dry from the end)
+    // The arguments of an out-of-line function arrive in vector registers, and everything derived from them counts as per-lane data: the problem's fields, the LDS
+    // regions, the pass's bounds ... ~30 registers of "the same value in every lane", in a function that needs every one of its 256.  Say that they are uniform.
+    const BaProb &P = *(const BaProb *)uglobal(&P_);
+    const double lambda = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(lambda_)), __builtin_amdgcn_readfirstlane(__double2loint(lambda_)));
+    double *lds_ = (double *)(MS_LDS double *)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MS_LDS double *)lds_v);
     BA_IDS
     const int n = P.n6;
     const FsSet &F = P.fs[T_ > 1 ? 1 : 0];
     MS_LDS double *stage = (MS_LDS double *)lds_ + (size_t)wave * (FS_OB * FS_ZD);
     MS_LDS int32_t *meta = (MS_LDS int32_t *)((MS_LDS double *)lds_ + kFsStageDoubles) + wave * FS_OB;
     MS_LDS double *ptab = (MS_LDS double *)lds_ + kFsStageDoubles + kFsMetaDoubles;          // [7 n_pose] when n_pose <= kFsPoseTab
-    MS_LDS double *tile = ptab + 7 * kFsPoseTab;
+    MS_LDS i2_t *rowtab = (MS_LDS i2_t *)(ptab + 7 * kFsPoseTab);                          // [r1 - r0] of the pass: first scalar column of the row's envelope part, offset of the row in the tile
+    MS_LDS double *tile = (MS_LDS double *)rowtab + kFsRowTab;
     constexpr bool pose_lds = POSE_LDS;
     const MS_GLOBAL int32_t *cs = uglobal(P.fs_cs), *env = uglobal(P.env16);
     const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)uglobal(F.pobs);
@@ -1150,30 +1308,53 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
         }
         for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = by_pts ? 0.0 : P.bp[6 * r0 + i];
         if (pose_lds) for (int i = tid; i < 7 * P.n_pose; i += NT) ptab[i] = gpose[i];
-        if (tid == 0) s_fs_next = 0;
+        for (int i = tid; i < r1 - r0; i += NT) rowtab[i] = i2_t{cs[r0 + i], rowoff[r0 + i]};
+        if (tid < NW) {                                            // the pass's batches in NW contiguous ranges
+            const int pbs = F.batch_start[pass], nbp = F.batch_start[pass + 1] - pbs;
+            const unsigned lo = (unsigned)(pbs + (long long)nbp * tid / NW), hi = (unsigned)(pbs + (long long)nbp * (tid + 1) / NW);
+            s_fs_q[tid] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
         __syncthreads();
         const long long tp1 = clock64();
         cyc[5] += tp1 - tp0;
-        // every wave takes a contiguous range of the pass's batches (balanced by the host): the pass's points are sorted by their set of
-        // poses, so consecutive batches mostly repeat the same blocks and a lane keeps the sum of "its" block in registers from batch
-        // to batch (LDS fp64 atomics retire ~2 lanes per cycle: one flush per block change instead of one per pair makes them affordable).
-        // Index data is read one batch ahead (lane records) resp. before the Jacobians (the lane's first run), so their latency hides.
-        // batches are handed out in runs of FS_RUN consecutive ones from a counter in LDS (the cost of a batch depends on how its pairs
-        // fall onto lanes: a static split left the slowest wave 30 % behind)
+        // Every wave owns a contiguous range of the pass's batches: the pass's points are sorted by their set of poses, so consecutive batches mostly repeat the
+        // same blocks and a lane keeps the sum of "its" block in registers from batch to batch -- the block goes to the tile (36 LDS fp64 atomics per lane, ~2 lanes
+        // per cycle) only when the lane's block changes.  A wave that has finished its range takes batches off the END of another wave's (the waves of a SIMD do not
+        // run at the same speed: the older one has priority, 27 against 19 batches of a C4 pass), so the owner's run stays contiguous.  (Round 3 handed out runs of
+        // three batches from one counter: a wave's consecutive runs were then far apart, every run started with a flush, and the flushes -- with two dependent global
+        // loads for the row's tile offset in front of them -- were 3 k of the 8 k cycles a batch's products took.)
         const int pb0 = F.batch_start[pass], pb1 = F.batch_start[pass + 1];
         double acc[36];
 #pragma unroll
         for (int q = 0; q < 36; ++q) acc[q] = 0;
         int key = -1;                                              // fa << 16 | fb of the block held in acc
+        double yacc[6] = {0, 0, 0, 0, 0, 0};                       // the lane's running part of the rhs of pose ykey
+        int ykey = -1;
         // runs per hand-out: a row pass of a team has ~75 batches per workgroup (runs of 1 / 2 / 3 / 4 / 5 / 7 gave 2.22 / 2.08 / 2.00 / 1.99 / 1.96 / 1.98 ms per C4 window:
         // fewer block flushes against a longer tail); a pass that owns points has ~10, one at a time
-        const int fs_run = by_pts ? 1 : (T_ > 1 ? 5 : FS_RUN);
         FSP_DECL
         // One stream of batches per wave, every batch's operands requested while the batch before it is worked on (round 4: with everything fetched at the top of
         // a batch a wave of the 256-window launch waited 5.2 k cycles per batch for memory -- 270 MB of windows stream from HBM in every pass --, 29 % of the pass):
-        // the hand-out of the next run, the next batch's lane records and run table entry go out before the Jacobians, its point and observation values
-        // (15 doubles per lane) before the pair products.  A batch owns FS_OB lane slots of pobs / puv whatever it holds (padding: observation -1), so no
-        // address in this chain depends on a loaded value.
+        // the next batch's lane records and run table entry go out before the Jacobians, its point and observation values (15 doubles per lane) before the pair
+        // products.  A batch owns FS_OB lane slots of pobs / puv whatever it holds (padding: observation -1), so no address in this chain depends on a loaded value.
+        auto next_batch = [&]() -> int {                           // the wave's next batch, or pb1 when the pass has none left for it (the same value in every lane)
+            int got = pb1;
+            if (lane == 0) {
+                for (int k = 0; k < NW && got == pb1; ++k) {
+                    const int v = (wave + (k & 1) * (NW / 2) + (k >> 1)) % NW;      // itself first, then its SIMD partner, then the others
+                    unsigned long long old = s_fs_q[v];
+                    for (;;) {
+                        const unsigned h = (unsigned)old, t = (unsigned)(old >> 32);
+                        if (h >= t) break;
+                        const unsigned long long nw = k == 0 ? ((unsigned long long)t << 32 | (h + 1)) : ((unsigned long long)(t - 1) << 32 | h);
+                        const unsigned long long seen = atomicCAS(&s_fs_q[v], old, nw);
+                        if (seen == old) { got = (int)(k == 0 ? h : t - 1); break; }
+                        old = seen;
+                    }
+                }
+            }
+            return __builtin_amdgcn_readfirstlane(got);
+        };
         struct LaneData { double X[3], bl[3], H[6], uv[2], info; };
         const MS_GLOBAL double *hsrc = uglobal(pre ? P.Hinv : P.Hll), *blsrc = uglobal(pre ? P.dl : P.bl);
         auto fetch_lane = [&](const i4_t &r, int slot, LaneData &d) {
@@ -1188,12 +1369,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
                 d.uv[0] = a.x; d.uv[1] = a.y; d.info = ((const MS_GLOBAL double *)puv)[4 * slot + 2];       // (8 bytes, not the whole 16: a destination register nobody reads is re-used at once, and that write waits for the load)
             }
         };
-        int b = 0, b_hi = 0;
-        {
-            int lo = 0;
-            if (lane == 0) lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
-            b = __builtin_amdgcn_readfirstlane(lo); b_hi = min(b + fs_run, pb1);
-        }
+        int b = next_batch();
         i4_t rec = {-1, 0, 0, -1};
         LaneData cur = {};
         int fmt = 0, run0 = 0, run1 = 0;
@@ -1207,12 +1383,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             __builtin_amdgcn_s_waitcnt(0x0F70);
             const bool act = rec.x >= 0;
             const int pi = rec.y, fa = rec.w;
-            int bn = b + 1, bn_hi = b_hi;
-            if (bn >= b_hi) {                                      // (uniform) the wave's next run
-                int lo = 0;
-                if (lane == 0) lo = pb0 + fs_run * atomicAdd(&s_fs_next, 1);
-                bn = __builtin_amdgcn_readfirstlane(lo); bn_hi = min(bn + fs_run, pb1);
-            }
+            const int bn = next_batch();
             double pose[7];
             if (act) {
                 if constexpr (pose_lds) {
@@ -1268,9 +1439,18 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
                 MS_LDS d2_t *ent = (MS_LDS d2_t *)(stage + lane * FS_ZD);
                 ent[0] = d2_t{G[0], G[1]}; ent[1] = d2_t{G[2], G[3]}; ent[2] = d2_t{G[4], G[5]};
                 ent[3] = d2_t{Jp[0], Jp[1]}; ent[4] = d2_t{Jp[2], Jp[3]}; ent[5] = d2_t{Jp[5], Jp[6]}; ent[6] = d2_t{Jp[8], Jp[11]};      // (Jp[4] = Jp[9] = 0, Jp[7] = -Jp[0], Jp[10] = Jp[3])
-                if (fa >= r0 && fa < r1) {
+                if (fa >= r0 && fa < r1) {                                    // W (Hll + lambda I)^-1 bl = Jp^T (G L^-1 bl), summed in the lane while its pose stays the same (lane = point x pose slot)
+                    if (fa != ykey) {
+                        if (ykey >= 0) {
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) lds_sub(tile + yoff + 6 * (fa - r0) + r, Jp[r] * sr[0] + Jp[6 + r] * sr[1]);         // W (Hll + lambda I)^-1 bl = Jp^T (G L^-1 bl)
+                            for (int r = 0; r < 6; ++r) lds_sub(tile + yoff + 6 * (ykey - r0) + r, yacc[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) yacc[r] = 0;
+                        ykey = fa;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) yacc[r] = fma(Jp[r], sr[0], fma(Jp[6 + r], sr[1], yacc[r]));
                 }
                 meta[lane] = fa;
             }
@@ -1284,12 +1464,14 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
                 const int k2 = (meta[ab & 255u] << 16) | meta[ab >> 8];
                 if (k2 != key) {
                     if (key >= 0) {
-                        const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
-                        MS_LDS double *blk = tile + rowoff[fa2] + 6 * fb2 - c0;
+                        const int fa2 = key >> 16, fb2 = key & 0xFFFF;
+                        const i2_t rt = rowtab[fa2 - r0];
+                        const int len = 6 * fa2 + 6 - rt.x;
+                        MS_LDS double *blk = tile + rt.y + 6 * fb2 - rt.x;
 #pragma unroll
                         for (int i = 0; i < 6; ++i)
 #pragma unroll
-                            for (int j = 0; j < 6; ++j) { lds_sub(blk + i * len + j, acc[6 * i + j]); acc[6 * i + j] = 0; }
+                            for (int j = 0; j < 6; ++j) { if (!(MS_FS_ABL & 8)) lds_sub(blk + i * len + j, acc[6 * i + j]); acc[6 * i + j] = 0; }
                     }
                     key = k2;
                 }
@@ -1297,7 +1479,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
             auto add_pair = [&](unsigned ab) {
                 const MS_LDS d2_t *za = (const MS_LDS d2_t *)(stage + (ab & 255u) * FS_ZD), *zb = (const MS_LDS d2_t *)(stage + (ab >> 8) * FS_ZD);
                 double A[FS_ZD], B[FS_ZD];
-#if MS_FS_ABL == 2          /* timing ablation (wrong results): no slab reads */
+#if (MS_FS_ABL & 3) == 2          /* timing ablation (wrong results): no slab reads */
 #pragma unroll
                 for (int q = 0; q < FS_ZD; ++q) { A[q] = acc[q] * 1e-300; B[q] = acc[q + 14] * 1e-300; }
                 (void)za; (void)zb;
@@ -1305,7 +1487,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 #pragma unroll
                 for (int q = 0; q < FS_ZD / 2; ++q) { const d2_t u = za[q], v = zb[q]; A[2 * q] = u.x; A[2 * q + 1] = u.y; B[2 * q] = v.x; B[2 * q + 1] = v.y; }
 #endif
-#if MS_FS_ABL == 1          /* timing ablation (wrong results): slab reads, no products */
+#if (MS_FS_ABL & 3) == 1          /* timing ablation (wrong results): slab reads, no products */
 #pragma unroll
                 for (int q = 0; q < FS_ZD; ++q) acc[q] += A[q] + B[q];
                 return;
@@ -1366,15 +1548,21 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda, double
 #ifdef MS_FS_PROF
             fsacc[5] += 1;
 #endif
-            rec = rec_n; cur = nxt; fmt = fmt_n; run0 = run0_n; run1 = run1_n; b = bn; b_hi = bn_hi;
+            rec = rec_n; cur = nxt; fmt = fmt_n; run0 = run0_n; run1 = run1_n; b = bn;
         }
         if (key >= 0) {
-            const int fa2 = key >> 16, fb2 = key & 0xFFFF, c0 = cs[fa2], len = 6 * fa2 + 6 - c0;
-            MS_LDS double *blk = tile + rowoff[fa2] + 6 * fb2 - c0;
+            const int fa2 = key >> 16, fb2 = key & 0xFFFF;
+            const i2_t rt = rowtab[fa2 - r0];
+            const int len = 6 * fa2 + 6 - rt.x;
+            MS_LDS double *blk = tile + rt.y + 6 * fb2 - rt.x;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) lds_sub(blk + i * len + j, acc[6 * i + j]);
+        }
+        if (ykey >= 0) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) lds_sub(tile + yoff + 6 * (ykey - r0) + r, yacc[r]);
         }
         FSP(4); FSP_FLUSH;
         const long long tp2 = clock64();
@@ -2530,7 +2718,8 @@ __global__ __launch_bounds__(256) void k_ba_pack_result(const BaProb *probs, int
     const int np7 = 7 * P.n_pose, nl3 = 3 * P.n_point, total = 16 + np7 + nl3 + (with_chi2 ? P.n_obs : 0);
     for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
         double v;
-        if (k < 16) v = P.stats[k];
+        if (k < 16) v = (k == 7 && P.team > 1 && P.flag[1] != 0) ? 1.0 : P.stats[k];      // [7] "a team barrier gave up": the marker itself, read here, after the launch (a lane of the solve kernel
+                                                                                           //     may have looked before a workgroup on another XCD had set it)
         else if (k < 16 + np7) v = P.pose[k - 16];
         else if (k < 16 + np7 + nl3) v = P.point[k - 16 - np7];
         else v = P.chi2_obs[k - 16 - np7 - nl3];
@@ -3520,6 +3709,7 @@ struct ms_ba {
     bool team_checked = true;          // the last team launch has been looked at (every problem's gave-up marker) and, if need be, repeated
     int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
     int team_fallbacks = 0;            // launches repeated with one workgroup per problem after a team barrier gave up
+    int solves = 0;                    // launches so far (ms_ba_copy_state refuses a source that has never been solved)
 };
 
 // Team launches of this process, per device: what is (or may still be) running, so that the workgroups of all concurrent team launches
@@ -3544,13 +3734,13 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     auto tm_lap = [&](int k) { if (tm_on) { const double t = tm_now(); tm_part[k] += t - tm_mark; tm_mark = t; } };
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; std::vector<double> puv; bool by_points = false; };
-    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
+    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, fo_lo; std::vector<double> fo_uvi; std::vector<int32_t> chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0;
                   bool one_pose = false; std::vector<int32_t> op_pose, op_o; std::vector<double> op_uvi; };
     std::vector<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
-    struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs,
+    struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
                  free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red; };
     std::vector<Off> off(n);
     std::vector<size_t> in_lo(n), in_hi(n);
@@ -3580,6 +3770,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         R.fobs.resize(R.fstart[R.np_free]);
         { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
         for (int o = 0; o < Q.n_obs; ++o) if (R.pidx[Q.obs_pose[o]] < 0) R.fobs.push_back(o);      // behind them: the observations of FIXED poses (fobs[fstart[np_free] .. n_obs))
+        R.fo_lo.resize(2 * (size_t)Q.n_obs); R.fo_uvi.assign(4 * (size_t)Q.n_obs, 0.0);          // the same order as a stream of values (linearise_stream)
+        for (int ii = 0; ii < Q.n_obs; ++ii) {
+            const int o = R.fobs[ii];
+            R.fo_lo[2 * (size_t)ii] = Q.obs_point[o]; R.fo_lo[2 * (size_t)ii + 1] = o;
+            R.fo_uvi[4 * (size_t)ii] = Q.obs_uv[2 * (size_t)o]; R.fo_uvi[4 * (size_t)ii + 1] = Q.obs_uv[2 * (size_t)o + 1]; R.fo_uvi[4 * (size_t)ii + 2] = Q.obs_info[o];
+        }
         {   // one free pose + at least one free point (stage 1 of localBundleAdjust): k_ba_one_pose reads the observations in point order, indices and values side by side
             bool any_free_point = false;
             for (int l = 0; l < Q.n_point && !any_free_point; ++l) any_free_point = !(Q.point_fixed && Q.point_fixed[l]);
@@ -3940,7 +4136,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.pose0 = bump(7 * Q.n_pose * D); O.point0 = bump(3 * Q.n_point * D);
         O.pidx = bump(4 * Q.n_pose); O.pfix = bump(Q.n_point);
         O.obs_pose = bump(4 * Q.n_obs); O.obs_point = bump(4 * Q.n_obs); O.obs_uv = bump(2 * Q.n_obs * D); O.obs_info = bump(Q.n_obs * D);
-        O.pt_start = bump(4 * (Q.n_point + 1)); O.pt_obs = bump(4 * Q.n_obs); O.fstart = bump(4 * (R.np_free + 1)); O.fobs = bump(4 * R.fobs.size());
+        O.pt_start = bump(4 * (Q.n_point + 1)); O.pt_obs = bump(4 * Q.n_obs); O.fstart = bump(4 * (R.np_free + 1)); O.fobs = bump(4 * R.fobs.size()); O.fo_lo = bump(4 * R.fo_lo.size()); O.fo_uvi = bump(8 * R.fo_uvi.size());
         O.free2pose = bump(4 * R.np_free); O.edge_i = bump(4 * Q.n_pose_edge); O.edge_j = bump(4 * Q.n_pose_edge);
         O.edge_meas = bump(7 * Q.n_pose_edge * D); O.edge_info = bump(36 * Q.n_pose_edge * D);
         O.chunk_items = bump(4 * R.chunk_items.size()); O.seg_start = bump(4 * R.seg_start.size()); O.seg_pair = bump(4 * R.seg_pair.size());
@@ -4009,7 +4205,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         up(O.pidx, R.pidx.data(), 4 * Q.n_pose); if (Q.point_fixed) up(O.pfix, Q.point_fixed, Q.n_point);
         up(O.obs_pose, Q.obs_pose, 4 * Q.n_obs); up(O.obs_point, Q.obs_point, 4 * Q.n_obs); up(O.obs_uv, Q.obs_uv, 2 * Q.n_obs * D); up(O.obs_info, Q.obs_info, Q.n_obs * D);
         up(O.pt_start, R.pt_start.data(), 4 * (Q.n_point + 1)); up(O.pt_obs, R.pt_obs.data(), 4 * Q.n_obs);
-        up(O.fstart, R.fstart.data(), 4 * (R.np_free + 1)); up(O.fobs, R.fobs.data(), 4 * R.fobs.size()); up(O.free2pose, R.free2pose.data(), 4 * R.np_free);
+        up(O.fstart, R.fstart.data(), 4 * (R.np_free + 1)); up(O.fobs, R.fobs.data(), 4 * R.fobs.size()); up(O.fo_lo, R.fo_lo.data(), 4 * R.fo_lo.size()); up(O.fo_uvi, R.fo_uvi.data(), 8 * R.fo_uvi.size()); up(O.free2pose, R.free2pose.data(), 4 * R.np_free);
         up(O.chunk_items, R.chunk_items.data(), 4 * R.chunk_items.size()); up(O.seg_start, R.seg_start.data(), 4 * R.seg_start.size()); up(O.seg_pair, R.seg_pair.data(), 4 * R.seg_pair.size());
         up(O.env16, R.env16.data(), 4 * R.env16.size());
         up(O.act_start, R.act_start.data(), 4 * R.act_start.size()); up(O.act_blk, R.act_blk.data(), 4 * R.act_blk.size());
@@ -4036,7 +4232,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.point = PTR(double, point); H.point_bk = PTR(double, point_bk); H.point0 = PTR(double, point0);
         H.pidx = PTR(int32_t, pidx); H.point_fixed = Q.point_fixed ? PTR(uint8_t, pfix) : nullptr;
         H.obs_pose = PTR(int32_t, obs_pose); H.obs_point = PTR(int32_t, obs_point); H.obs_uv = PTR(double, obs_uv); H.obs_info = PTR(double, obs_info);
-        H.pt_start = PTR(int32_t, pt_start); H.pt_obs = PTR(int32_t, pt_obs); H.fstart = PTR(int32_t, fstart); H.fobs = PTR(int32_t, fobs); H.free2pose = PTR(int32_t, free2pose);
+        H.pt_start = PTR(int32_t, pt_start); H.pt_obs = PTR(int32_t, pt_obs); H.fstart = PTR(int32_t, fstart); H.fobs = PTR(int32_t, fobs); H.fo_lo = PTR(int32_t, fo_lo); H.fo_uvi = PTR(double, fo_uvi); H.free2pose = PTR(int32_t, free2pose);
         H.edge_i = PTR(int32_t, edge_i); H.edge_j = PTR(int32_t, edge_j); H.edge_meas = PTR(double, edge_meas); H.edge_info = PTR(double, edge_info);
         H.Hpp = PTR(double, Hpp); H.S = PTR(double, S); H.bp = PTR(double, bp); H.dp = PTR(double, dp); H.y = PTR(double, y);
         H.Hll = PTR(double, Hll); H.bl = PTR(double, bl); H.Hinv = PTR(double, Hinv); H.Hpl = PTR(double, Hpl); H.dl = PTR(double, dl);
@@ -4097,17 +4293,18 @@ void ms_ba_destroy(ms_ba *B) {
     }
     if (B->d_arena) {                                               // back to the context's cache; when that is full the smallest block goes
         ms_ctx *c = B->ctx;
-        int slot = -1;
+        int slot = -1, small = 0;
         for (int i = 0; i < 4; ++i) if (!c->ba_cache[i].p) { slot = i; break; }
-        if (slot < 0) {
-            int small = 0;
-            for (int i = 1; i < 4; ++i) if (c->ba_cache[i].bytes < c->ba_cache[small].bytes) small = i;
-            if (c->ba_cache[small].bytes < B->arena_bytes) { (void)hipFree(c->ba_cache[small].p); c->ba_cache[small] = {}; slot = small; }
-        }
+        for (int i = 1; i < 4; ++i) if (c->ba_cache[i].bytes < c->ba_cache[small].bytes) small = i;
+        const bool evict = slot < 0 && c->ba_cache[small].bytes < B->arena_bytes;      // full: the new block replaces the smallest one if it is larger
         size_t kept = 0;
-        for (int i = 0; i < 4; ++i) if (i != slot) kept += c->ba_cache[i].bytes;
-        if (slot >= 0 && kept + B->arena_bytes <= kBaCacheMaxBytes) { c->ba_cache[slot].p = B->d_arena; c->ba_cache[slot].bytes = B->arena_bytes; }
-        else (void)hipFree(B->d_arena);                            // over the cap (a global-BA sized block): not kept
+        for (int i = 0; i < 4; ++i) if (!(evict && i == small)) kept += c->ba_cache[i].bytes;
+        // the cap is tested BEFORE anything is evicted: a block that will not be kept anyway (a global-BA sized arena) must not cost the cache a warm local-BA block
+        // (hipFree synchronises the whole device, and the next per-keyframe create would have to hipMalloc again)
+        if ((slot >= 0 || evict) && kept + B->arena_bytes <= kBaCacheMaxBytes) {
+            if (evict) { (void)hipFree(c->ba_cache[small].p); slot = small; }
+            c->ba_cache[slot].p = B->d_arena; c->ba_cache[slot].bytes = B->arena_bytes;
+        } else (void)hipFree(B->d_arena);
     }
     delete B;
 }
@@ -4136,7 +4333,7 @@ int ms_ba_solve(ms_ba *B) {
     if (B->pose_only && B->team <= 1 && !std::getenv("MS_BA_NO_POSE_KERNEL")) {      // (an explicit team request keeps the general kernel: tests compare the two)
         hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), 0, c->stream, B->d_probs);
         MS_KERNEL_CHECK(c, "k_ba_pose_only");
-        B->launched_team = 1; B->team_checked = true; B->last_one_pose = false;
+        B->launched_team = 1; B->team_checked = true; B->last_one_pose = false; ++B->solves;
         return MS_OK;
     }
     int most_obs = 0, most_points = 0, most_poses = 0;
@@ -4228,6 +4425,7 @@ int ms_ba_solve(ms_ba *B) {
     }
     B->launched_team = team;
     B->team_checked = team == 1;
+    ++B->solves;
     return MS_OK;
 }
 
@@ -4252,6 +4450,23 @@ static int ba_relaunch_single(ms_ba *B) {
     return MS_OK;
 }
 
+// The last launch was a team launch nobody has looked at yet: did a barrier give up anywhere in it?  The markers are collected by a kernel of their own AFTER the launch
+// (a marker stored by a workgroup on another XCD is only certain to be visible once its kernel has ended -- also for a single problem, whose in-kernel stats[7] is
+// read by one lane of the first workgroup while the others may still be storing), and a launch with one set is repeated with one workgroup per problem before
+// anything of it is handed on -- to the caller (ms_ba_download) or to another handle (ms_ba_copy_state).
+static int ba_team_verdict(ms_ba *B) {
+    if (B->team_checked) return MS_OK;
+    ms_ctx *c = B->ctx;
+    int any = 0;
+    hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
+    MS_KERNEL_CHECK(c, "k_ba_collect_gave_up");
+    MS_HIP(c, hipMemcpyAsync(&any, B->host[0].flag + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MS_HIP(c, hipStreamSynchronize(c->stream));
+    if (any) MS_TRY_BA(ba_relaunch_single(B));
+    B->team_checked = true;
+    return MS_OK;
+}
+
 int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_per_obs, ms_ba_result *res) {
     MsRange range("ms_ba_download");
     if (!B || i < 0 || i >= B->n) return MS_ERR_INVALID;
@@ -4262,17 +4477,7 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
     // A team barrier that gave up anywhere in the batch voids the whole launch (the workgroups of one launch share the chip): before the FIRST
     // problem of a team launch is handed out, every problem's marker is looked at and the batch is solved again without teams if one is set --
     // never after some results have already been returned.
-    if (!B->team_checked) {
-        int any = 0;
-        if (B->n > 1) {
-            hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
-            MS_KERNEL_CHECK(c, "k_ba_collect_gave_up");
-            MS_HIP(c, hipMemcpyAsync(&any, B->host[0].flag + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            MS_HIP(c, hipStreamSynchronize(c->stream));
-            if (any) MS_TRY_BA(ba_relaunch_single(B));
-            B->team_checked = true;
-        }                                                   // (a single problem's marker arrives with its results below)
-    }
+    if (B->n > 1) MS_TRY_BA(ba_team_verdict(B));          // (a single problem's marker arrives with its results below: no extra round trip)
     // everything the caller asked for in ONE device-to-host copy (status, poses, points, per-observation chi2 packed side by side by a small kernel, into the
     // context's pinned staging block): four blocking copies were 0.09 ms of a 2.3 ms window
     const bool want_chi2 = chi2_per_obs && H.n_obs;
@@ -4287,7 +4492,7 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
         MS_HIP(c, hipMemcpyAsync(c->pinned, scr, n_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         MS_HIP(c, hipStreamSynchronize(c->stream));
         st = static_cast<const double *>(c->pinned);
-        if (B->team_checked || st[7] == 0) break;            // a team barrier gave up (n = 1: its own marker): solve again without a team, then fetch again
+        if (B->team_checked || st[7] == 0) break;            // a team barrier gave up: solve again without a team, then fetch again
         MS_TRY_BA(ba_relaunch_single(B));
     }
     B->team_checked = true;
@@ -4316,6 +4521,9 @@ int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src
         }
     }
     MS_HIP(c, hipSetDevice(c->device));
+    if (src->solves == 0) return ms_fail(c, MS_ERR_INVALID, "ms_ba_copy_state: the source handle has never been solved");
+    // a source whose last launch ran on teams is looked at first (and repeated without teams if a barrier gave up): nothing of a void launch becomes anybody's initial state
+    MS_TRY_BA(ba_team_verdict(const_cast<ms_ba *>(src)));
     int32_t *d_extra = nullptr;
     if (need_extra) {
         void *scr = nullptr;

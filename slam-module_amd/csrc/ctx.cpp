@@ -3,6 +3,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <dirent.h>
+#include <unistd.h>
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
@@ -73,10 +75,29 @@ int ms_set_trace_ranges(int on) {
 void ms_trace_range_push(const char *name) { ms_range_push(name ? name : ""); }
 void ms_trace_range_pop(void) { ms_range_pop(); }
 
+// Is the ROCm runtime of this process up?  Its first act is to open the kernel driver's device node, so a descriptor on /dev/kfd says so -- whoever initialised
+// it (this library, torch, a profiler's preloaded tool), and without making a HIP call that would initialise it as a side effect.
+static bool gpu_runtime_is_up() {
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool up = false;
+    char link[64], target[64];
+    while (const dirent *e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        std::snprintf(link, sizeof(link), "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(link, target, sizeof(target) - 1);
+        if (n == 8 && std::memcmp(target, "/dev/kfd", 8) == 0) { up = true; break; }
+    }
+    closedir(d);
+    return up;
+}
+
 int ms_prepare_process(int concurrent_contexts) {
     if (concurrent_contexts < 1) return MS_ERR_INVALID;
+    if (std::getenv("GPU_MAX_HW_QUEUES")) return MS_OK;              // the caller's own setting wins (and was there when the runtime came up, if it has)
+    if (gpu_runtime_is_up()) return MS_ERR_TOO_LATE;                 // the variable has been read: setting it now would only pretend
     const int q = std::max(4, std::min(concurrent_contexts, 16));
-    return setenv("GPU_MAX_HW_QUEUES", std::to_string(q).c_str(), 0 /* keep the caller's own setting */) == 0 ? MS_OK : MS_ERR_INVALID;
+    return setenv("GPU_MAX_HW_QUEUES", std::to_string(q).c_str(), 0) == 0 ? MS_OK : MS_ERR_INVALID;
 }
 
 int ms_ctx_create(int device, ms_ctx **out) {

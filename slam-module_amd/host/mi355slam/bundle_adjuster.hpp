@@ -8,8 +8,9 @@
 #include <cmath>
 #include <cstdio>
 #include <functional>
-#include <map>
+#include <array>
 #include <set>
+#include <stdexcept>
 #include "common.hpp"
 
 namespace mi355slam {
@@ -22,37 +23,42 @@ constexpr float CHI2_THRESHOLD = 5.991f;                                     // 
 // by the mapper (mapper.cpp:392, :431).  The reference prints through the parent project's log_info; here the table goes to `sink`.
 class BaStats {
 public:
-    enum class Ba { NONE, POSE, NEIGHBOR, LOCAL, GLOBAL, LAST };
-    explicit BaStats(bool enabled, std::function<void(const char *)> sink = {}) : enabled(enabled), sink(std::move(sink)) {
-        if (!enabled) return;
-        for (int i = 0; i < last; ++i) { bas.emplace(static_cast<Ba>(i), 0); totalBas.emplace(static_cast<Ba>(i), 0); }
-    }
-    void update(Ba ba) { if (enabled) ++bas.at(ba); }
+    enum class Ba { NONE, POSE, NEIGHBOR, LOCAL, GLOBAL, LAST };             // the interface the reference's call sites use (ba_stats.hpp:11-19)
+    explicit BaStats(bool enabled, std::function<void(const char *)> sink = {}) : on_(enabled), sink_(std::move(sink)) {}
+    void update(Ba kind) { if (on_) ++frame_[slot(kind)]; }
+    // end of a frame: a frame in which nothing ran counts as "none"; prints the table the reference prints (kind, this frame, since the start) and clears the frame's counters
     void finishFrame() {
-        if (!enabled) return;
-        int count = 0;
-        for (int i = 0; i < last; ++i) { const Ba t = static_cast<Ba>(i); totalBas.at(t) += bas.at(t); count += bas.at(t); }
-        if (count == 0) { bas.at(Ba::NONE) += 1; totalBas.at(Ba::NONE) += 1; }
-        static const char *names[6] = {"none     ", "pose     ", "neighbor ", "local    ", "global   ", "TOTAL    "};
-        char line[96];
-        emit(""); emit("TYPE   \tNUM\tTOTAL");
-        int sum = 0, totalSum = 0;
-        for (int i = 0; i < last; ++i) {
-            const Ba t = static_cast<Ba>(i);
-            sum += bas.at(t); totalSum += totalBas.at(t);
-            std::snprintf(line, sizeof(line), "%s\t%d\t%d", names[i], bas.at(t), totalBas.at(t)); emit(line);
+        if (!on_) return;
+        bool ran = false;
+        for (int n : frame_) ran = ran || n != 0;
+        if (!ran) frame_[slot(Ba::NONE)] = 1;
+        Row total_row{};
+        print("", nullptr);
+        print("TYPE   \tNUM\tTOTAL", nullptr);
+        for (size_t k = 0; k < kKinds; ++k) {
+            total_[k] += frame_[k];
+            const Row r{frame_[k], total_[k]};
+            total_row.frame += r.frame; total_row.total += r.total;
+            print(kLabel[k], &r);
         }
-        std::snprintf(line, sizeof(line), "%s\t%d\t%d", names[last], sum, totalSum); emit(line);
-        for (int i = 0; i < last; ++i) bas.at(static_cast<Ba>(i)) = 0;
+        print(kLabel[kKinds], &total_row);
+        frame_.fill(0);
     }
-    int frameCount(Ba ba) const { return enabled ? bas.at(ba) : 0; }           // counters since the last finishFrame (not in the reference: for tests)
-    int totalCount(Ba ba) const { return enabled ? totalBas.at(ba) : 0; }
+    int frameCount(Ba kind) const { return on_ ? frame_[slot(kind)] : 0; }      // counters since the last finishFrame (not in the reference: for tests)
+    int totalCount(Ba kind) const { return on_ ? total_[slot(kind)] : 0; }
 private:
-    void emit(const char *l) const { if (sink) sink(l); else std::printf("%s\n", l); }
-    static constexpr int last = static_cast<int>(Ba::LAST);
-    bool enabled;
-    std::function<void(const char *)> sink;
-    std::map<Ba, int> bas, totalBas;
+    struct Row { int frame, total; };
+    static constexpr size_t kKinds = static_cast<size_t>(Ba::LAST);
+    static constexpr const char *kLabel[kKinds + 1] = {"none     ", "pose     ", "neighbor ", "local    ", "global   ", "TOTAL    "};
+    static size_t slot(Ba kind) { return static_cast<size_t>(kind) < kKinds ? static_cast<size_t>(kind) : throw std::out_of_range("BaStats: not a kind of bundle adjustment"); }
+    void print(const char *label, const Row *r) const {
+        char line[96];
+        if (r) std::snprintf(line, sizeof(line), "%s\t%d\t%d", label, r->frame, r->total); else std::snprintf(line, sizeof(line), "%s", label);
+        if (sink_) sink_(line); else std::printf("%s\n", line);
+    }
+    bool on_;
+    std::function<void(const char *)> sink_;
+    std::array<int, kKinds> frame_{}, total_{};
 };
 
 // WorkspaceBA (bundle_adjuster.hpp:16-25): the id sets localBundleAdjust refills on every call (bundle_adjuster.cpp:158-223; MpId / KfId

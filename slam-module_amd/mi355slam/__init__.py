@@ -62,11 +62,24 @@ def lib():
     return _lib
 
 
+MS_ERR_TOO_LATE = -6
+
+
 def prepare_process(concurrent_contexts):
-    """ms_prepare_process: before the first HIP call of the process -- as many hardware queues as there will be contexts driving the GPU at once."""
+    """ms_prepare_process: before the first HIP call of the process -- as many hardware queues as there will be contexts driving the GPU at once.
+    Returns True when the setting is in place (made now, or already in the environment), False when the GPU runtime of this process was up already
+    (MS_ERR_TOO_LATE: e.g. under a profiler whose preloaded tool initialises the GPU first) -- the process then runs on the queues it has."""
     rc = lib().ms_prepare_process(int(concurrent_contexts))
+    if rc == MS_ERR_TOO_LATE:
+        return False
     if rc != 0:
         raise MsError("ms_prepare_process(%d) failed with %d" % (concurrent_contexts, rc))
+    return True
+
+
+def hw_queues():
+    """The number of hardware queues the HIP runtime of this process maps its streams onto (GPU_MAX_HW_QUEUES at the time it came up; its default is 4)."""
+    return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
 
 
 def _vp(x):

@@ -144,3 +144,30 @@ print(libc.getenv(b"GPU_MAX_HW_QUEUES").decode())
     run = lambda n, e: subprocess.run([sys.executable, "-c", code, str(n)], env=e, capture_output=True, text=True, check=True).stdout.strip()
     assert run(8, env) == "8" and run(2, env) == "4" and run(40, env) == "16"
     assert run(8, dict(env, GPU_MAX_HW_QUEUES="2")) == "2"               # the caller's own setting wins
+
+
+def test_prepare_process_says_when_it_is_too_late():
+    """Once the GPU runtime of the process is up (the driver's device node is open) the variable has been read: MS_ERR_TOO_LATE, environment untouched.
+    The child opens /dev/kfd itself, as the runtime would (no HIP call): where the node exists (the GPU box) the late half is checked, elsewhere the early half."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(%r, "slam-module_amd"))
+import mi355slam
+L = mi355slam.lib()
+fd = None
+try:
+    fd = os.open("/dev/kfd", os.O_RDWR)
+except OSError:
+    pass
+rc = L.ms_prepare_process(8)
+libc = C.CDLL("libc.so.6"); libc.getenv.restype = C.c_char_p
+print(rc, libc.getenv(b"GPU_MAX_HW_QUEUES") is not None, fd is not None)
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    rc, was_set, opened = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    if opened == "True":
+        assert int(rc) == mi355slam.MS_ERR_TOO_LATE and was_set == "False"
+    else:
+        assert int(rc) == 0 and was_set == "True"

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -77,7 +79,7 @@ def _long_launcher(*extra):
 
 def _ranks_of(launcher, wait_s=60):
     import time
-    import psutil
+    psutil = pytest.importorskip("psutil")      # (in this image's wheelhouse; not a dependency of the product)
     t_end = time.time() + wait_s
     while time.time() < t_end:
         kids = [c for c in psutil.Process(launcher.pid).children(recursive=True)]
@@ -88,7 +90,7 @@ def _ranks_of(launcher, wait_s=60):
 
 
 def _all_gone(procs, wait_s=40):
-    import psutil
+    psutil = pytest.importorskip("psutil")      # (in this image's wheelhouse; not a dependency of the product)
     gone, alive = psutil.wait_procs(procs, timeout=wait_s)
     return not alive
 

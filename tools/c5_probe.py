@@ -1,6 +1,7 @@
 """C5 on one GPU outside bench.py: N sequences (host thread + context each, bench.py's SequenceRunner) for F frames, a new-window BA every 5th frame.
    python tools/c5_probe.py [n_seq] [frames] [ba_team] [no_ba]
-Under `rocprofv3 --kernel-trace -d DIR -- python3 tools/c5_probe.py ...` the kernel trace shows how the sequences' kernels overlap (tools/c5_trace_summary.py)."""
+Under `GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace -d DIR -- python3 tools/c5_probe.py ...` the kernel trace shows how the sequences' kernels overlap (tools/c5_trace_summary.py);
+the variable has to be in the environment there: the profiler's preloaded tool initialises the GPU before ms_prepare_process can set it."""
 import os, sys, threading, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "slam-module_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
