@@ -85,7 +85,7 @@ struct BaProb {
     const int32_t *pt_start, *pt_obs;        // observations grouped by point
     const int32_t *fstart, *fobs;            // observations grouped by FREE pose index; behind them, fobs[fstart[np_free] .. n_obs), those of the fixed poses
     const int32_t *free2pose;                // free index -> pose vertex
-    const int32_t *fo_lo;                    // the observations in fobs order as a stream: (point, observation) ...
+    const int32_t *fo_lo;                    // the observations in fobs order as a stream: (point, observation | point fixed << 31, pose vertex, free pose index or -1) ...
     const double *fo_uvi;                    // ... and (u, v, information, 0): coalesced loads at addresses that need no index (linearise_stream)
     // Schur work list: pairs (a,b) of observations of one free point with free poses fb <= fa, sorted by (fa,fb),
     // cut into chunks of CH items of the same pose pair (padding = -1); segments = runs of chunks of one pair
@@ -525,19 +525,18 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
     const int tid = threadIdx.x, lane = tid & 63;
     MS_LDS double *ptab = (MS_LDS double *)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MS_LDS double *)lds_v);      // [n_point][H 6 | b 3]
     const int n_point = P.n_point, np = P.np_free, n6 = P.n6, n_obs = P.n_obs;
-    const MS_GLOBAL i2_t *rec = (const MS_GLOBAL i2_t *)uglobal(P.fo_lo);
+    const MS_GLOBAL i4_t *rec = (const MS_GLOBAL i4_t *)uglobal(P.fo_lo);
     const MS_GLOBAL d2_t *uvi = (const MS_GLOBAL d2_t *)uglobal(P.fo_uvi);
     const MS_GLOBAL double *gpoint = uglobal(P.point), *gpose = uglobal(P.pose);
-    const MS_GLOBAL uint8_t *pfix = P.point_fixed ? uglobal(P.point_fixed) : nullptr;
-    const MS_GLOBAL int32_t *fstart = uglobal(P.fstart), *free2pose = uglobal(P.free2pose), *obs_pose = uglobal(P.obs_pose);
+    const MS_GLOBAL int32_t *fstart = uglobal(P.fstart), *free2pose = uglobal(P.free2pose);
     MS_GLOBAL double *Hpp = (MS_GLOBAL double *)uglobal(P.Hpp), *bp = (MS_GLOBAL double *)uglobal(P.bp);
     const double hub = P.huber;
     for (int i = tid; i < 9 * n_point; i += NT) ptab[i] = 0;
     if (tid == 0) s_ls_next = 0;
     __syncthreads();
     // one observation: residual, both Jacobians, Huber weight; the point's Hll / bl terms into the LDS table, the pose's terms into A / g when it is free
-    auto point_terms = [&](int l, const double (&Jl)[6], const double (&e)[2], double wi) {
-        if (pfix && pfix[l]) return;
+    auto point_terms = [&](int l, bool fixed, const double (&Jl)[6], const double (&e)[2], double wi) {
+        if (fixed) return;
         double Jw[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) Jw[a] = wi * Jl[a];
@@ -555,10 +554,10 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
     };
     // the observations of FIXED poses (the tail of the stream): point terms only, a thread each
     for (int ix = fstart[np] + tid; ix < n_obs; ix += NT) {
-        const i2_t r = rec[ix];
+        const i4_t r = rec[ix];
         const d2_t uvv = uvi[2 * ix];
         const double info = ((const MS_GLOBAL double *)uvi)[4 * ix + 2];
-        const int pi = obs_pose[r.y];
+        const int pi = r.z;
         double pose[7], X[3], e[2], Jp[12], Jl[6];
 #pragma unroll
         for (int q = 0; q < 7; ++q) pose[q] = gpose[7 * pi + q];
@@ -568,7 +567,7 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
         proj_edge<true>(pose, X, uv, e, Jp, Jl);
         double rho, w;
         huber(info * (e[0] * e[0] + e[1] * e[1]), hub, rho, w);
-        point_terms(r.x, Jl, e, w * info);
+        point_terms(r.x, r.y < 0, Jl, e, w * info);
     }
     // the free poses, a wave each (handed out from a counter: the waves of a SIMD do not run at the same speed)
     for (;;) {
@@ -588,10 +587,11 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
         for (int a = 0; a < 6; ++a) g[a] = 0;
         // every load of the pipeline is unconditional (indices clamped into the pose's run): a load inside a branch makes the compiler's wait for ANY later value a
         // wait for everything in flight, and the pipeline collapses into one round trip per step
-        struct Ob { int l; double u, v, info; };
+        struct Ob { int l; bool fixed; double u, v, info; };
         auto fetch_ob = [&](int ii, Ob &d) {
             const int ic = min(ii, hi - 1);
-            d.l = rec[ic].x;
+            const i2_t r = ((const MS_GLOBAL i2_t *)rec)[2 * ic];
+            d.l = r.x; d.fixed = r.y < 0;
             const d2_t a = uvi[2 * ic];
             d.u = a.x; d.v = a.y; d.info = ((const MS_GLOBAL double *)uvi)[4 * ic + 2];
         };
@@ -626,7 +626,7 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
 #pragma unroll
                         for (int b = a; b < 6; ++b) { A[k] = fma(Jw[a], Jp[b], fma(Jw[6 + a], Jp[6 + b], A[k])); ++k; }
                     }
-                    point_terms(o0.l, Jl, e, wi);
+                    point_terms(o0.l, o0.fixed, Jl, e, wi);
                 }
                 o0 = o1; o1 = o2; o2 = o3;
                 X0[0] = X1[0]; X0[1] = X1[1]; X0[2] = X1[2];
@@ -652,6 +652,148 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
         const int l = i / 9, c = i - 9 * l;
         if (c < 6) Hll[6 * l + c] = ptab[i]; else bl[3 * l + c - 6] = ptab[i];
     }
+}
+
+// robust chi2 of the current state for a window on ONE workgroup, from the same streams (eval_chi2 below walks observation -> pose / point index chains, per-lane
+// gathers two dependent round trips deep): a flat loop over the stream, records two steps and point positions one step ahead, the poses in an LDS table
+__device__ __noinline__ double eval_stream(const BaProb &P_, double *lds_v, double *s_red_v, bool store, double extra, double *extra_sum) {
+    const BaProb &P = *(const BaProb *)uglobal(&P_);
+    const int tid = threadIdx.x;
+    MS_LDS double *ptab = (MS_LDS double *)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MS_LDS double *)lds_v);      // [7 n_pose]
+    const int n_obs = P.n_obs, n_pose = P.n_pose;
+    const MS_GLOBAL i4_t *rec = (const MS_GLOBAL i4_t *)uglobal(P.fo_lo);
+    const MS_GLOBAL d2_t *uvi = (const MS_GLOBAL d2_t *)uglobal(P.fo_uvi);
+    const MS_GLOBAL double *gpoint = uglobal(P.point), *gpose = uglobal(P.pose);
+    MS_GLOBAL double *chi2_obs = (MS_GLOBAL double *)uglobal(P.chi2_obs);
+    const double hub = P.huber;
+    for (int i = tid; i < 7 * n_pose; i += NT) ptab[i] = gpose[i];
+    __syncthreads();
+    double acc = 0;
+    struct Ob { int l, o, pi; double u, v, info; };
+    auto fetch_ob = [&](int ix, Ob &d) {
+        const int ic = min(ix, n_obs - 1);
+        const i4_t r = rec[ic];
+        d.l = r.x; d.o = r.y & 0x7fffffff; d.pi = r.z;
+        const d2_t a = uvi[2 * ic];
+        d.u = a.x; d.v = a.y; d.info = ((const MS_GLOBAL double *)uvi)[4 * ic + 2];
+    };
+    if (n_obs > 0) {
+        Ob o0, o1, o2;
+        double X0[3], X1[3];
+        int ix = tid;
+        fetch_ob(ix, o0); fetch_ob(ix + NT, o1); fetch_ob(ix + 2 * NT, o2);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) X0[q] = gpoint[3 * o0.l + q];
+        for (; ix - tid < n_obs; ix += NT) {
+            Ob o3;
+            fetch_ob(ix + 3 * NT, o3);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) X1[q] = gpoint[3 * o1.l + q];
+            if (ix < n_obs) {
+                double pose[7], e[2];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) pose[q] = ptab[7 * o0.pi + q];
+                const double uv[2] = {o0.u, o0.v};
+                proj_edge<false>(pose, X0, uv, e, nullptr, nullptr);
+                const double chi2 = o0.info * (e[0] * e[0] + e[1] * e[1]);
+                double r, w;
+                huber(chi2, hub, r, w);
+                if (store) chi2_obs[o0.o] = chi2;
+                acc += r;
+            }
+            o0 = o1; o1 = o2; o2 = o3;
+            X0[0] = X1[0]; X0[1] = X1[1]; X0[2] = X1[2];
+        }
+    }
+    for (int k = tid; k < P.n_edge; k += NT) {
+        double e[6];
+        pose_edge(P.pose + 7 * (size_t)P.edge_i[k], P.pose + 7 * (size_t)P.edge_j[k], P.edge_meas + 7 * (size_t)k, e, nullptr, nullptr, false);
+        const double *W = P.edge_info + 36 * (size_t)k;
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) acc += e[i] * W[6 * i + j] * e[j];
+    }
+    const double total = block_sum(acc, s_red_v);
+    if (extra_sum) *extra_sum = block_sum(extra, s_red_v);
+    return total;
+}
+
+// dl = (Hll + lambda I)^-1 (bl - sum_a W_a^T dp_a) for a window on ONE workgroup, from the streams: every observation of a free pose takes its W^T dp off an LDS
+// table that starts as bl (three ds_add_f64 per observation), then a thread per point solves the 3 x 3 system.  (point_backsub_fused's thread-per-point loop walks
+// pt_obs -> observation -> pose index chains and fetches dp per observation.)
+__device__ __noinline__ void backsub_stream(const BaProb &P_, double lambda_, double *lds_v) {
+    const BaProb &P = *(const BaProb *)uglobal(&P_);
+    const double lambda = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(lambda_)), __builtin_amdgcn_readfirstlane(__double2loint(lambda_)));
+    const int tid = threadIdx.x;
+    const int n_point = P.n_point, n_pose = P.n_pose, np = P.np_free;
+    MS_LDS double *rtab = (MS_LDS double *)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MS_LDS double *)lds_v);      // [3 n_point] | [7 n_pose] | [6 np_free]
+    MS_LDS double *ptab = rtab + 3 * n_point, *xtab = ptab + 7 * n_pose;
+    const MS_GLOBAL i4_t *rec = (const MS_GLOBAL i4_t *)uglobal(P.fo_lo);
+    const MS_GLOBAL d2_t *uvi = (const MS_GLOBAL d2_t *)uglobal(P.fo_uvi);
+    const MS_GLOBAL double *gpoint = uglobal(P.point), *gpose = uglobal(P.pose), *gbl = uglobal(P.bl), *gdp = uglobal(P.dp), *gHll = uglobal(P.Hll);
+    const MS_GLOBAL uint8_t *pfix = P.point_fixed ? uglobal(P.point_fixed) : nullptr;
+    MS_GLOBAL double *gdl = (MS_GLOBAL double *)uglobal(P.dl);
+    const double hub = P.huber;
+    const int n_free_obs = P.fstart[np];                           // the stream's observations of free poses come first
+    for (int i = tid; i < 3 * n_point; i += NT) rtab[i] = gbl[i];
+    for (int i = tid; i < 7 * n_pose; i += NT) ptab[i] = gpose[i];
+    for (int i = tid; i < 6 * np; i += NT) xtab[i] = gdp[i];
+    __syncthreads();
+    struct Ob { int l, pi, fa; double u, v, info; };                // fa < 0: the observation's point is fixed (nothing to move)
+    auto fetch_ob = [&](int ix, Ob &d) {
+        const int ic = min(ix, n_free_obs - 1);
+        const i4_t r = rec[ic];
+        d.l = r.x; d.pi = r.z; d.fa = r.y < 0 ? -1 : r.w;
+        const d2_t a = uvi[2 * ic];
+        d.u = a.x; d.v = a.y; d.info = ((const MS_GLOBAL double *)uvi)[4 * ic + 2];
+    };
+    if (n_free_obs > 0) {
+        Ob o0, o1, o2;
+        double X0[3], X1[3];
+        int ix = tid;
+        fetch_ob(ix, o0); fetch_ob(ix + NT, o1); fetch_ob(ix + 2 * NT, o2);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) X0[q] = gpoint[3 * o0.l + q];
+        for (; ix - tid < n_free_obs; ix += NT) {
+            Ob o3;
+            fetch_ob(ix + 3 * NT, o3);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) X1[q] = gpoint[3 * o1.l + q];
+            if (ix < n_free_obs && o0.fa >= 0) {
+                double pose[7], x[6], e[2], Jp[12], Jl[6];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) pose[q] = ptab[7 * o0.pi + q];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) x[q] = xtab[6 * o0.fa + q];
+                const double uv[2] = {o0.u, o0.v};
+                proj_edge<true>(pose, X0, uv, e, Jp, Jl);
+                double rho, w;
+                huber(o0.info * (e[0] * e[0] + e[1] * e[1]), hub, rho, w);
+                const double wi = w * o0.info;
+                double s0 = 0, s1 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { s0 = fma(Jp[a], x[a], s0); s1 = fma(Jp[6 + a], x[a], s1); }
+                s0 *= wi; s1 *= wi;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lds_addd(rtab + 3 * o0.l + c, -fma(Jl[c], s0, Jl[3 + c] * s1));
+            }
+            o0 = o1; o1 = o2; o2 = o3;
+            X0[0] = X1[0]; X0[1] = X1[1]; X0[2] = X1[2];
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < n_point; l += NT) {
+        if (pfix && pfix[l]) { gdl[3 * l] = 0; gdl[3 * l + 1] = 0; gdl[3 * l + 2] = 0; continue; }
+        const double r0 = rtab[3 * l], r1 = rtab[3 * l + 1], r2 = rtab[3 * l + 2];
+        const MS_GLOBAL d2_t *h2 = (const MS_GLOBAL d2_t *)(gHll + 6 * l);
+        const d2_t ha = h2[0], hb = h2[1], hc = h2[2];
+        const double a = ha.x + lambda, b = ha.y, c = hb.x, d = hb.y + lambda, e2 = hc.x, f = hc.y + lambda;
+        const double A = d * f - e2 * e2, B = c * e2 - b * f, C = b * e2 - c * d;
+        const double id = 1.0 / (a * A + b * B + c * C);
+        const double h0 = A * id, h1 = B * id, h2v = C * id, h3 = (a * f - c * c) * id, h4 = (b * c - a * e2) * id, h5 = (a * d - b * b) * id;
+        gdl[3 * l] = h0 * r0 + h1 * r1 + h2v * r2;
+        gdl[3 * l + 1] = h1 * r0 + h3 * r1 + h4 * r2;
+        gdl[3 * l + 2] = h2v * r0 + h4 * r1 + h5 * r2;
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------- linearisation
@@ -1340,34 +1482,30 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
         auto next_batch = [&]() -> int {                           // the wave's next batch, or pb1 when the pass has none left for it (the same value in every lane)
             int got = pb1;
             if (lane == 0) {
+                // next | end << 32 moves with ONE 64-bit atomic add per attempt (the owner adds 1 to the front, a thief takes 1 off the end): both halves come back from
+                // the same instant, so "was there a batch left" needs no compare-and-swap loop; attempts on an empty range overshoot it, which only keeps it empty
                 for (int k = 0; k < NW && got == pb1; ++k) {
                     const int v = (wave + (k & 1) * (NW / 2) + (k >> 1)) % NW;      // itself first, then its SIMD partner, then the others
-                    unsigned long long old = s_fs_q[v];
-                    for (;;) {
-                        const unsigned h = (unsigned)old, t = (unsigned)(old >> 32);
-                        if (h >= t) break;
-                        const unsigned long long nw = k == 0 ? ((unsigned long long)t << 32 | (h + 1)) : ((unsigned long long)(t - 1) << 32 | h);
-                        const unsigned long long seen = atomicCAS(&s_fs_q[v], old, nw);
-                        if (seen == old) { got = (int)(k == 0 ? h : t - 1); break; }
-                        old = seen;
-                    }
+                    const unsigned long long old = atomicAdd(&s_fs_q[v], k == 0 ? 1ull : 0xFFFFFFFF00000000ull);
+                    const int h = (int)(unsigned)old, t = (int)(unsigned)(old >> 32);
+                    if (h < t) got = k == 0 ? h : t - 1;
                 }
             }
             return __builtin_amdgcn_readfirstlane(got);
         };
         struct LaneData { double X[3], bl[3], H[6], uv[2], info; };
         const MS_GLOBAL double *hsrc = uglobal(pre ? P.Hinv : P.Hll), *blsrc = uglobal(pre ? P.dl : P.bl);
+        // (every load of the chain is unconditional -- padding slots name point 0 / pose 0, a batch index past the pass is clamped into it: a load inside a branch
+        //  turns the compiler's wait for any LATER value into a wait for everything in flight, and the chain collapses into one round trip per batch)
         auto fetch_lane = [&](const i4_t &r, int slot, LaneData &d) {
-            if (r.x >= 0) {
-                const int l = r.z;
+            const int l = r.z;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { d.X[q] = gpoint[3 * l + q]; d.bl[q] = blsrc[3 * l + q]; }
-                const MS_GLOBAL d2_t *h2 = (const MS_GLOBAL d2_t *)(hsrc + 6 * l);
+            for (int q = 0; q < 3; ++q) { d.X[q] = gpoint[3 * l + q]; d.bl[q] = blsrc[3 * l + q]; }
+            const MS_GLOBAL d2_t *h2 = (const MS_GLOBAL d2_t *)(hsrc + 6 * l);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { const d2_t u = h2[q]; d.H[2 * q] = u.x; d.H[2 * q + 1] = u.y; }
-                const d2_t a = puv[2 * slot];
-                d.uv[0] = a.x; d.uv[1] = a.y; d.info = ((const MS_GLOBAL double *)puv)[4 * slot + 2];       // (8 bytes, not the whole 16: a destination register nobody reads is re-used at once, and that write waits for the load)
-            }
+            for (int q = 0; q < 3; ++q) { const d2_t u = h2[q]; d.H[2 * q] = u.x; d.H[2 * q + 1] = u.y; }
+            const d2_t a = puv[2 * slot];
+            d.uv[0] = a.x; d.uv[1] = a.y; d.info = ((const MS_GLOBAL double *)puv)[4 * slot + 2];       // (8 bytes, not the whole 16: a destination register nobody reads is re-used at once, and that write waits for the load)
         };
         int b = next_batch();
         i4_t rec = {-1, 0, 0, -1};
@@ -1385,23 +1523,22 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
             const int pi = rec.y, fa = rec.w;
             const int bn = next_batch();
             double pose[7];
-            if (act) {
-                if constexpr (pose_lds) {
+            if constexpr (pose_lds) {
 #pragma unroll
-                    for (int q = 0; q < 7; ++q) pose[q] = ptab[7 * pi + q];
-                } else {
+                for (int q = 0; q < 7; ++q) pose[q] = ptab[7 * pi + q];
+            } else {
 #pragma unroll
-                    for (int q = 0; q < 7; ++q) pose[q] = gpose[7 * pi + q];
-                }
+                for (int q = 0; q < 7; ++q) pose[q] = gpose[7 * pi + q];
             }
             const int run_lo = run0 >> 3, run_hi = fmt ? run_lo : (run1 >> 3);
-            u4_t pk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (run_lo + lane < run_hi) pk = chunks[run_lo + lane];
-            unsigned single = 0xFFFFu;
-            if (fmt > 0 && lane < fmt) single = pairs16[run0 + lane];
-            i4_t rec_n = {-1, 0, 0, -1};
-            int fmt_n = 0, run0_n = 0, run1_n = 0;
-            if (bn < pb1) { rec_n = pobs4[FS_OB * bn + lane]; fmt_n = b_fmt[bn]; run0_n = b_run[bn]; run1_n = b_run[bn + 1]; }
+            u4_t pk = chunks[min(run_lo + lane, max(run_hi - 1, run_lo))];
+            if (!(run_lo + lane < run_hi)) pk = u4_t{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            unsigned single = pairs16[run0 + min(lane, max(fmt - 1, 0))];
+            if (!(fmt > 0 && lane < fmt)) single = 0xFFFFu;
+            const int bc = min(bn, pb1 - 1);
+            i4_t rec_n = pobs4[FS_OB * bc + lane];
+            const int fmt_n = b_fmt[bc], run0_n = b_run[bc], run1_n = b_run[bc + 1];
+            if (bn >= pb1) rec_n.x = -1;
             FSP_WAIT_VM; FSP(1);
             const double (&X)[3] = cur.X, (&blv)[3] = cur.bl, (&H)[6] = cur.H, (&uv)[2] = cur.uv;
             const double info = cur.info;
@@ -1457,8 +1594,8 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             FSP(2);
-            LaneData nxt = {};
-            if (bn < pb1) fetch_lane(rec_n, FS_OB * bn + lane, nxt);
+            LaneData nxt;
+            fetch_lane(rec_n, FS_OB * bc + lane, nxt);
             FSP(6);
             auto take_block = [&](unsigned ab) {                      // the block of pair ab becomes the lane's current one: the old sum goes out first
                 const int k2 = (meta[ab & 255u] << 16) | meta[ab >> 8];
@@ -1530,8 +1667,8 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
             if (single != 0xFFFFu) { take_block(single); add_pair(single); }
             FSP(7);
             for (int run = run_lo + lane; run < run_hi; run += 64) {
-                u4_t nx = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                if (run + 64 < run_hi) nx = chunks[run + 64];
+                u4_t nx = chunks[min(run + 64, run_hi - 1)];
+                if (!(run + 64 < run_hi)) nx = u4_t{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 take_block(pk.x & 0xFFFFu);
 #pragma unroll 1
                 for (int k = 0; k < 8; ++k) {
@@ -2701,7 +2838,8 @@ __device__ bool solve_step(const BaProb &P, double lambda, double *lds, long lon
     const bool ok = s_sound != 0;
     __syncthreads();
     if (!ok) return false;
-    if (fused) point_backsub_fused(P, lambda, lds); else point_backsub(P);
+    if (fused && P.team == 1 && P.fo_lo != nullptr && 3 * (size_t)P.n_point + 7 * (size_t)P.n_pose + 6 * (size_t)P.np_free <= kLdsBytes / 8 && !MS_LIN_NO_STREAM) backsub_stream(P, lambda, lds);
+    else if (fused) point_backsub_fused(P, lambda, lds); else point_backsub(P);
     cyc[4] += clock64() - t0;
     return true;
 }
@@ -2769,7 +2907,9 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
     int it = 0, trials = 0, stop = 0;
     long long cyc[7] = {0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
-    const double chi2_init = eval_chi2(P, s_red, false, seq);
+    // one workgroup per window, streams built, pose table in LDS: the streamed phases (eval_stream, backsub_stream)
+    const bool ev_stream = P.team == 1 && P.fo_lo != nullptr && 7 * (size_t)P.n_pose <= kLdsBytes / 8 && !MS_LIN_NO_STREAM;
+    const double chi2_init = ev_stream ? eval_stream(P, lds, s_red, false, 0.0, nullptr) : eval_chi2(P, s_red, false, seq);
     double chi2_carried = chi2_init;
     for (it = 0; it < P.max_iters; ++it) {
         long long tt = clock64();
@@ -2815,7 +2955,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
                 for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
                 for (int i = gt; i < 3 * P.n_point; i += GT) sc += P.dl[i] * (lambda * P.dl[i] + P.bl[i]);
             }
-            temp = ok2 ? eval_chi2(P, s_red, false, seq, sc, &scale) : DBL_MAX;     // chi2 of the new state and the gain denominator behind one team barrier
+            temp = ok2 ? (ev_stream ? eval_stream(P, lds, s_red, false, sc, &scale) : eval_chi2(P, s_red, false, seq, sc, &scale)) : DBL_MAX;     // chi2 of the new state and the gain denominator behind one team barrier
             scale += 1e-3;
             cyc[0] += clock64() - tt;
             rho = (current - temp) / scale;
@@ -2835,7 +2975,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
         } while (rho < 0 && qmax < 10);
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) { stop = 1; ++it; break; }
     }
-    const double chi2_final = eval_chi2(P, s_red, true, seq);
+    const double chi2_final = ev_stream ? eval_stream(P, lds, s_red, true, 0.0, nullptr) : eval_chi2(P, s_red, true, seq);
     if (gt == 0) {
         const bool hung = P.team > 1 && P.flag[1] != 0;        // a team barrier gave up: the result is not to be trusted
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = hung ? NAN : chi2_final;
@@ -3770,10 +3910,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         R.fobs.resize(R.fstart[R.np_free]);
         { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
         for (int o = 0; o < Q.n_obs; ++o) if (R.pidx[Q.obs_pose[o]] < 0) R.fobs.push_back(o);      // behind them: the observations of FIXED poses (fobs[fstart[np_free] .. n_obs))
-        R.fo_lo.resize(2 * (size_t)Q.n_obs); R.fo_uvi.assign(4 * (size_t)Q.n_obs, 0.0);          // the same order as a stream of values (linearise_stream)
+        R.fo_lo.resize(4 * (size_t)Q.n_obs); R.fo_uvi.assign(4 * (size_t)Q.n_obs, 0.0);          // the same order as a stream of values (linearise_stream)
         for (int ii = 0; ii < Q.n_obs; ++ii) {
             const int o = R.fobs[ii];
-            R.fo_lo[2 * (size_t)ii] = Q.obs_point[o]; R.fo_lo[2 * (size_t)ii + 1] = o;
+            R.fo_lo[4 * (size_t)ii] = Q.obs_point[o]; R.fo_lo[4 * (size_t)ii + 1] = o | ((Q.point_fixed && Q.point_fixed[Q.obs_point[o]]) ? (int32_t)0x80000000 : 0); R.fo_lo[4 * (size_t)ii + 2] = Q.obs_pose[o]; R.fo_lo[4 * (size_t)ii + 3] = R.pidx[Q.obs_pose[o]];
             R.fo_uvi[4 * (size_t)ii] = Q.obs_uv[2 * (size_t)o]; R.fo_uvi[4 * (size_t)ii + 1] = Q.obs_uv[2 * (size_t)o + 1]; R.fo_uvi[4 * (size_t)ii + 2] = Q.obs_info[o];
         }
         {   // one free pose + at least one free point (stage 1 of localBundleAdjust): k_ba_one_pose reads the observations in point order, indices and values side by side
