@@ -116,7 +116,8 @@ struct BaProb {
     const int32_t *cw_slot;                  // [nblk] LDS slot (row and column index in the tile grid) of 16-row block b while it is active
     const int32_t *cw_act_start, *cw_act;    // per panel p: the other active blocks (block | slot << 16), ascending
     const int32_t *cw_load_start, *cw_load;  // per panel p: tiles that enter the window (bi | si << 16, bj | sj << 16)
-    const int32_t *fs_cs;                    // [np_free] first scalar column of pose row fa held in the tile (<= 6 * first coupled pose, 16-aligned envelope)
+    const int32_t *fs_cs;                    // [np_free] first scalar column of pose row fa held in the tile (6 * first coupled pose), then [np_free] the first column of the row in which Hpp
+                                             // can be non-zero (6 * first pose coupled by a pose-pose edge; Hpp is the diagonal blocks and the edges' blocks, lower triangle only)
     // one free pose + free points (k_ba_one_pose): the observations sorted by point -- pose vertex, original index, (u, v, information) --, the per-point
     // records [28][n_point] and the team's partial sums [2][team][64]; null for every other shape
     const int32_t *op_pose, *op_o;
@@ -817,6 +818,16 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
 #ifdef MS_LIN_PROF
     const long long lin_t0 = clock64();
 #endif
+    if (P.fused) {
+        // Hpp is its diagonal blocks and the lower blocks of the pose-pose edges: only those row pieces are written below, read by the Schur pass and cleared here (the
+        // rest of the n6 x n6 array keeps the zeros it was created with; round 3 cleared all of it, 720 KB per window and iteration)
+        const MS_GLOBAL int32_t *hcs = uglobal(P.fs_cs) + P.np_free;
+        MS_GLOBAL double *Hz = (MS_GLOBAL double *)uglobal(P.Hpp);
+        for (int it = gt >> 4; it < n6; it += GT / 16) {
+            const int f = it / 6;
+            for (int c = hcs[f] + (gt & 15); c < 6 * f + 6; c += 16) Hz[(size_t)it * n6 + c] = 0;
+        }
+    } else
     for (size_t i = gt; i < (size_t)n6 * n6; i += GT) P.Hpp[i] = 0;
     for (int i = gt; i < n6; i += GT) P.bp[i] = 0;
     LINP(0);
@@ -1083,7 +1094,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
                 if (lane < 6) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += Js[6 * r2 + lane] * slab[108 + r2]; atomicAdd(&P.bp[6 * fs + lane], v); }
                 for (int tidx = 0; tidx < 2; ++tidx) {
                     const int ft = tidx ? fj : fi;
-                    if (ft < 0) continue;
+                    if (ft < 0 || ft > fs) continue;                           // (lower block triangle only: nothing reads the blocks above the diagonal)
                     const MS_LDS double *Jt = slab + 36 * tidx;
                     if (lane < 36) {
                         double v = 0;
@@ -1137,7 +1148,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             for (int it = tid; it < kn * 24; it += NT) {
                 const int ke = it / 24, r = it - 24 * ke, st = r / 6, b3 = r - 6 * st, k = k0 + ke;
                 const int fs = P.pidx[(st >> 1) ? P.edge_j[k] : P.edge_i[k]], ft = P.pidx[(st & 1) ? P.edge_j[k] : P.edge_i[k]];
-                if (fs < 0 || ft < 0) continue;
+                if (fs < 0 || ft < 0 || ft > fs) continue;                    // (lower block triangle only: nothing reads the blocks above the diagonal)
                 const MS_LDS double *d = eb + ke * ES, *Js = d + 6 + 36 * (st >> 1), *Jt = d + 6 + 36 * (st & 1);
                 const double *W = P.edge_info + 36 * (size_t)k;
                 double m[6];
@@ -1337,7 +1348,7 @@ constexpr int kFsStageDoubles = NW * FS_OB * FS_ZD;              // slabs of the
 constexpr int kFsMetaDoubles = NW * FS_OB / 2;                   // free-pose index per lane: 2,048 B
 constexpr int kFsPoseTab = 128;                                  // poses (all vertices, free or fixed) whose 7 doubles each sit in LDS during the pass; a window with more reads them from memory
 constexpr int kFsRowTab = 320;                                   // pose rows a pass can hold at most (a row needs 42 doubles of the tile at least): their (first column, tile offset) pairs sit in LDS
-constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles - 7 * kFsPoseTab - kFsRowTab;     // 10,560 doubles = 82.5 KB
+constexpr int kFsTileDoubles = (int)(kLdsBytes / 8) - kFsStageDoubles - kFsMetaDoubles - 7 * kFsPoseTab - 2 * kFsRowTab;     // 10,240 doubles = 80 KB
 static_assert(kFsTileDoubles / 42 <= kFsRowTab, "row table too small for the tile");
 
 __device__ __forceinline__ void lds_sub(MS_LDS double *p, double v) {
@@ -1387,10 +1398,10 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
     MS_LDS double *stage = (MS_LDS double *)lds_ + (size_t)wave * (FS_OB * FS_ZD);
     MS_LDS int32_t *meta = (MS_LDS int32_t *)((MS_LDS double *)lds_ + kFsStageDoubles) + wave * FS_OB;
     MS_LDS double *ptab = (MS_LDS double *)lds_ + kFsStageDoubles + kFsMetaDoubles;          // [7 n_pose] when n_pose <= kFsPoseTab
-    MS_LDS i2_t *rowtab = (MS_LDS i2_t *)(ptab + 7 * kFsPoseTab);                          // [r1 - r0] of the pass: first scalar column of the row's envelope part, offset of the row in the tile
-    MS_LDS double *tile = (MS_LDS double *)rowtab + kFsRowTab;
+    MS_LDS i4_t *rowtab = (MS_LDS i4_t *)(ptab + 7 * kFsPoseTab);                          // [r1 - r0] of the pass: first scalar column of the row's envelope part, offset of the row in the tile, first column of its part of Hpp
+    MS_LDS double *tile = (MS_LDS double *)rowtab + 2 * kFsRowTab;
     constexpr bool pose_lds = POSE_LDS;
-    const MS_GLOBAL int32_t *cs = uglobal(P.fs_cs), *env = uglobal(P.env16);
+    const MS_GLOBAL int32_t *cs = uglobal(P.fs_cs), *hcs = cs + P.np_free, *env = uglobal(P.env16);
     const MS_GLOBAL i4_t *pobs4 = (const MS_GLOBAL i4_t *)uglobal(F.pobs);
     const MS_GLOBAL u4_t *chunks = (const MS_GLOBAL u4_t *)uglobal(F.pairs);
     const MS_GLOBAL uint16_t *pairs16 = uglobal(F.pairs);
@@ -1409,8 +1420,9 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
             const int fa = row / 6, c0 = cs[fa], len = 6 * fa + 6 - c0, z0 = env[row >> 4] & ~15;
             const MS_GLOBAL double *hrow = Hpp + (size_t)row * n + c0;
             MS_GLOBAL double *srow = Sg + (size_t)row * n;
-            for (int c = z0 + lane; c < c0; c += 64) srow[c] = 0.0;
-            for (int c = lane; c < len; c += 64) srow[c0 + c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
+            const int h0 = hcs[fa];
+            for (int c = z0 + lane; c < h0; c += 64) srow[c] = 0.0;             // (Hpp holds nothing left of the row's first edge block: not read)
+            for (int c = h0 - c0 + lane; c < len; c += 64) srow[c0 + c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
         }
         for (int i = gt; i < n; i += GT) P.y[i] = P.bp[i];
         team_sync(P);
@@ -1440,23 +1452,30 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
         const int r0 = F.row0[pass], r1 = F.row1[pass], yoff = F.yoff[2 * pass];
         const MS_GLOBAL int32_t *rowoff = (const MS_GLOBAL int32_t *)F.rowoff + F.yoff[2 * pass + 1] - r0;      // rowoff[fa] for the rows of this pass
         const long long tp0 = clock64();
-        // tile <- Hpp (the envelope part of the pass's rows) + lambda I, rhs segment <- bp (or zeros: a pass that owns points only collects their sums)
-        for (int rr = wave; rr < 6 * (r1 - r0); rr += NW) {
-            const int fa = r0 + rr / 6, i = rr - 6 * (rr / 6), row = 6 * fa + i, c0 = cs[fa], len = 6 * fa + 6 - c0;
-            MS_LDS double *trow = tile + rowoff[fa] + i * len;
-            const MS_GLOBAL double *hrow = Hpp + (size_t)row * n + c0;
-            if (by_pts) { for (int c = lane; c < len; c += 64) trow[c] = 0.0; }
-            else for (int c = lane; c < len; c += 64) trow[c] = hrow[c] + (c0 + c == row ? lambda : 0.0);
-        }
-        for (int i = tid; i < 6 * (r1 - r0); i += NT) tile[yoff + i] = by_pts ? 0.0 : P.bp[6 * r0 + i];
+        // tile <- Hpp (the envelope part of the pass's rows) + lambda I, rhs segment <- bp (or zeros: a pass that owns points only collects their sums).  Hpp is its diagonal
+        // blocks and the blocks of the pose-pose edges, nothing else: the tile is cleared in LDS and only the row pieces from the first such block on are fetched, 16 lanes
+        // per row (round 3 copied the whole envelope row by row, each row two dependent round trips: 47 k cycles per pass for 80 KB that are mostly zeros)
+        const int tile_used = yoff + 6 * (r1 - r0);
+        for (int i = tid; i < tile_used; i += NT) tile[i] = (i >= yoff && !by_pts) ? P.bp[6 * r0 + i - yoff] : 0.0;
         if (pose_lds) for (int i = tid; i < 7 * P.n_pose; i += NT) ptab[i] = gpose[i];
-        for (int i = tid; i < r1 - r0; i += NT) rowtab[i] = i2_t{cs[r0 + i], rowoff[r0 + i]};
+        for (int i = tid; i < r1 - r0; i += NT) rowtab[i] = i4_t{cs[r0 + i], rowoff[r0 + i], hcs[r0 + i], 0};
         if (tid < NW) {                                            // the pass's batches in NW contiguous ranges
             const int pbs = F.batch_start[pass], nbp = F.batch_start[pass + 1] - pbs;
             const unsigned lo = (unsigned)(pbs + (long long)nbp * tid / NW), hi = (unsigned)(pbs + (long long)nbp * (tid + 1) / NW);
             s_fs_q[tid] = (unsigned long long)lo | ((unsigned long long)hi << 32);
         }
         __syncthreads();
+        if (!by_pts) {
+            for (int it = tid >> 4; it < 6 * (r1 - r0); it += NT / 16) {
+                const int f = it / 6, i = it - 6 * f, fa = r0 + f, row = 6 * fa + i;
+                const i4_t rt = rowtab[f];
+                const int len = 6 * fa + 6 - rt.x;
+                MS_LDS double *trow = tile + rt.y + i * len - rt.x;                 // trow[c]: scalar column c of the row
+                const MS_GLOBAL double *hrow = Hpp + (size_t)row * n;
+                for (int c = rt.z + (tid & 15); c < 6 * fa + 6; c += 16) trow[c] = hrow[c] + (c == row ? lambda : 0.0);
+            }
+            __syncthreads();
+        }
         const long long tp1 = clock64();
         cyc[5] += tp1 - tp0;
         // Every wave owns a contiguous range of the pass's batches: the pass's points are sorted by their set of poses, so consecutive batches mostly repeat the
@@ -1602,7 +1621,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
                 if (k2 != key) {
                     if (key >= 0) {
                         const int fa2 = key >> 16, fb2 = key & 0xFFFF;
-                        const i2_t rt = rowtab[fa2 - r0];
+                        const i4_t rt = rowtab[fa2 - r0];
                         const int len = 6 * fa2 + 6 - rt.x;
                         MS_LDS double *blk = tile + rt.y + 6 * fb2 - rt.x;
 #pragma unroll
@@ -1689,7 +1708,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
         }
         if (key >= 0) {
             const int fa2 = key >> 16, fb2 = key & 0xFFFF;
-            const i2_t rt = rowtab[fa2 - r0];
+            const i4_t rt = rowtab[fa2 - r0];
             const int len = 6 * fa2 + 6 - rt.x;
             MS_LDS double *blk = tile + rt.y + 6 * fb2 - rt.x;
 #pragma unroll
@@ -3933,10 +3952,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
         // envelope of the reduced camera matrix at pose level: the first free pose each free pose is coupled with (a shared point or a
         // pose-pose edge), and the free observations of every free point, sorted by free pose (flat arrays: the fused Schur pass is built from them)
-        std::vector<int> first(R.np_free);
+        std::vector<int> first(R.np_free), hfirst(R.np_free);          // hfirst: the first free pose a pose is coupled with by a pose-pose EDGE (Hpp has nothing left of that block)
         std::vector<int32_t> fp_start(Q.n_point + 1, 0), fp_f, fp_o;
         {
-            for (int f = 0; f < R.np_free; ++f) first[f] = f;
+            for (int f = 0; f < R.np_free; ++f) first[f] = hfirst[f] = f;
             int max_k = 0;
             for (int l = 0; l < Q.n_point; ++l) {
                 fp_start[l] = (int32_t)fp_f.size();
@@ -3956,7 +3975,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             fp_start[Q.n_point] = (int32_t)fp_f.size();
             for (int k = 0; k < Q.n_pose_edge; ++k) {
                 const int fi = R.pidx[Q.edge_i[k]], fj = R.pidx[Q.edge_j[k]];
-                if (fi >= 0 && fj >= 0) first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj));
+                if (fi >= 0 && fj >= 0) { first[std::max(fi, fj)] = std::min(first[std::max(fi, fj)], std::min(fi, fj)); hfirst[std::max(fi, fj)] = std::min(hfirst[std::max(fi, fj)], std::min(fi, fj)); }
             }
             bool ok = R.np_free > 0 && max_k <= FS_OB;
             for (int f = 0; f < R.np_free && ok; ++f) if (36 * (f - first[f] + 1) + 6 > kFsTileDoubles) ok = false;
@@ -4029,8 +4048,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         tm_lap(2);
         {   // fused Schur pass (schur_fused): pose rows -> passes whose envelope part fits the LDS tile, points -> batches of <= 64 observations
             const int np = R.np_free;
-            R.fs_cs.resize(np);
-            for (int f = 0; f < np; ++f) R.fs_cs[f] = 6 * first[f];
+            R.fs_cs.resize(2 * (size_t)np);                              // [np] first column of the row's envelope part, then [np] first column of the row's part of Hpp
+            for (int f = 0; f < np; ++f) { R.fs_cs[f] = 6 * first[f]; R.fs_cs[(size_t)np + f] = 6 * hfirst[f]; }
             const bool ok = R.fused;
             std::vector<int32_t> stamp(Q.n_point, -1);
             std::vector<std::pair<uint64_t, int32_t>> pts;               // (signature of the point's pose set, point)
