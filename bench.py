@@ -59,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--c5-keyframe-every", type=int, default=5)
     ap.add_argument("--c5-team", type=int, default=0, help="workgroups per BA window in the C5 leg (0 = by the number of sequences sharing the GPU)")
     ap.add_argument("--c5-native", action="store_true", help="drive the C5 sequences from C++ threads (tools/c5_native.cpp) instead of Python threads")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="every rank binds device 0 and the ranks' few numbers travel over gloo (RCCL refuses two ranks on one device): the N > 1 code -- launcher, one "
+                         "context / slab set per rank, ms_prepare_process per rank, the C5 partition s mod N, the ending -- on a one-GPU lease.  Not a scaling measurement")
+    ap.add_argument("--only-c5", action="store_true", help="C5 leg only (after a 2-step headline)")
     ap.add_argument("--plumbing", action="store_true", help="no GPU work: launcher / rendezvous / aggregation only (gloo)")
     ap.add_argument("--plumbing-fail-rank", type=int, default=-1, help="with --plumbing: this rank exits with code 3 (launcher test)")
     ap.add_argument("--master-port", type=int, default=0)
@@ -66,6 +70,10 @@ def parse_args(argv=None):
     a = ap.parse_args(argv)
     if a.only_headline:
         a.no_ba = a.no_c5 = a.no_extra = a.no_cpu_baseline = a.no_greedy = True
+    a.no_ba_leg = a.no_ba
+    if a.only_c5:
+        a.no_ba_leg = a.no_extra = a.no_cpu_baseline = a.no_greedy = True      # (the C5 leg keeps its own new-window BA every 5th frame)
+        a.steps, a.warmup = min(a.steps, 2), min(a.warmup, 1)
     return a
 
 
@@ -245,23 +253,28 @@ class Rank:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.deferred = []                             # rank 0: (object, fn) -- CPU baselines, run after every GPU leg and after the process group is gone
-        self.device = "cpu" if args.plumbing else "cuda"
+        self.share = bool(getattr(args, "ranks_share_gpu", False))
+        self.gpu = 0 if self.share else self.local_rank       # the device this rank's context, tensors and streams live on
+        self.device = "cpu" if (args.plumbing or self.share) else "cuda"      # where the few numbers the ranks exchange live (gloo: host tensors)
         if not args.plumbing:
             # before the first HIP call of this rank (and AFTER `import torch`, whose own copy of the HIP runtime has to be the one the process loads): one
             # hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's default of 4 queues a sequence's 10 us
             # front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
             import mi355slam
             self.queues_prepared = mi355slam.prepare_process(N_SEQ)   # False: the runtime was up already (a profiler's preloaded tool): the queues are what the environment said then
-            self.hw_queues = mi355slam.hw_queues() if (self.queues_prepared or "GPU_MAX_HW_QUEUES" in os.environ) else 4
-            torch.cuda.set_device(self.local_rank)
+            self.hw_queues = mi355slam.hw_queues()
+            torch.cuda.set_device(self.gpu)
+        self.backend = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if args.plumbing:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            import datetime
+            if args.plumbing or self.share:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=3))
             else:
-                import datetime
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank),
                                         timeout=datetime.timedelta(minutes=3))
+            self.backend = dist.get_backend()
+            self.group_world = dist.get_world_size()          # what the collective library itself says (RCCL on the real N-GPU run)
 
     def barrier(self):
         if not self.args.plumbing:
@@ -288,9 +301,18 @@ class Rank:
 
 
 def base_line(R, args, value, dt):
-    return {"metric": "frames/sec ORB extract+match (720p)", "value": round(value, 1), "unit": "frames/s", "n_gpus": R.world,
+    line = {"metric": "frames/sec ORB extract+match (720p)", "value": round(value, 1), "unit": "frames/s", "n_gpus": R.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+    if R.world > 1:
+        line["collective_backend"] = getattr(R, "backend", None)             # "nccl" = RCCL over xGMI on the N-GPU run
+        line["rccl_world"] = getattr(R, "group_world", None) if getattr(R, "backend", None) == "nccl" else None
+        line["collective_world"] = getattr(R, "group_world", None)
+    if getattr(R, "share", False):
+        line["ranks_share_gpu"] = True
+        line["note"] = ("--ranks-share-gpu: %d ranks (processes) on ONE device, their totals over gloo -- a run of the N > 1 code on a one-GPU lease, not a scaling "
+                        "measurement: `value` is the sum of ranks that share the same CUs") % R.world
+    return line
 
 
 def run_plumbing(R, args):
@@ -435,7 +457,7 @@ def run_gpu(R, args):
     import mi355slam                                # after torch: both must share one HIP runtime
     import synth
     torch = R.torch
-    ctx = mi355slam.Context(R.local_rank)
+    ctx = mi355slam.Context(R.gpu)
     if args.only_ba:
         args.no_cpu_baseline = True
         res = bench_ba(R, ctx, args)
@@ -549,7 +571,7 @@ def run_gpu(R, args):
         hl.close()
         leg("c3", lambda: bench_c3(R, ctx, args))
     # ---- secondary metric: local-BA solves/s (BASELINE config C4), 256 distinct windows per launch, device-resident ----
-    if not args.no_ba:
+    if not args.no_ba_leg:
         leg("local_ba", lambda: bench_ba(R, ctx, args))
     # ---- the reference's own matchers M1 / M2 on a new keyframe's pairs ----
     if not args.no_greedy:
@@ -682,7 +704,7 @@ def pcie_overlapped(R, host, cap, steps):
     """The same PCIe-inclusive step as two half-batches on two contexts (two host threads, two streams)."""
     start = threading.Event()
     half = BATCH // 2
-    workers = [PcieWorker(R.local_rank, host[i * half:(i + 1) * half], steps, start) for i in range(2)]
+    workers = [PcieWorker(R.gpu, host[i * half:(i + 1) * half], steps, start) for i in range(2)]
     for wk in workers:
         wk.start()
     for wk in workers:
@@ -1137,7 +1159,7 @@ def bench_c5(R, args):
         warr = (mi355slam.BaProblemC * max(len(structs), 1))(*structs)
         fptr = (C.c_void_p * len(mine))(*[f.ctypes.data for f in seq_frames])
         native.c5_prepare.restype = C.c_void_p
-        job = native.c5_prepare(R.local_rank, len(mine), F, FD, W, H, fptr, warr, len(structs), args.c5_keyframe_every, LEVELS, C.c_float(SCALE), MAX_KPTS, FAST_THR, C.c_float(LOWE_RATIO))
+        job = native.c5_prepare(R.gpu, len(mine), F, FD, W, H, fptr, warr, len(structs), args.c5_keyframe_every, LEVELS, C.c_float(SCALE), MAX_KPTS, FAST_THR, C.c_float(LOWE_RATIO))
         if not job:
             raise RuntimeError("c5_prepare failed")
         secs, seq_s = C.c_double(), (C.c_double * len(mine))()
@@ -1154,7 +1176,7 @@ def bench_c5(R, args):
         del keep
     else:
         start = threading.Event()
-        runners = [SequenceRunner(R.local_rank, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start, n_total=F, ba_team=ba_team) for k, s in enumerate(mine)]
+        runners = [SequenceRunner(R.gpu, s, seq_frames[k], seq_windows[k], args.c5_keyframe_every, start, n_total=F, ba_team=ba_team) for k, s in enumerate(mine)]
         for r in runners:
             r.start()
         for r in runners:

@@ -78,8 +78,12 @@ def prepare_process(concurrent_contexts):
 
 
 def hw_queues():
-    """The number of hardware queues the HIP runtime of this process maps its streams onto (GPU_MAX_HW_QUEUES at the time it came up; its default is 4)."""
-    return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    """The number of hardware queues the HIP runtime of this process maps its streams onto (GPU_MAX_HW_QUEUES at the time it came up; its default is 4).
+    Read from the C environment: ms_prepare_process sets the variable with setenv(), which Python's os.environ snapshot does not see."""
+    libc = C.CDLL(None)
+    libc.getenv.restype = C.c_char_p
+    v = libc.getenv(b"GPU_MAX_HW_QUEUES")
+    return int(v) if v else 4
 
 
 def _vp(x):
