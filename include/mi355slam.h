@@ -454,8 +454,15 @@ int ms_ba_team_fallbacks(const ms_ba *ba);
 /* Event-query failures the team admission list has seen in this process (0 in a healthy run; see above). */
 int ms_ba_admission_errors(void);
 int ms_ba_debug_fail_team_barriers(ms_ba *ba, int on);
+/* Test hook: the first `first_trials` damped trials of the following solves count as rejected whatever their gain (state restored, lambda *= nu, nu *= 2): ten of them
+ * in one iteration drive g2o's Terminate path (OptimizationAlgorithmLevenberg, _maxTrialsAfterFailure = 10) deterministically.  General solver only. */
+int ms_ba_debug_force_reject(ms_ba *ba, int first_trials);
 /* Results of problem i (synchronises): poses [n_pose*7], points [n_point*3], per-observation chi2
- * (edge->chi2() of :378, for the outlier rule chi2 > 5.991).  Any output pointer may be NULL.  The status is read first: on
+ * (what the outlier rule chi2 > 5.991 of :376-388 reads).  They are evaluated at the state that is RETURNED, i.e. the last accepted one.  g2o's edge->chi2() is the
+ * error of the last computeActiveErrors(): when optimize() ends on rejected trials (Terminate after ten failures in a row, or a trial without gain) the vertices
+ * are restored but the edges keep the rejected trial's errors, and bundle_adjuster.cpp:378 reads those.  The two differ by the last rejected step -- after ten
+ * rejections lambda has grown by 2^55, so by about 2^-55 of a Gauss-Newton step; oracle/ba.c restates g2o's value under flag bit 1, and
+ * tests/test_gpu_ba.py::test_ten_rejected_trials_terminate_like_the_oracle holds the two against each other.  Any output pointer may be NULL.  The status is read first: on
  * MS_ERR_NUMERIC (non-finite state) none of the caller's arrays is written (res, when given, is filled). */
 int ms_ba_download(ms_ba *ba, int i, double *pose, double *point, double *chi2_per_obs, ms_ba_result *res);
 /* create + solve + download + destroy for one problem. */

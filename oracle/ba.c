@@ -390,7 +390,12 @@ static int solve_full(const mso_ba_problem *P, const normal_eq *N, double lambda
 }
 
 /* OptimizationAlgorithmLevenberg::solve wrapped in SparseOptimizer::optimize(max_iters) */
-int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int full_system) {
+/* flags: bit 0 = the un-marginalised system (what the reference solves, bundle_adjuster.cpp:269 commented out); bit 1 = per-observation chi2 as g2o's edge->chi2() would
+ * return it after optimize(): the errors of the LAST computeActiveErrors(), i.e. of the last trial even when that trial was rejected and the vertices restored
+ * (bundle_adjuster.cpp:376-379 reads exactly that; it differs from the accepted state only when the solve ends on rejected trials -- Terminate); bits 8..15 = test
+ * hook shared with the GPU solver: the first n damped trials count as rejected whatever their gain (drives the ten-rejections Terminate path deterministically) */
+int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int flags) {
+    const int full_system = flags & 1, stale_chi2 = (flags >> 1) & 1, force_reject = (flags >> 8) & 0xFF;
     normal_eq N;
     memset(&N, 0, sizeof(N));
     N.pidx = (int *)malloc(sizeof(int) * (size_t)(P->n_pose ? P->n_pose : 1));
@@ -405,6 +410,8 @@ int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int 
     N.Hpl = (double *)calloc(18 * (size_t)(P->n_obs ? P->n_obs : 1), sizeof(double));
     double *dp = (double *)malloc(sizeof(double) * (size_t)(n6 ? n6 : 1)), *dl = (double *)malloc(sizeof(double) * 3 * (size_t)(P->n_point ? P->n_point : 1));
     double *pose_bk = (double *)malloc(sizeof(double) * 7 * (size_t)(P->n_pose ? P->n_pose : 1)), *point_bk = (double *)malloc(sizeof(double) * 3 * (size_t)(P->n_point ? P->n_point : 1));
+    double *pose_tr = (double *)malloc(sizeof(double) * 7 * (size_t)(P->n_pose ? P->n_pose : 1)), *point_tr = (double *)malloc(sizeof(double) * 3 * (size_t)(P->n_point ? P->n_point : 1));      /* the state of the last trial (g2o's edges keep its errors) */
+    int have_trial = 0;
     double lambda = 0, ni = 2;
     int it = 0, trials_total = 0, stop = 0;
     st->chi2_init = robust_chi2(P, P->pose, P->point, NULL);
@@ -427,6 +434,7 @@ int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int 
                 for (int l = 0; l < P->n_point; ++l) if (N.lidx[l] >= 0) for (int a = 0; a < 3; ++a) P->point[3 * (size_t)l + a] += dl[3 * (size_t)l + a];
             }
             temp = ok2 ? robust_chi2(P, P->pose, P->point, NULL) : DBL_MAX;
+            if (ok2) { memcpy(pose_tr, P->pose, sizeof(double) * 7 * (size_t)P->n_pose); memcpy(point_tr, P->point, sizeof(double) * 3 * (size_t)P->n_point); have_trial = 1; }
             rho = current - temp;
             double scale = 0;                                       /* computeScale: sum x_j (lambda x_j + b_j) */
             if (ok2) {
@@ -435,6 +443,7 @@ int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int 
             }
             scale += 1e-3;
             rho /= scale;
+            if (trials_total < force_reject) rho = -1.0;
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);
@@ -452,6 +461,8 @@ int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int 
     }
     st->iters = it; st->lambda = lambda; st->trials_total = trials_total; st->stop_reason = stop;
     st->chi2_final = robust_chi2(P, P->pose, P->point, chi2_per_obs);
+    if (stale_chi2 && have_trial && chi2_per_obs) (void)robust_chi2(P, pose_tr, point_tr, chi2_per_obs);
+    free(pose_tr); free(point_tr);
     free(N.pidx); free(N.lidx); free(N.Hpp); free(N.bp); free(N.Hll); free(N.bl); free(N.Hpl); free(dp); free(dl); free(pose_bk); free(point_bk);
     return 0;
 }

@@ -180,7 +180,7 @@ typedef struct {
 typedef struct { int iters, trials_total, stop_reason; double lambda, chi2_init, chi2_final; } mso_ba_stats;
 
 /* full_system = 1 solves the undamped-ordering-free dense (poses+points) system, 0 the Schur complement. */
-int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int full_system);
+int mso_ba_solve(mso_ba_problem *P, double *chi2_per_obs, mso_ba_stats *st, int flags);      /* flags: see ba.c */
 void mso_se3_exp(const double *update6, double *pose7);
 void mso_se3_log(const double *pose7, double *out6);
 /* test hooks: residual + Jacobians of the two edge types */

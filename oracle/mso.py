@@ -348,8 +348,9 @@ class BaStats(C.Structure):
                 ("lambda_", C.c_double), ("chi2_init", C.c_double), ("chi2_final", C.c_double)]
 
 
-def ba_solve(prob, max_iters=10, full_system=False):
-    """prob: dict from tests/ba_synth.py (numpy arrays).  Returns dict(pose, point, chi2, stats)."""
+def ba_solve(prob, max_iters=10, full_system=False, g2o_stale_chi2=False, force_reject=0):
+    """prob: dict from tests/ba_synth.py (numpy arrays).  Returns dict(pose, point, chi2, stats).  g2o_stale_chi2: per-observation chi2 as g2o's edge->chi2() holds it
+    after optimize() (the last trial's errors, even of a rejected trial); force_reject: the first n trials count as rejected (test hook, also in the GPU solver)."""
     pose = np.ascontiguousarray(prob["pose"], np.float64).copy()
     point = np.ascontiguousarray(prob["point"], np.float64).copy()
     keep = dict(pf=np.ascontiguousarray(prob["pose_fixed"], np.uint8),
@@ -363,7 +364,7 @@ def ba_solve(prob, max_iters=10, full_system=False):
                   float(prob["huber_delta"]), _p(keep["ei"], i32p), _p(keep["ej"], i32p), _p(keep["em"], f64p), _p(keep["ew"], f64p), max_iters)
     chi2 = np.zeros(max(len(keep["op"]), 1), np.float64)
     st = BaStats()
-    rc = lib().mso_ba_solve(C.byref(P), _p(chi2, f64p), C.byref(st), int(full_system))
+    rc = lib().mso_ba_solve(C.byref(P), _p(chi2, f64p), C.byref(st), int(bool(full_system)) | (int(bool(g2o_stale_chi2)) << 1) | ((int(force_reject) & 0xFF) << 8))
     assert rc == 0
     return dict(pose=pose, point=point, chi2=chi2[:len(keep["op"])],
                 stats=dict(iters=st.iters, trials=st.trials_total, stop=st.stop_reason, lam=st.lambda_, chi2_init=st.chi2_init, chi2_final=st.chi2_final))

@@ -74,6 +74,7 @@ struct BaProb {
     int32_t n_pose, n_point, n_obs, n_edge, np_free, n6, max_iters;
     int32_t team;                            // workgroups that share this problem (1 = the whole solve in one workgroup)
     int32_t chol_team;                       // of these, the workgroups that share the distributed Cholesky (systems beyond kMaxFreePoses)
+    int32_t debug_reject;                    // test hook (ms_ba_debug_force_reject): the first n damped trials of k_ba_lm count as rejected
     double huber;
     // state
     double *pose, *pose_bk, *point, *point_bk;
@@ -2978,6 +2979,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
             scale += 1e-3;
             cyc[0] += clock64() - tt;
             rho = (current - temp) / scale;
+            if (trials < P.debug_reject) rho = -1.0;                // (test hook: drives the ten-rejections Terminate path)
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);
@@ -3218,6 +3220,7 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
             } else temp = DBL_MAX;
             const double scale = sc + 1e-3;
             rho = (current - temp) / scale;
+            if (trials < P.debug_reject) rho = -1.0;                // (test hook: drives the ten-rejections Terminate path)
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);
@@ -3802,6 +3805,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
             } else temp = DBL_MAX;
             const double scale = (ok2 ? s_sum[29] : 0.0) + 1e-3;
             rho = (current - temp) / scale;
+            if (trials < P.debug_reject) rho = -1.0;                // (test hook: drives the ten-rejections Terminate path)
             if (rho > 0 && isfinite(temp)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);
@@ -4416,7 +4420,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.Y = PTR(double, Y); H.zrow = PTR(double, zrow);
         H.dinv = PTR(double, dinv);
         H.panG = R.np_free > kMaxFreePoses ? PTR(double, panG) : nullptr;
-        H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1; H.chol_team = 1;
+        H.bar = PTR(uint32_t, bar); H.red = PTR(double, red); H.flag = PTR(int32_t, flag); H.team = 1; H.chol_team = 1; H.debug_reject = 0;
         H.op_pose = R.one_pose ? PTR(int32_t, op_pose) : nullptr; H.op_o = R.one_pose ? PTR(int32_t, op_o) : nullptr; H.op_uvi = R.one_pose ? PTR(double, op_uvi) : nullptr;
         H.op_rec = R.one_pose ? PTR(double, op_rec) : nullptr; H.op_red = R.one_pose ? PTR(double, op_red) : nullptr;
         if (p == 0) B->one_pose = R.one_pose; else B->one_pose = B->one_pose && R.one_pose;
@@ -4698,6 +4702,14 @@ int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src
 int ms_ba_team_fallbacks(const ms_ba *B) { return B ? B->team_fallbacks : MS_ERR_INVALID; }
 int ms_ba_admission_errors(void) { std::lock_guard<std::mutex> lk(g_team_mu); return g_team_query_errors; }
 int ms_ba_debug_fail_team_barriers(ms_ba *B, int on) { if (!B) return MS_ERR_INVALID; B->debug_fail_barriers = on ? 1 : 0; return MS_OK; }
+int ms_ba_debug_force_reject(ms_ba *B, int first_trials) {
+    if (!B || first_trials < 0 || first_trials > 255) return MS_ERR_INVALID;
+    if (B->pose_only || B->one_pose) return ms_fail(B->ctx, MS_ERR_INVALID, "ms_ba_debug_force_reject: only the general solver (k_ba_lm) has the hook");
+    for (auto &h : B->host) h.debug_reject = first_trials;
+    MS_HIP(B->ctx, hipSetDevice(B->ctx->device));
+    MS_HIP(B->ctx, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, B->ctx->stream));
+    return MS_OK;
+}
 
 int ms_ba_solve_host(ms_ctx *c, const ms_ba_problem *problem, double *pose_out, double *point_out, double *chi2_per_obs, ms_ba_result *res) {
     ms_ba *B = nullptr;

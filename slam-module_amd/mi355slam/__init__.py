@@ -670,6 +670,9 @@ class BundleAdjuster:
     def team_fallbacks(self):
         return lib().ms_ba_team_fallbacks(self._h)
 
+    def debug_force_reject(self, first_trials):
+        self.ctx.check(lib().ms_ba_debug_force_reject(self._h, int(first_trials)), "ms_ba_debug_force_reject")
+
     def debug_fail_team_barriers(self, on=True):
         self.ctx.check(lib().ms_ba_debug_fail_team_barriers(self._h, int(on)), "ms_ba_debug_fail_team_barriers")
 

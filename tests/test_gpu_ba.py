@@ -55,6 +55,38 @@ def test_rejected_lm_steps_follow_the_oracle(oracle, ctx):
         ba.close()
 
 
+def test_ten_rejected_trials_terminate_like_the_oracle(oracle, ctx):
+    """g2o's Terminate: ten damped trials rejected in ONE iteration (OptimizationAlgorithmLevenberg, _maxTrialsAfterFailure = 10) end the solve with the state
+    restored ten times and lambda grown by 2 * 4 * ... * 1024 = 2^55.  Rejections cannot be provoked ten times in a row by data alone without the outcome hanging
+    on rounding, so the solver and the oracle share a test hook (the first n trials count as rejected): the control flow after the decision -- pop(), the lambda /
+    nu schedule, qmax, the stop flag, the team barriers around the restore -- is the real one.  One workgroup per problem and teams; also a run of seven
+    rejections followed by an accepted step (the solve goes on with the grown lambda), and the chi2_per_obs contract next to g2o's stale edge->chi2()."""
+    import mi355slam
+    probs = [ba_synth.make_problem(8, 150, 5, seed=3), ba_synth.make_problem(20, 400, 6, seed=9, outlier_frac=0.05)]
+    for n_rej, iters in ((10, 6), (12, 6), (7, 5)):
+        wants = [oracle.ba_solve(p, iters, False, force_reject=n_rej) for p in probs]
+        if n_rej >= 10:
+            assert all(w["stats"]["iters"] == 1 and w["stats"]["trials"] == 10 and w["stats"]["stop"] == 1 for w in wants)
+            assert all(np.array_equal(w["pose"], p["pose"]) and np.array_equal(w["point"], p["point"]) for w, p in zip(wants, probs))      # restored, not "nearly"
+        else:
+            assert all(w["stats"]["stop"] == 0 and w["stats"]["trials"] == w["stats"]["iters"] + n_rej and w["stats"]["chi2_final"] < w["stats"]["chi2_init"] for w in wants)
+        for team in (1, 4):
+            ba = mi355slam.BundleAdjuster(ctx, probs, max_iters=iters)
+            ba.set_team(team); ba.debug_force_reject(n_rej); ba.solve()
+            for i, p in enumerate(probs):
+                got = ba.download(i)
+                _check(p, got, wants[i])
+                if n_rej >= 10:
+                    assert np.array_equal(got["pose"], p["pose"]) and np.array_equal(got["point"], p["point"])
+            assert ba.team_fallbacks() == 0
+            ba.close()
+    # chi2_per_obs is evaluated at the state that is returned; g2o's edge->chi2() after a solve that ends on rejected trials is the last REJECTED trial's (oracle flag):
+    # after ten rejections the two differ by a step damped 2^55 times -- measurably (the oracle has both), but far inside what the outlier rule chi2 > 5.991 can see
+    fresh, stale = oracle.ba_solve(probs[0], 6, False, force_reject=10), oracle.ba_solve(probs[0], 6, False, g2o_stale_chi2=True, force_reject=10)
+    d = np.abs(fresh["chi2"] - stale["chi2"]).max()
+    assert 0 < d < 1e-5 and np.array_equal(fresh["chi2"] > 5.991, stale["chi2"] > 5.991)
+
+
 def test_c4_local_ba_matches_oracle(oracle, ctx):
     """BASELINE config C4: 50 keyframes x 2000 points x 20000 observations, 10 LM iterations, seed 42."""
     import mi355slam
