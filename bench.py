@@ -578,6 +578,7 @@ def run_gpu(R, args):
         leg("greedy_match", lambda: bench_greedy(R, ctx, args))
     # ---- C5: 8 independent sequences, sequence s on GPU s mod N, frame by frame ----
     if not args.no_c5:
+        leg("pipelined_sequence", lambda: bench_pipelined(R, args))
         leg("c5", lambda: bench_c5(R, args))
     if failed:
         out["failed_legs"] = failed
@@ -1129,6 +1130,165 @@ class SequenceRunner(threading.Thread):
         except Exception as e:                                   # noqa: BLE001 -- reported by the parent
             self.error = e
             self.ready.set()
+
+
+def bench_pipelined(R, args):
+    """One sequence the way the reference runs it on one device: the FRONT END on frame k + 1 (mapper.cpp:356-393: detectAndExtract, match against the previous
+    frame, poseBundleAdjust) beside the BACK END on keyframe k (mapper.cpp:229-279, mapper_helpers.cpp:1079-1081: localBundleAdjust, two-stage, a NEW C4 window),
+    two host threads, two contexts.  Measured three ways on the same inputs: the front end alone, the back end alone (windows back to back), and both together
+    with the back end fed one keyframe per `--c5-keyframe-every` frames (a keyframe that arrives while the back end is busy waits; the front end never does)."""
+    import numpy as np
+    import ba_synth
+    import mi355slam
+    import synth
+    F, FD, KF = args.c5_frames, min(args.c5_distinct, args.c5_frames), args.c5_keyframe_every
+    g = synth.SequenceSynth(W, H, 2000 + 100 * R.rank, 2 * (FD - 1), FD - 1)
+    frames = np.ascontiguousarray(np.stack([g.frame(2 * i, i) for i in range(FD)]))
+    wins = [ba_synth.make_problem_fast(50, 2000, 10, seed=9000 + 16 * R.rank + k) for k in range(4)]
+    cur = len(wins[0]["pose"]) - 1
+    stages = [two_stage_problems(p, cur) for p in wins]
+    pose_probs = [ba_synth.pose_only_from_window(p, 25) for p in wins]
+    iters = int(1 + np.sqrt(50.0))
+    extra = np.full(1, cur, np.int32)
+
+    class Front(threading.Thread):
+        def __init__(self, start_evt, on_keyframe):
+            super().__init__()
+            self.start_evt, self.on_keyframe = start_evt, on_keyframe
+            self.ready, self.error, self.seconds, self.stage, self.pose_ms = threading.Event(), None, 0.0, {}, 0.0
+
+        def run(self):
+            try:
+                ctx = mi355slam.Context(R.gpu)
+                buf = ctx.upload(frames)
+                ex = [mi355slam.OrbExtractor(ctx, W, H, levels=LEVELS, scale_factor=SCALE, max_kpts=MAX_KPTS, fast_threshold=FAST_THR, max_batch=1) for _ in range(2)]
+                for e in ex:
+                    e.set_profiling(True)
+                cap = ex[0].capacity
+                bi, bd, sd, match = ctx.alloc(4 * cap + 16), ctx.alloc(2 * cap + 16), ctx.alloc(2 * cap + 16), ctx.alloc(4 * cap + 16)
+                views = [None, None]
+                pose_t = [0.0]
+
+                def frame(i, count):
+                    e = ex[i & 1]
+                    e.extract(buf.ptr + image_of(i, FD) * W * H, n_frames=1, frame_stride=W * H, row_stride=W)
+                    if views[i & 1] is None:
+                        views[i & 1] = e.device_view()
+                    if i:
+                        q, t = views[i & 1], views[(i - 1) & 1]
+                        mi355slam.hamming_best2_sets(ctx, q.desc, cap, q.count, t.desc, cap, t.count, None, None, 1, bi, bd, sd)
+                        mi355slam.ratio_test_device(ctx, bi, bd, sd, cap, LOWE_RATIO, 50, match)
+                    t0 = time.perf_counter()
+                    pb = mi355slam.BundleAdjuster(ctx, [pose_probs[i % len(pose_probs)]], max_iters=10)      # poseBundleAdjust of this frame (bundle_adjuster.cpp:396-491)
+                    pb.solve(); pb.download(0); pb.close()
+                    if count:
+                        pose_t[0] += time.perf_counter() - t0
+                        if i % KF == 0 and self.on_keyframe:
+                            self.on_keyframe(i // KF)
+                for i in range(2):
+                    frame(i, False)
+                ctx.sync()
+                self.ready.set()
+                self.start_evt.wait()
+                t0 = time.perf_counter()
+                for i in range(F):
+                    frame(i, True)
+                ctx.sync()
+                self.seconds = time.perf_counter() - t0
+                self.pose_ms = pose_t[0] / F * 1e3
+                acc = {}
+                for back in range(16):                                     # the kernels of the last 32 frames (HIP events around every stage of ms_orb_extract)
+                    for e in ex:
+                        for k, v in e.stage_ms_back(back).items():
+                            acc.setdefault(k, []).append(v)
+                self.stage = {k: round(float(np.mean(v)) * 1e3, 2) for k, v in acc.items() if k not in ("blur",)}
+                for e in ex:
+                    e.close()
+                ctx.close()
+            except Exception as e:                                       # noqa: BLE001 -- reported by the caller
+                self.error = e
+                self.ready.set()
+
+    class Back(threading.Thread):
+        def __init__(self, start_evt, n_windows=None):
+            super().__init__()
+            self.start_evt, self.n_windows = start_evt, n_windows            # n_windows: back to back (alone); None: fed by keyframes until stop()
+            self.ready, self.error = threading.Event(), None
+            self.pending, self.cv, self.stopping = [], threading.Condition(), False
+            self.lat_ms, self.wait_ms = [], []
+
+        def keyframe(self, k):
+            with self.cv:
+                self.pending.append((k, time.perf_counter())); self.cv.notify()
+
+        def stop(self):
+            with self.cv:
+                self.stopping = True; self.cv.notify()
+
+        def run(self):
+            try:
+                ctx = mi355slam.Context(R.gpu)
+
+                def window(k):
+                    a, b = stages[k % len(stages)]
+                    h1 = mi355slam.BundleAdjuster(ctx, [a], max_iters=iters); h1.solve()      # stage 1 runs while the host builds stage 2's index structures
+                    h2 = mi355slam.BundleAdjuster(ctx, [b], max_iters=iters)
+                    h2.copy_state_from(h1, extra); h2.solve(); h2.download(0); h1.close(); h2.close()
+                window(0); ctx.sync()
+                self.ready.set()
+                self.start_evt.wait()
+                if self.n_windows is not None:
+                    for k in range(self.n_windows):
+                        t0 = time.perf_counter(); window(k); self.lat_ms.append((time.perf_counter() - t0) * 1e3)
+                else:
+                    while True:
+                        with self.cv:
+                            while not self.pending and not self.stopping:
+                                self.cv.wait()
+                            if not self.pending:
+                                break
+                            k, t_arr = self.pending.pop(0)
+                        t0 = time.perf_counter(); window(k); t1 = time.perf_counter()
+                        self.lat_ms.append((t1 - t0) * 1e3); self.wait_ms.append((t0 - t_arr) * 1e3)
+                ctx.close()
+            except Exception as e:                                       # noqa: BLE001
+                self.error = e
+                self.ready.set()
+
+    def run_pair(with_front, back_mode):
+        start = threading.Event()
+        back = Back(start, n_windows=24) if back_mode == "alone" else (Back(start) if back_mode == "fed" else None)
+        front = Front(start, back.keyframe if back_mode == "fed" else None) if with_front else None
+        for t in (front, back):
+            if t:
+                t.start()
+        for t in (front, back):
+            if t:
+                t.ready.wait()
+        start.set()
+        if front:
+            front.join()
+        if back and back_mode == "fed":
+            back.stop()
+        if back:
+            back.join()
+        for t in (front, back):
+            if t and t.error:
+                raise t.error
+        return front, back
+    f_alone, _ = run_pair(True, None)
+    _, b_alone = run_pair(False, "alone")
+    f_both, b_both = run_pair(True, "fed")
+    med = lambda v: round(float(np.median(v)), 3) if len(v) else None
+    return {"workload": "one 720p sequence x %d frames; front end per frame: extract -> match vs previous -> ratio test -> poseBundleAdjust (new problem: create + solve + download); "
+                        "back end per keyframe (every %d-th frame): localBundleAdjust of a NEW C4 window, two-stage, %d + %d iterations; two host threads, two contexts" % (F, KF, iters, iters),
+            "reference": "mapper.cpp:356-393 beside mapper.cpp:229-279 (mapper_helpers.cpp:1043-1050, :1079-1081)",
+            "front_end_alone": {"frames_per_s": round(F / f_alone.seconds, 1), "ms_per_frame": round(f_alone.seconds / F * 1e3, 4), "pose_ba_ms_per_frame": round(f_alone.pose_ms, 4),
+                                "extract_stage_us": f_alone.stage},
+            "back_end_alone": {"two_stage_new_window_ms_median": med(b_alone.lat_ms), "windows": len(b_alone.lat_ms)},
+            "together": {"frames_per_s": round(F / f_both.seconds, 1), "ms_per_frame": round(f_both.seconds / F * 1e3, 4), "pose_ba_ms_per_frame": round(f_both.pose_ms, 4),
+                         "extract_stage_us": f_both.stage, "two_stage_new_window_ms_median": med(b_both.lat_ms), "keyframes_handled": len(b_both.lat_ms),
+                         "keyframe_wait_ms_median": med(b_both.wait_ms), "keyframes_per_s": round(len(b_both.lat_ms) / f_both.seconds, 1)}}
 
 
 def bench_c5(R, args):

@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <utility>
 
@@ -413,7 +414,10 @@ __device__ __forceinline__ void group_sync(const BaProb &P, uint32_t *counter, u
     }
     __syncthreads();
 }
-__device__ __noinline__ void team_sync(const BaProb &P) { group_sync(P, P.bar, (uint32_t)P.team); }
+#ifndef MS_TEAM_NO_FENCE
+#define MS_TEAM_NO_FENCE 0          /* -DMS_TEAM_NO_FENCE=1: k_ba_lm's team barriers without the agent-scope write-back / invalidate (WRONG results; timing A/B of tools/beside_probe.py) */
+#endif
+__device__ __noinline__ void team_sync(const BaProb &P) { group_sync<!MS_TEAM_NO_FENCE>(P, P.bar, (uint32_t)P.team); }
 __device__ __noinline__ void team_sync_light(const BaProb &P, int team) { group_sync<false>(P, P.bar, (uint32_t)team); }
 // barrier of the first P.chol_team workgroups only (the distributed factorisation), on a counter of its own (P.bar + 32: another 128-byte line)
 __device__ __noinline__ void chol_sync(const BaProb &P) { group_sync(P, P.bar + 32, (uint32_t)P.chol_team); }
@@ -3873,6 +3877,8 @@ struct ms_ba {
     int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
     int team_fallbacks = 0;            // launches repeated with one workgroup per problem after a team barrier gave up
     int solves = 0;                    // launches so far (ms_ba_copy_state refuses a source that has never been solved)
+    hipEvent_t ev_done = nullptr;      // the end of this handle's last launch (what reads its results waits for it ON THE HOST, politely: ba_wait_event)
+    bool pending = false;
 };
 
 // Team launches of this process, per device: what is (or may still be) running, so that the workgroups of all concurrent team launches
@@ -3882,6 +3888,34 @@ static std::mutex g_team_mu;
 static std::vector<TeamLaunch> g_team_live[64];
 static int g_team_query_errors = 0;        // hipEventQuery answers other than success / not-ready seen by the admission list (guarded by g_team_mu)
 #define MS_TRY_BA(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
+
+// The end of a handle's last launch, as an event the handle owns: whatever reads the launch's results waits for it ON THE HOST, politely (ba_wait_event), before it
+// enqueues anything -- not with hipStreamSynchronize, and not with a wait packet behind the launch (round 4, tools/hog_probe.py: a stream with packets queued behind
+// a 2 ms kernel slowed the front end of ANOTHER sequence 10 ... 90 x, one that holds one launch at a time 3 ... 15 x).
+static int ba_launch_done(ms_ctx *c, ms_ba *B) {
+    if (!B->ev_done) MS_HIP(c, hipEventCreateWithFlags(&B->ev_done, hipEventDisableTiming));
+    MS_HIP(c, hipEventRecord(B->ev_done, c->stream));
+    B->pending = true;
+    return MS_OK;
+}
+// A host wait for a solver launch (milliseconds) that leaves the processor to the other sequences' threads: hipStreamSynchronize / hipEventSynchronize spin, and
+// seven threads spinning in them made the thread that drives another sequence's front end 3 ... 15 x slower (tools/hog_probe.py: x 3.3 beside two streams whose
+// threads wait in hipStreamSynchronize, x 1.09 beside the same streams with the threads asleep) -- on this runtime a waiting thread is not free for the others.
+static int ba_wait_event(ms_ctx *c, hipEvent_t ev) {
+    for (int i = 0;; ++i) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return MS_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return ms_fail(c, MS_ERR_HIP, "waiting for a solver launch failed: %s", hipGetErrorString(q)); }
+        if (i < 4) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(25));
+    }
+}
+static int ba_wait_pending(ms_ba *B) {
+    if (!B->pending) return MS_OK;
+    MS_TRY_BA(ba_wait_event(B->ctx, B->ev_done));
+    B->pending = false;
+    return MS_OK;
+}
 
 extern "C" {
 
@@ -4448,6 +4482,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
 void ms_ba_destroy(ms_ba *B) {
     if (!B) return;
     (void)hipSetDevice(B->ctx->device);
+    if (B->pending) (void)ba_wait_event(B->ctx, B->ev_done);
+    if (B->ev_done) (void)hipEventDestroy(B->ev_done);
     (void)hipStreamSynchronize(B->ctx->stream);
     {   // every team launch of this stream has finished: its entries leave the admission list now, before the stream itself can go away (an event
         // queried after its stream was destroyed answered "operation not permitted on an event last recorded in a capturing stream" once in ~20 runs)
@@ -4489,15 +4525,16 @@ int ms_ba_solve(ms_ba *B) {
     if (!B) return MS_ERR_INVALID;
     ms_ctx *c = B->ctx;
     MS_HIP(c, hipSetDevice(c->device));
-    if (!B->cus) { hipDeviceProp_t pr; MS_HIP(c, hipGetDeviceProperties(&pr, c->device)); B->cus = pr.multiProcessorCount; }
+    if (!B->cus) B->cus = c->n_cu;
+    const hipStream_t ls = c->stream;
     // A workgroup takes more than half a CU's LDS, so one per CU: a team is only possible while problems x team fits the chip
     // (all its workgroups must be resident for the barriers), hence the cooperative launch below.  Automatic choice: as many
     // workgroups per problem as fit, at most 32 (beyond that the single-workgroup Cholesky dominates).
     if (B->pose_only && B->team <= 1 && !std::getenv("MS_BA_NO_POSE_KERNEL")) {      // (an explicit team request keeps the general kernel: tests compare the two)
-        hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), 0, c->stream, B->d_probs);
+        hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), 0, ls, B->d_probs);
         MS_KERNEL_CHECK(c, "k_ba_pose_only");
         B->launched_team = 1; B->team_checked = true; B->last_one_pose = false; ++B->solves;
-        return MS_OK;
+        return ba_launch_done(c, B);
     }
     int most_obs = 0, most_points = 0, most_poses = 0;
     for (const auto &h : B->host) { most_obs = std::max(most_obs, h.n_obs); most_points = std::max(most_points, h.n_point); most_poses = std::max(most_poses, h.n_pose); }
@@ -4514,9 +4551,9 @@ int ms_ba_solve(ms_ba *B) {
     auto launch_lm = [&](int tm) {
         if (one_pose) {
             const size_t lds = ((size_t)op_pose_doubles + (size_t)OP_NW * 27 * op_slab_cap(lgG)) * sizeof(double);
-            if ((long long)(tm * OP_NT >> lgG) >= most_points) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n * tm), dim3(OP_NT), lds, c->stream, B->d_probs, tm, lgG, op_pose_doubles);
-            else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n * tm), dim3(OP_NT), lds, c->stream, B->d_probs, tm, lgG, op_pose_doubles);
-        } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, c->stream, B->d_probs, tm);
+            if ((long long)(tm * OP_NT >> lgG) >= most_points) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n * tm), dim3(OP_NT), lds, ls, B->d_probs, tm, lgG, op_pose_doubles);
+            else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n * tm), dim3(OP_NT), lds, ls, B->d_probs, tm, lgG, op_pose_doubles);
+        } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, ls, B->d_probs, tm);
     };
     B->last_one_pose = one_pose; B->one_pose_lg = lgG;
     // the distributed factorisation is barrier-bound on banded systems: it gets one workgroup per 16 row tiles a panel touches
@@ -4528,7 +4565,7 @@ int ms_ba_solve(ms_ba *B) {
     }
     if (changed) {
         for (auto &h : B->host) h.team = team;
-        MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
+        MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, ls));
     }
     // A plain launch: every workgroup needs more than half a CU's LDS and problems x team <= CUs, so all of a team's workgroups
     // become resident as soon as CUs are free.  What the spin barriers additionally need is that no OTHER team launch holds CUs
@@ -4544,6 +4581,7 @@ int ms_ba_solve(ms_ba *B) {
         std::vector<TeamLaunch> &live = g_team_live[c->device & 63];
         const int need = B->n * team;
         int in_use = 0;
+        in_use = 0;
         for (TeamLaunch &t : live) {                                   // retire what has finished; launches of this stream precede the new one anyway
             if (t.live) {                                              // anything but "not ready" retires the entry (an error: the stream it was recorded on is gone)
                 const hipError_t q = hipEventQuery(t.ev);
@@ -4556,15 +4594,15 @@ int ms_ba_solve(ms_ba *B) {
                     }
                 }
             }
-            if (t.live && t.stream != c->stream) in_use += t.wgs;
+            if (t.live && t.stream != ls) in_use += t.wgs;
         }
-        for (TeamLaunch &t : live) {                                   // oldest first: wait (on the device) for as many as it takes to make room
+        for (TeamLaunch &t : live) {                                   // oldest first: wait for as many as it takes to make room
             if (in_use + need <= B->cus) break;
-            if (!t.live || t.stream == c->stream) continue;
-            MS_HIP(c, hipStreamWaitEvent(c->stream, t.ev, 0));
+            if (!t.live || t.stream == ls) continue;
+            MS_HIP(c, hipStreamWaitEvent(ls, t.ev, 0));                // on the device
             in_use -= t.wgs;
         }
-        hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, c->stream, B->d_probs, B->n, B->debug_fail_barriers);
+        hipLaunchKernelGGL(k_ba_team_reset, dim3(ms_div_up(B->n, 64)), dim3(64), 0, ls, B->d_probs, B->n, B->debug_fail_barriers);
         launch_lm(team);
         MS_KERNEL_CHECK(c, "k_ba_lm");
         TeamLaunch *slot = nullptr;
@@ -4579,8 +4617,8 @@ int ms_ba_solve(ms_ba *B) {
                 MS_HIP(c, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
             }
         }
-        MS_HIP(c, hipEventRecord(slot->ev, c->stream));
-        slot->stream = c->stream; slot->wgs = need; slot->live = true;
+        MS_HIP(c, hipEventRecord(slot->ev, ls));
+        slot->stream = ls; slot->wgs = need; slot->live = true;
         if (slot != &live.back()) std::rotate(slot, slot + 1, &live.back() + 1);      // keep the list in launch order (oldest first)
     } else {
         launch_lm(team);
@@ -4589,23 +4627,26 @@ int ms_ba_solve(ms_ba *B) {
     B->launched_team = team;
     B->team_checked = team == 1;
     ++B->solves;
-    return MS_OK;
+    return ba_launch_done(c, B);
 }
 
 // one workgroup per problem, no team barriers: the fallback after a team barrier gave up
 static int ba_relaunch_single(ms_ba *B) {
     ms_ctx *c = B->ctx;
+    const hipStream_t ls = c->stream;
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
-    MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, c->stream));
+    MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, ls));
     if (B->last_one_pose) {
         int most_poses = 0, most_points = 0;
         for (const auto &h : B->host) { most_poses = std::max(most_poses, h.n_pose); most_points = std::max(most_points, h.n_point); }
         const int pd = most_poses <= OP_MAX_LDS_POSES ? (7 * most_poses + 1) & ~1 : 0;
         const size_t lds = ((size_t)pd + (size_t)OP_NW * 27 * op_slab_cap(0)) * sizeof(double);
-        if (most_points <= OP_NT) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n), dim3(OP_NT), lds, c->stream, B->d_probs, 1, 0, pd);
-        else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n), dim3(OP_NT), lds, c->stream, B->d_probs, 1, 0, pd);
-    } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, c->stream, B->d_probs, 1);
+        if (most_points <= OP_NT) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n), dim3(OP_NT), lds, ls, B->d_probs, 1, 0, pd);
+        else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n), dim3(OP_NT), lds, ls, B->d_probs, 1, 0, pd);
+    } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, ls, B->d_probs, 1);
     MS_KERNEL_CHECK(c, "k_ba_lm");
+    MS_TRY_BA(ba_launch_done(c, B));
+    MS_TRY_BA(ba_wait_pending(B));
     MS_HIP(c, hipStreamSynchronize(c->stream));
     B->launched_team = 1;
     B->team_checked = true;
@@ -4618,6 +4659,7 @@ static int ba_relaunch_single(ms_ba *B) {
 // read by one lane of the first workgroup while the others may still be storing), and a launch with one set is repeated with one workgroup per problem before
 // anything of it is handed on -- to the caller (ms_ba_download) or to another handle (ms_ba_copy_state).
 static int ba_team_verdict(ms_ba *B) {
+    MS_TRY_BA(ba_wait_pending(B));
     if (B->team_checked) return MS_OK;
     ms_ctx *c = B->ctx;
     int any = 0;
@@ -4640,6 +4682,7 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
     // A team barrier that gave up anywhere in the batch voids the whole launch (the workgroups of one launch share the chip): before the FIRST
     // problem of a team launch is handed out, every problem's marker is looked at and the batch is solved again without teams if one is set --
     // never after some results have already been returned.
+    MS_TRY_BA(ba_wait_pending(B));
     if (B->n > 1) MS_TRY_BA(ba_team_verdict(B));          // (a single problem's marker arrives with its results below: no extra round trip)
     // everything the caller asked for in ONE device-to-host copy (status, poses, points, per-observation chi2 packed side by side by a small kernel, into the
     // context's pinned staging block): four blocking copies were 0.09 ms of a 2.3 ms window

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
+#include <vector>
 #include <algorithm>
 
 namespace {
@@ -116,7 +117,7 @@ int ms_ctx_create(int device, ms_ctx **out) {
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        delete c;
+        ms_ctx_destroy(c);
         return MS_ERR_HIP;
     }
     *out = c;
