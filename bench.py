@@ -1197,7 +1197,7 @@ def bench_pipelined(R, args):
                 self.seconds = time.perf_counter() - t0
                 self.pose_ms = pose_t[0] / F * 1e3
                 acc = {}
-                for back in range(16):                                     # the kernels of the last 32 frames (HIP events around every stage of ms_orb_extract)
+                for back in range(max(1, min(16, F // 2 - 1))):            # the kernels of the last (up to) 32 frames (HIP events around every stage of ms_orb_extract)
                     for e in ex:
                         for k, v in e.stage_ms_back(back).items():
                             acc.setdefault(k, []).append(v)

@@ -454,6 +454,10 @@ int ms_ba_team_fallbacks(const ms_ba *ba);
 /* Event-query failures the team admission list has seen in this process (0 in a healthy run; see above). */
 int ms_ba_admission_errors(void);
 int ms_ba_debug_fail_team_barriers(ms_ba *ba, int on);
+/* Allocations the library has made so far on the host or the device (handle objects, growth of its host scratch, device blocks, pinned staging, events), process-wide.
+ * The per-keyframe path -- ms_ba_create / solve / download / destroy of windows of a steady size -- leaves it unchanged after warm-up (the reference mallocs
+ * per vertex and edge, bundle_adjuster.cpp:55,73,247,265,279).  tests/host_shim_smoke.cpp holds 20 consecutive windows against it. */
+long long ms_debug_host_allocs(void);
 /* Test hook: the first `first_trials` damped trials of the following solves count as rejected whatever their gain (state restored, lambda *= nu, nu *= 2): ten of them
  * in one iteration drive g2o's Terminate path (OptimizationAlgorithmLevenberg, _maxTrialsAfterFailure = 10) deterministically.  General solver only. */
 int ms_ba_debug_force_reject(ms_ba *ba, int first_trials);

@@ -24,6 +24,7 @@
 // so results may differ in the last bits run-to-run; parity is judged at 1e-5 on the residuals.
 #include "ms_internal.h"
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <chrono>
@@ -33,6 +34,8 @@
 #include <thread>
 #include <type_traits>
 #include <utility>
+
+#define g_ba_host_allocs g_ms_host_allocs      // (the library-wide counter of ms_internal.h)
 
 namespace {
 
@@ -3893,7 +3896,7 @@ static int g_team_query_errors = 0;        // hipEventQuery answers other than s
 // enqueues anything -- not with hipStreamSynchronize, and not with a wait packet behind the launch (round 4, tools/hog_probe.py: a stream with packets queued behind
 // a 2 ms kernel slowed the front end of ANOTHER sequence 10 ... 90 x, one that holds one launch at a time 3 ... 15 x).
 static int ba_launch_done(ms_ctx *c, ms_ba *B) {
-    if (!B->ev_done) MS_HIP(c, hipEventCreateWithFlags(&B->ev_done, hipEventDisableTiming));
+    if (!B->ev_done) { MS_HIP(c, hipEventCreateWithFlags(&B->ev_done, hipEventDisableTiming)); ++g_ba_host_allocs; }
     MS_HIP(c, hipEventRecord(B->ev_done, c->stream));
     B->pending = true;
     return MS_OK;
@@ -3917,6 +3920,49 @@ static int ba_wait_pending(ms_ba *B) {
     return MS_OK;
 }
 
+// ---------------------------------------------------------------- host scratch of ms_ba_create: no allocation per window after warm-up
+// Everything ms_ba_create builds on the host (index structures, batch lists, the streams: ~40 arrays per problem) lives in a per-thread bump arena that keeps its
+// memory from call to call: a sliding-window BA per keyframe allocates nothing once the first windows have sized it.  (A batch that does not fit overflows into
+// plain blocks, freed at the next call.)  g_ba_host_allocs counts every allocation this file makes on the host or the device -- arena growth, overflow blocks,
+// handle objects, device blocks, events -- so a test can hold "none after warm-up" against it (ms_debug_host_allocs; tests/host_shim_smoke.cpp).
+struct BaArena {
+    static constexpr size_t kKeepMax = (size_t)64 << 20;            // what a thread keeps between calls: enough for a handful of windows per call, not for a 256-window batch
+    char *base = nullptr;
+    size_t cap = 0, used = 0, total = 0;
+    std::vector<void *> overflow;
+    void begin() {                                                  // start of a create: nothing of the previous call is alive any more
+        const size_t want = std::min(kKeepMax, total + total / 4);
+        if (want > cap) { std::free(base); cap = ms_align_up(want, (size_t)1 << 20); base = static_cast<char *>(std::malloc(cap)); ++g_ba_host_allocs; }
+        used = 0; total = 0;
+    }
+    void end() {                                                    // end of a create: what did not fit goes back at once (the arena itself stays)
+        for (void *p : overflow) std::free(p);
+        overflow.clear();
+    }
+    void *take(size_t bytes, size_t align) {
+        const size_t at = ms_align_up(used, align);
+        total = ms_align_up(total, align) + bytes;
+        if (base && at + bytes <= cap) { used = at + bytes; return base + at; }
+        void *p = std::malloc(bytes ? bytes : 1);
+        ++g_ba_host_allocs;
+        overflow.push_back(p);
+        return p;
+    }
+    ~BaArena() { end(); std::free(base); }
+};
+static thread_local BaArena tl_ba_arena;
+template <class T>
+struct BaAlloc {
+    typedef T value_type;
+    BaAlloc() = default;
+    template <class U> BaAlloc(const BaAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(tl_ba_arena.take(n * sizeof(T), alignof(T) < 16 ? 16 : alignof(T))); }
+    void deallocate(T *, size_t) {}
+    template <class U> bool operator==(const BaAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const BaAlloc<U> &) const { return false; }
+};
+template <class T> using bvec = std::vector<T, BaAlloc<T>>;
+
 extern "C" {
 
 int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
@@ -3924,23 +3970,25 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     if (!c || !problems || !out || n < 1) return MS_ERR_INVALID;
     *out = nullptr;
     MS_HIP(c, hipSetDevice(c->device));
+    tl_ba_arena.begin();
+    struct ArenaEnd { ~ArenaEnd() { tl_ba_arena.end(); } } arena_end;      // (after every container of this call is gone: declared first, destroyed last)
     const bool tm_on = std::getenv("MS_BA_TIMING") != nullptr;           // prints the host index build and the allocation + upload time of every create to stderr
     auto tm_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tm0 = tm_now();
     double tm_part[5] = {0, 0, 0, 0, 0}, tm_mark = tm0;                  // CSR + envelope | record-based Schur lists | Cholesky panel lists | fused Schur batches | windowed Cholesky tables
     auto tm_lap = [&](int k) { if (tm_on) { const double t = tm_now(); tm_part[k] += t - tm_mark; tm_mark = t; } };
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
-    struct FsHost { std::vector<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; std::vector<uint16_t> pairs; std::vector<double> puv; bool by_points = false; };
-    struct Prep { std::vector<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; std::vector<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, fo_lo; std::vector<double> fo_uvi; std::vector<int32_t> chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
+    struct FsHost { bvec<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; bvec<uint16_t> pairs; bvec<double> puv; bool by_points = false; };
+    struct Prep { bvec<int32_t> cw_slot, cw_act_start, cw_act, cw_load_start, cw_load; int cw_W = 0; bool cw_zglobal = false, cw_meta_lds = false; bvec<int32_t> pidx, free2pose, pt_start, pt_obs, fstart, fobs, fo_lo; bvec<double> fo_uvi; bvec<int32_t> chunk_items, seg_start, seg_pair, env16, act_start, act_blk, fs_cs; FsHost fs[2];
                   bool fused = false; int fs_only = 0; int np_free = 0, n_chunks = 0, n_seg = 0; double chol_tiles = 0;
-                  bool one_pose = false; std::vector<int32_t> op_pose, op_o; std::vector<double> op_uvi; };
-    std::vector<Prep> prep(n);
+                  bool one_pose = false; bvec<int32_t> op_pose, op_o; bvec<double> op_uvi; };
+    bvec<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
                  free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red; };
-    std::vector<Off> off(n);
-    std::vector<size_t> in_lo(n), in_hi(n);
+    bvec<Off> off(n);
+    bvec<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
         const ms_ba_problem &Q = problems[p];
         if (Q.n_pose < 1 || Q.n_point < 0 || Q.n_obs < 0 || Q.n_pose_edge < 0 || !Q.pose || !Q.pose_fixed || (Q.n_point && !Q.point) ||
@@ -3960,15 +4008,18 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         for (int o = 0; o < Q.n_obs; ++o) R.pt_start[Q.obs_point[o] + 1]++;
         for (int l = 0; l < Q.n_point; ++l) R.pt_start[l + 1] += R.pt_start[l];
         R.pt_obs.resize(Q.n_obs);
-        { std::vector<int32_t> cur(R.pt_start.begin(), R.pt_start.end() - 1); for (int o = 0; o < Q.n_obs; ++o) R.pt_obs[cur[Q.obs_point[o]]++] = o; }
+        { bvec<int32_t> cur(R.pt_start.begin(), R.pt_start.end() - 1); for (int o = 0; o < Q.n_obs; ++o) R.pt_obs[cur[Q.obs_point[o]]++] = o; }
         R.fstart.assign(R.np_free + 1, 0);
         for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fstart[f + 1]++; }
         for (int f = 0; f < R.np_free; ++f) R.fstart[f + 1] += R.fstart[f];
         R.fobs.resize(R.fstart[R.np_free]);
-        { std::vector<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
+        { bvec<int32_t> cur(R.fstart.begin(), R.fstart.end() - 1); for (int o = 0; o < Q.n_obs; ++o) { const int f = R.pidx[Q.obs_pose[o]]; if (f >= 0) R.fobs[cur[f]++] = o; } }
         for (int o = 0; o < Q.n_obs; ++o) if (R.pidx[Q.obs_pose[o]] < 0) R.fobs.push_back(o);      // behind them: the observations of FIXED poses (fobs[fstart[np_free] .. n_obs))
-        R.fo_lo.resize(4 * (size_t)Q.n_obs); R.fo_uvi.assign(4 * (size_t)Q.n_obs, 0.0);          // the same order as a stream of values (linearise_stream)
-        for (int ii = 0; ii < Q.n_obs; ++ii) {
+        // the same order as a stream of values (linearise_stream, eval_stream, backsub_stream): read by launches with ONE workgroup per window -- the same rule
+        // ms_ba_solve applies; a handle that will get teams (a window per keyframe) neither builds nor uploads them
+        const bool want_streams = std::min(std::max(1, std::min(kMaxTeam, c->n_cu / std::max(n, 1))), std::min(32, std::max(1, Q.n_obs / 512))) == 1;
+        if (want_streams) { R.fo_lo.resize(4 * (size_t)Q.n_obs); R.fo_uvi.assign(4 * (size_t)Q.n_obs, 0.0); }
+        for (int ii = 0; want_streams && ii < Q.n_obs; ++ii) {
             const int o = R.fobs[ii];
             R.fo_lo[4 * (size_t)ii] = Q.obs_point[o]; R.fo_lo[4 * (size_t)ii + 1] = o | ((Q.point_fixed && Q.point_fixed[Q.obs_point[o]]) ? (int32_t)0x80000000 : 0); R.fo_lo[4 * (size_t)ii + 2] = Q.obs_pose[o]; R.fo_lo[4 * (size_t)ii + 3] = R.pidx[Q.obs_pose[o]];
             R.fo_uvi[4 * (size_t)ii] = Q.obs_uv[2 * (size_t)o]; R.fo_uvi[4 * (size_t)ii + 1] = Q.obs_uv[2 * (size_t)o + 1]; R.fo_uvi[4 * (size_t)ii + 2] = Q.obs_info[o];
@@ -3990,8 +4041,8 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
         // envelope of the reduced camera matrix at pose level: the first free pose each free pose is coupled with (a shared point or a
         // pose-pose edge), and the free observations of every free point, sorted by free pose (flat arrays: the fused Schur pass is built from them)
-        std::vector<int> first(R.np_free), hfirst(R.np_free);          // hfirst: the first free pose a pose is coupled with by a pose-pose EDGE (Hpp has nothing left of that block)
-        std::vector<int32_t> fp_start(Q.n_point + 1, 0), fp_f, fp_o;
+        bvec<int> first(R.np_free), hfirst(R.np_free);          // hfirst: the first free pose a pose is coupled with by a pose-pose EDGE (Hpp has nothing left of that block)
+        bvec<int32_t> fp_start(Q.n_point + 1, 0), fp_f, fp_o;
         {
             for (int f = 0; f < R.np_free; ++f) first[f] = hfirst[f] = f;
             int max_k = 0;
@@ -4023,7 +4074,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         if (!R.fused) {   // record-based Schur work list: for every free point, every ordered pair (a, b) of its observations with free poses fb <= fa,
             // counting-sorted by (fa, fb), then cut into chunks of CH items of one pose pair
             const int np = R.np_free;
-            std::vector<int32_t> count((size_t)np * np + 1, 0);
+            bvec<int32_t> count((size_t)np * np + 1, 0);
             auto for_items = [&](auto &&fn) {
                 for (int l = 0; l < Q.n_point; ++l) {
                     if (Q.point_fixed && Q.point_fixed[l]) continue;
@@ -4039,9 +4090,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 }
             };
             for_items([&](int key, int, int) { count[key + 1]++; });
-            std::vector<int32_t> kstart(count);
+            bvec<int32_t> kstart(count);
             for (size_t k = 1; k < kstart.size(); ++k) kstart[k] += kstart[k - 1];
-            std::vector<int32_t> sorted(2 * (size_t)kstart.back()), cur(kstart.begin(), kstart.end() - 1);
+            bvec<int32_t> sorted(2 * (size_t)kstart.back()), cur(kstart.begin(), kstart.end() - 1);
             for_items([&](int key, int a, int b) { const int pos = cur[key]++; sorted[2 * (size_t)pos] = a; sorted[2 * (size_t)pos + 1] = b; });
             R.seg_start.push_back(0);
             for (int key = 0; key < np * np; ++key) {
@@ -4089,9 +4140,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             R.fs_cs.resize(2 * (size_t)np);                              // [np] first column of the row's envelope part, then [np] first column of the row's part of Hpp
             for (int f = 0; f < np; ++f) { R.fs_cs[f] = 6 * first[f]; R.fs_cs[(size_t)np + f] = 6 * hfirst[f]; }
             const bool ok = R.fused;
-            std::vector<int32_t> stamp(Q.n_point, -1);
-            std::vector<std::pair<uint64_t, int32_t>> pts;               // (signature of the point's pose set, point)
-            std::vector<std::pair<int32_t, uint16_t>> bp2;                // (block key, pair) of the open batch
+            bvec<int32_t> stamp(Q.n_point, -1);
+            bvec<std::pair<uint64_t, int32_t>> pts;               // (signature of the point's pose set, point)
+            bvec<std::pair<int32_t, uint16_t>> bp2;                // (block key, pair) of the open batch
             // Only the set the launches will use is built (the other one aliases it: still correct, only slower, should ms_ba_set_team
             // ask for the other regime later): a batch that fills the chip always runs one workgroup per problem, a handful of windows
             // gets teams -- the same rule ms_ba_solve applies.
@@ -4115,10 +4166,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 // block products; its rows are the poses those points see (they overlap with the neighbours': the sums meet in S through atomics).  Every
                 // observation is then linearised once per damped solve.  (Row passes made each of the 32 workgroups re-evaluate every point that touches its
                 // one or two rows: 8x the observations, 75 batches per workgroup instead of 10.)
-                std::vector<std::vector<int32_t>> group_pts;
+                bvec<bvec<int32_t>> group_pts;
                 F.by_points = false;
                 if (set == 1) {
-                    std::vector<std::pair<uint32_t, int32_t>> order;      // (first pose << 16 | last pose, point)
+                    bvec<std::pair<uint32_t, int32_t>> order;      // (first pose << 16 | last pose, point)
                     double total_cost = 0;
                     for (int l = 0; l < Q.n_point; ++l) {
                         const int k = fp_start[l + 1] - fp_start[l];
@@ -4284,7 +4335,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         tm_lap(3);
         {   // windowed Cholesky (cholesky_window): active 16-row blocks per panel, LDS slots, tiles entering per panel
             const int np = R.np_free, n6i = 6 * np, nblk = (n6i + 15) / 16;
-            std::vector<int> ent(nblk, 0);
+            bvec<int> ent(nblk, 0);
             for (int b = 0; b < nblk; ++b) {
                 int e = n6i;
                 for (int r = 16 * b; r < std::min(16 * b + 16, n6i); ++r) e = std::min(e, 6 * first[r / 6]);
@@ -4292,9 +4343,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             }
             for (int b = nblk - 2; b >= 0; --b) ent[b] = std::min(ent[b], b);      // (a block is active at its own panel at the latest)
             R.cw_slot.assign(nblk, 0);
-            std::vector<int> free_slots, active;
+            bvec<int> free_slots, active;
             int W = 0;
-            std::vector<std::vector<int>> entering(nblk);
+            bvec<bvec<int>> entering(nblk);
             for (int b = 0; b < nblk; ++b) entering[ent[b]].push_back(b);
             R.cw_act_start.push_back(0); R.cw_load_start.push_back(0);
             for (int pnl = 0; pnl < nblk; ++pnl) {
@@ -4361,7 +4412,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.op_rec = bump(R.one_pose ? 28 * (size_t)Q.n_point * D : 8); O.op_red = bump(R.one_pose ? 2 * (size_t)kMaxTeam * OP_NV * D : 8);
     }
     const double tm1 = tm_now();
-    ms_ba *B = new ms_ba();
+    ms_ba *B = nullptr;
+    for (void *&slot : c->ba_handle_pool) if (slot) { B = static_cast<ms_ba *>(slot); slot = nullptr; break; }      // a destroyed handle's object: its vectors keep their capacity, its event stays
+    if (!B) { B = new ms_ba(); ++g_ba_host_allocs; }
     B->ctx = c; B->n = n;
     {   // ONE device block per handle (arena + the problem descriptors behind it), taken from the context's cache of destroyed handles when one is large enough
         const size_t probs_at = ms_align_up(total, 256), need = probs_at + sizeof(BaProb) * n;
@@ -4374,6 +4427,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         if (best >= 0) { B->d_arena = static_cast<char *>(c->ba_cache[best].p); B->arena_bytes = c->ba_cache[best].bytes; c->ba_cache[best] = {}; }
         else {
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&B->d_arena), need);
+            ++g_ba_host_allocs;
             if (e != hipSuccess) {                                  // out of memory with blocks kept for later: give them back and try once more
                 (void)hipGetLastError();
                 (void)hipStreamSynchronize(c->stream);
@@ -4429,7 +4483,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.point = PTR(double, point); H.point_bk = PTR(double, point_bk); H.point0 = PTR(double, point0);
         H.pidx = PTR(int32_t, pidx); H.point_fixed = Q.point_fixed ? PTR(uint8_t, pfix) : nullptr;
         H.obs_pose = PTR(int32_t, obs_pose); H.obs_point = PTR(int32_t, obs_point); H.obs_uv = PTR(double, obs_uv); H.obs_info = PTR(double, obs_info);
-        H.pt_start = PTR(int32_t, pt_start); H.pt_obs = PTR(int32_t, pt_obs); H.fstart = PTR(int32_t, fstart); H.fobs = PTR(int32_t, fobs); H.fo_lo = PTR(int32_t, fo_lo); H.fo_uvi = PTR(double, fo_uvi); H.free2pose = PTR(int32_t, free2pose);
+        H.pt_start = PTR(int32_t, pt_start); H.pt_obs = PTR(int32_t, pt_obs); H.fstart = PTR(int32_t, fstart); H.fobs = PTR(int32_t, fobs); H.fo_lo = R.fo_lo.empty() ? nullptr : PTR(int32_t, fo_lo); H.fo_uvi = R.fo_lo.empty() ? nullptr : PTR(double, fo_uvi); H.free2pose = PTR(int32_t, free2pose);
         H.edge_i = PTR(int32_t, edge_i); H.edge_j = PTR(int32_t, edge_j); H.edge_meas = PTR(double, edge_meas); H.edge_info = PTR(double, edge_info);
         H.Hpp = PTR(double, Hpp); H.S = PTR(double, S); H.bp = PTR(double, bp); H.dp = PTR(double, dp); H.y = PTR(double, y);
         H.Hll = PTR(double, Hll); H.bl = PTR(double, bl); H.Hinv = PTR(double, Hinv); H.Hpl = PTR(double, Hpl); H.dl = PTR(double, dl);
@@ -4483,7 +4537,6 @@ void ms_ba_destroy(ms_ba *B) {
     if (!B) return;
     (void)hipSetDevice(B->ctx->device);
     if (B->pending) (void)ba_wait_event(B->ctx, B->ev_done);
-    if (B->ev_done) (void)hipEventDestroy(B->ev_done);
     (void)hipStreamSynchronize(B->ctx->stream);
     {   // every team launch of this stream has finished: its entries leave the admission list now, before the stream itself can go away (an event
         // queried after its stream was destroyed answered "operation not permitted on an event last recorded in a capturing stream" once in ~20 runs)
@@ -4504,6 +4557,21 @@ void ms_ba_destroy(ms_ba *B) {
             if (evict) { (void)hipFree(c->ba_cache[small].p); slot = small; }
             c->ba_cache[slot].p = B->d_arena; c->ba_cache[slot].bytes = B->arena_bytes;
         } else (void)hipFree(B->d_arena);
+    }
+    {   // the handle OBJECT goes back to the context as well (emptied; its vectors' capacity and its event are what the next window per keyframe re-uses)
+        ms_ctx *c = B->ctx;
+        void **slot = nullptr;
+        for (void *&sl : c->ba_handle_pool) if (!sl) { slot = &sl; break; }
+        if (slot) {
+            const hipEvent_t ev = B->ev_done;
+            std::vector<BaProb> host = std::move(B->host); std::vector<ms_ba_problem> dims = std::move(B->dims); std::vector<double> tiles = std::move(B->chol_tiles);
+            host.clear(); dims.clear(); tiles.clear();
+            *B = ms_ba();
+            B->host = std::move(host); B->dims = std::move(dims); B->chol_tiles = std::move(tiles); B->ev_done = ev;
+            *slot = B;
+            return;
+        }
+        if (B->ev_done) (void)hipEventDestroy(B->ev_done);
     }
     delete B;
 }
@@ -4615,6 +4683,7 @@ int ms_ba_solve(ms_ba *B) {
                 live.push_back(TeamLaunch{nullptr, nullptr, 0, false});
                 slot = &live.back();
                 MS_HIP(c, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+                ++g_ba_host_allocs;
             }
         }
         MS_HIP(c, hipEventRecord(slot->ev, ls));
@@ -4765,3 +4834,7 @@ int ms_ba_solve_host(ms_ctx *c, const ms_ba_problem *problem, double *pose_out, 
 }
 
 }  // extern "C"
+
+void ms_ba_release_pool(ms_ctx *c) {
+    for (void *&sl : c->ba_handle_pool) if (sl) { ms_ba *B = static_cast<ms_ba *>(sl); if (B->ev_done) (void)hipEventDestroy(B->ev_done); delete B; sl = nullptr; }
+}

@@ -43,6 +43,7 @@ int ms_pinned(ms_ctx *c, size_t bytes) {
         const size_t want = ms_align_up(bytes * 2, 4096);
         MS_HIP(c, hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
         c->pinned_bytes = want;
+        ++g_ms_host_allocs;
     }
     return MS_OK;
 }
@@ -55,12 +56,17 @@ int ms_scratch(ms_ctx *c, size_t bytes, void **out) {
         const size_t want = ms_align_up(bytes * 2, 4096);
         MS_HIP(c, hipMalloc(&c->scratch, want));
         c->scratch_bytes = want;
+        ++g_ms_host_allocs;
     }
     *out = c->scratch;
     return MS_OK;
 }
 
+std::atomic<long long> g_ms_host_allocs{0};
+
 extern "C" {
+
+long long ms_debug_host_allocs(void) { return g_ms_host_allocs.load(); }
 
 const char *ms_version(void) { return "mi355slam 0.1 (gfx950)"; }
 
@@ -127,6 +133,7 @@ int ms_ctx_create(int device, ms_ctx **out) {
 void ms_ctx_destroy(ms_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    ms_ba_release_pool(c);
     if (c->d2h_stream) { (void)hipStreamSynchronize(c->d2h_stream); (void)hipStreamDestroy(c->d2h_stream); }
     if (c->ev_d2h_gate) (void)hipEventDestroy(c->ev_d2h_gate);
     if (c->ev_d2h_done) (void)hipEventDestroy(c->ev_d2h_done);

@@ -29,8 +29,15 @@ struct ms_ctx {
     bool d2h_pending = false;
     void *pinned = nullptr;       // page-locked host staging of small result blocks (ms_pinned), grow-only
     size_t pinned_bytes = 0;
+    void *ba_handle_pool[4] = {nullptr, nullptr, nullptr, nullptr};      // destroyed bundle-adjustment handle OBJECTS (their vectors keep their capacity, their event stays): ms_ba_create takes one back
     char err[512] = {0};
 };
+
+// every allocation the library makes on the host or the device after a context exists (handle objects, host scratch growth, device blocks, pinned staging, events):
+// a per-keyframe path must leave it unchanged after warm-up (ms_debug_host_allocs)
+#include <atomic>
+extern std::atomic<long long> g_ms_host_allocs;
+void ms_ba_release_pool(ms_ctx *ctx);      // ba.hip: deletes the pooled handle objects (ms_ctx_destroy)
 
 // page-locked host staging of at least `bytes` in ctx->pinned (contents are valid until the next call that uses it)
 int ms_pinned(ms_ctx *ctx, size_t bytes);

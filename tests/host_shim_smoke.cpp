@@ -389,6 +389,39 @@ int main(int argc, char **argv) {
         BaWindow empty; empty.poses.push_back({0, 0, 0, 1, 0, 0, 0});
         if (poseBundleAdjust(ctx, empty, 10)) return 19;                           // nothing to adjust: false, like :410-412
     }
+    {   // nothing is allocated on the per-keyframe path after warm-up.  24 consecutive sliding windows (12 keyframes x 360 points, 6 views each, every window
+        // with its own noise and its newest keyframe free in stage 1) through the two-stage mirror; the library's own count of allocations -- handle objects, growth of
+        // its host scratch, device blocks, pinned staging, events (ms_debug_host_allocs) -- must stand still from the fifth window on.
+        unsigned rng = 7u;
+        auto uni = [&]() { rng = rng * 1664525u + 1013904223u; return (rng >> 8) / 16777216.0; };
+        auto make = [&](int shift) {
+            BaWindow s; s.currentKeyframe = 11;
+            for (int i = 0; i < 12; ++i) s.poses.push_back({0, 0, 0, 1, -0.2 * (i + shift) + 0.004 * (uni() - 0.5), 0.004 * (uni() - 0.5), 0});
+            for (int l = 0; l < 360; ++l) {
+                const int s0 = l % 7;
+                const double X = 0.2 * (s0 + shift) + 0.6 + 1.2 * (uni() - 0.5), Y = 1.6 * (uni() - 0.5), Z = 4.0 + 4.0 * uni();
+                s.points.push_back({X + 0.02 * (uni() - 0.5), Y + 0.02 * (uni() - 0.5), Z + 0.05 * (uni() - 0.5)});
+                for (int i = s0; i < s0 + 6; ++i) {
+                    s.obsPose.push_back(i); s.obsPoint.push_back(l);
+                    s.obsUv.push_back({(X - 0.2 * (i + shift)) / Z + 1e-3 * (uni() - 0.5), Y / Z + 1e-3 * (uni() - 0.5)}); s.obsInfo.push_back(250000.0);
+                }
+            }
+            for (int i = 1; i < 12; ++i) { s.edgeI.push_back(i); s.edgeJ.push_back(i - 1); s.edgeMeas.push_back({0, 0, 0, 1, 0.2, 0, 0});
+                std::array<double, 36> info{}; for (int k = 0; k < 6; ++k) info[7 * k] = 1e4; s.edgeInfo.push_back(info); }
+            return s;
+        };
+        long long at_warm = 0;
+        double worst = 0;
+        for (int k = 0; k < 24; ++k) {
+            BaWindow s = make(k);
+            if (k == 4) at_warm = ms_debug_host_allocs();
+            const BaOutcome bo = localBundleAdjust(ctx, s, 12, params, true, nullptr);
+            worst = std::max(worst, bo.stage2.chi2_final / std::max(bo.stage1.chi2_initial, 1e-30));
+        }
+        const long long after = ms_debug_host_allocs();
+        std::printf("24 sliding windows: library allocations after warm-up %lld (total so far %lld), worst chi2 ratio %.3g\n", after - at_warm, after, worst);
+        if (after != at_warm || !(worst < 1.0)) return 21;
+    }
     // globalBundleAdjust-sized map: 200 keyframes on a line (the current one fixed), 1500 points each seen by 8 consecutive keyframes
     {
         BaWindow g; g.currentKeyframe = 199;

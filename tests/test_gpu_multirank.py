@@ -50,7 +50,8 @@ def test_bench_launcher_runs_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["ranks_share_gpu"] is True and line["collective_backend"] == "gloo" and line["collective_world"] == 2
     assert len(line["per_gpu_frames_per_s"]) == 2 and min(line["per_gpu_frames_per_s"]) > 1000
     assert abs(line["value"] - 2 * 256 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 0.02      # both ranks' frames over the slowest rank's time
-    assert "failed_legs" not in line
+    assert "failed_legs" not in line, {k: line[k] for k in line.get("failed_legs", [])}
+    assert line["pipelined_sequence"]["together"]["keyframes_handled"] >= 1
     assert line["local_ba"]["windows_per_launch"] == 4 and line["local_ba"]["value"] > 100
     assert line["c5"]["sequences_per_gpu"] == [4.0, 4.0] and line["c5"]["frames_per_s"] > 100
     assert line["c5"]["hw_queues"] == 8

@@ -21,7 +21,8 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
 res = {c + "_per_launch": round(sum(v) / len(v), 1) for c, v in sorted(acc.items())}
 if "FETCH_SIZE_per_launch" in res and "WRITE_SIZE_per_launch" in res:
     res["hbm_bytes_per_launch_uncorrected"] = int((res["FETCH_SIZE_per_launch"] + res["WRITE_SIZE_per_launch"]) * 1024)
-    res["hbm_bytes_per_launch"] = int((2.0 * res["FETCH_SIZE_per_launch"] + res["WRITE_SIZE_per_launch"]) * 1024)     # FETCH_SIZE counts half of the fetched bytes (tools/fetch_calib.hip: factor 2.0 at every access width)
+    res["hbm_bytes_per_launch"] = int((2.0 * res["FETCH_SIZE_per_launch"] + res["WRITE_SIZE_per_launch"]) * 1024)     # FETCH_SIZE counts half of the fetched bytes of whole-line patterns (tools/fetch_calib.hip)
+    res["hbm_bytes_per_launch_range"] = [res["hbm_bytes_per_launch_uncorrected"], res["hbm_bytes_per_launch"]]          # the kernel's gathers use parts of lines: the truth lies between (see pmc_calibration.json: stride128 / stride256 / rows48)
 res["launches_seen"] = {c: len(v) for c, v in acc.items()}
 sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "tools"))
 import build_id

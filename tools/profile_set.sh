@@ -46,13 +46,22 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
         if "k_calib_write" in r["Kernel_Name"]: continue
         if "k_calib" in r["Kernel_Name"]:
             kn = r["Kernel_Name"]
-            name = "strided8" if "strided8" in kn else ("stream16" if ", 4u>" in kn or ",4u>" in kn or "uint4" in kn else ("stream8" if ", 2u>" in kn or ",2u>" in kn or "uint2" in kn else "stream4"))
+            name = "strided8" if "strided8" in kn else "stride128" if "k_calib_stride<16>" in kn.replace(" ", "") else "stride256" if "k_calib_stride<32>" in kn.replace(" ", "") else "rows48" if "rows48" in kn else ("stream16" if ", 4u>" in kn or ",4u>" in kn or "uint4" in kn else ("stream8" if ", 2u>" in kn or ",2u>" in kn or "uint2" in kn else "stream4"))
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 GiB = float(1 << 30)
 res = {}
+# bytes of the 64-byte halves / 128-byte lines each pattern touches (what a counter of fetched bytes should at most see); streams touch everything once
+touched = {"stream4": (GiB, GiB), "stream8": (GiB, GiB), "stream16": (GiB, GiB), "strided8": (GiB, GiB), "stride128": (GiB / 2, GiB), "stride256": (GiB / 4, GiB / 2),
+           "rows48": (None, None)}
 for k, cs in acc.items():
     fetch = sum(cs["FETCH_SIZE"]) / max(len(cs["FETCH_SIZE"]), 1) * 1024
-    res[k] = {"known_bytes": GiB, "FETCH_SIZE_bytes": fetch, "factor_known_over_counter": round(GiB / fetch, 3) if fetch else None, "launches": len(cs["FETCH_SIZE"])}
+    halves, lines = touched.get(k, (GiB, GiB))
+    res[k] = {"FETCH_SIZE_bytes": fetch, "bytes_in_touched_64B_halves": halves, "bytes_in_touched_128B_lines": lines,
+              "known_bytes": lines if lines else None, "factor_known_over_counter": round(lines / fetch, 3) if fetch and lines else None,
+              "factor_halves_over_counter": round(halves / fetch, 3) if fetch and halves else None, "launches": len(cs["FETCH_SIZE"])}
+    if k == "rows48":
+        n = GiB / 256 - 1
+        res[k].update({"useful_bytes": n * 48, "counter_bytes_per_row_piece": round(fetch / n, 1)})
 for k, v in wacc.items():
     wb = sum(v) / len(v) * 1024
     res[k] = {"known_bytes": GiB, "WRITE_SIZE_bytes": wb, "factor_known_over_counter": round(GiB / wb, 3) if wb else None, "launches": len(v)}
