@@ -678,6 +678,12 @@ __device__ __noinline__ double eval_stream(const BaProb &P_, double *lds_v, doub
     for (int i = tid; i < 7 * n_pose; i += NT) ptab[i] = gpose[i];
     __syncthreads();
     double acc = 0;
+    // the SE3 edges are a long dependent chain per edge (inverse, two products, the logarithm: ~30 k cycles in one lane) -- the LAST wave takes them, a lane each,
+    // while the other waves stream the observations; all eight used to wait for the first wave's edges behind the reduction's barrier
+    const int n_edge = P.n_edge;
+    const bool split = n_edge > 0 && n_edge <= 64 && n_obs >= 4 * NT;
+    const int OT = split ? NT - 64 : NT;                          // threads that walk the stream
+    const bool edge_wave = split && tid >= OT;
     struct Ob { int l, o, pi; double u, v, info; };
     auto fetch_ob = [&](int ix, Ob &d) {
         const int ic = min(ix, n_obs - 1);
@@ -686,16 +692,16 @@ __device__ __noinline__ double eval_stream(const BaProb &P_, double *lds_v, doub
         const d2_t a = uvi[2 * ic];
         d.u = a.x; d.v = a.y; d.info = ((const MS_GLOBAL double *)uvi)[4 * ic + 2];
     };
-    if (n_obs > 0) {
+    if (n_obs > 0 && !edge_wave) {
         Ob o0, o1, o2;
         double X0[3], X1[3];
         int ix = tid;
-        fetch_ob(ix, o0); fetch_ob(ix + NT, o1); fetch_ob(ix + 2 * NT, o2);
+        fetch_ob(ix, o0); fetch_ob(ix + OT, o1); fetch_ob(ix + 2 * OT, o2);
 #pragma unroll
         for (int q = 0; q < 3; ++q) X0[q] = gpoint[3 * o0.l + q];
-        for (; ix - tid < n_obs; ix += NT) {
+        for (; ix - tid < n_obs; ix += OT) {
             Ob o3;
-            fetch_ob(ix + 3 * NT, o3);
+            fetch_ob(ix + 3 * OT, o3);
 #pragma unroll
             for (int q = 0; q < 3; ++q) X1[q] = gpoint[3 * o1.l + q];
             if (ix < n_obs) {
@@ -714,7 +720,7 @@ __device__ __noinline__ double eval_stream(const BaProb &P_, double *lds_v, doub
             X0[0] = X1[0]; X0[1] = X1[1]; X0[2] = X1[2];
         }
     }
-    for (int k = tid; k < P.n_edge; k += NT) {
+    for (int k = split ? tid - OT : tid; k >= 0 && k < n_edge; k += NT) {
         double e[6];
         pose_edge(P.pose + 7 * (size_t)P.edge_i[k], P.pose + 7 * (size_t)P.edge_j[k], P.edge_meas + 7 * (size_t)k, e, nullptr, nullptr, false);
         const double *W = P.edge_info + 36 * (size_t)k;
@@ -2926,7 +2932,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
     const int n6 = P.n6;
     int seq = 0;                                               // team_reduce call counter (same in every workgroup)
     // restart from the initial estimates
-    for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose0[i];
+    for (int i = gt; i < 7 * P.n_pose; i += GT) { P.pose[i] = P.pose0[i]; P.pose_bk[i] = P.pose0[i]; }      // (the saved copy of a FIXED pose is never written again)
     for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] = P.point0[i];
     if (gt == 0) P.flag[0] = 1;
     team_sync(P);
@@ -2955,33 +2961,39 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
         double rho = 0;
         int qmax = 0;
         do {
-            // push(): element i is saved and (on rejection) restored by the same thread, and every phase that changes the state
-            // sits behind later barriers, so the copy itself needs none
-            for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose_bk[i] = P.pose[i];
-            for (int i = gt; i < 3 * P.n_point; i += GT) P.point_bk[i] = P.point[i];
+            // push() happens where the state is changed: the update below saves every value it overwrites (a trial whose system cannot be solved changes nothing
+            // and needs neither the copy nor the restore) -- one walk over the state per trial instead of three (save, update, gain denominator)
             const bool ok2 = solve_step(P, lambda, lds, cyc);
             tt = clock64();
             // re-arm the flag for the next damped solve: on the good path every workgroup has read it before point_backsub's barrier; on the
             // (rare) failed path an extra barrier separates the reads from the write.  The barriers that follow order it before the next solve's phases.
             if (!ok2) team_sync(P);
             if (gt == 0) P.flag[0] = 1;
+            double sc = 0, scale = 0;
             if (ok2) {
                 for (int fp = gt; fp < P.np_free; fp += GT) {
                     const int pi = P.free2pose[fp];
-                    double ex[7], r[7];
+                    double ex[7], r[7], old[7];
+                    for (int a = 0; a < 7; ++a) { old[a] = P.pose[7 * (size_t)pi + a]; P.pose_bk[7 * (size_t)pi + a] = old[a]; }
                     se3_exp(P.dp + 6 * fp, ex);
-                    se3_mul(ex, P.pose + 7 * (size_t)pi, r);
+                    se3_mul(ex, old, r);
                     for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = r[a];
                 }
-                for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] += P.dl[i];
+                {
+                    const MS_GLOBAL double *gdl = uglobal(P.dl), *gbl = uglobal(P.bl);
+                    MS_GLOBAL double *gpt = (MS_GLOBAL double *)uglobal(P.point), *gbk = (MS_GLOBAL double *)uglobal(P.point_bk);
+                    const int n3 = 3 * P.n_point;
+#pragma unroll 4
+                    for (int i = gt; i < n3; i += GT) {
+                        const double old = gpt[i], d = gdl[i];
+                        gbk[i] = old; gpt[i] = old + d;
+                        sc = fma(d, fma(lambda, d, gbl[i]), sc);
+                    }
+                }
                 team_sync(P);
             }
             cyc[4] += clock64() - tt; tt = clock64();
-            double sc = 0, scale = 0;
-            if (ok2) {
-                for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
-                for (int i = gt; i < 3 * P.n_point; i += GT) sc += P.dl[i] * (lambda * P.dl[i] + P.bl[i]);
-            }
+            if (ok2) for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
             temp = ok2 ? (ev_stream ? eval_stream(P, lds, s_red, false, sc, &scale) : eval_chi2(P, s_red, false, seq, sc, &scale)) : DBL_MAX;     // chi2 of the new state and the gain denominator behind one team barrier
             scale += 1e-3;
             cyc[0] += clock64() - tt;
@@ -2994,8 +3006,10 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
                 ni = 2; current = temp; chi2_carried = temp;
             } else {
                 lambda *= ni; ni *= 2;
-                for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose_bk[i];      // pop()
-                for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] = P.point_bk[i];
+                if (ok2) {                                                                  // pop(): only a trial that moved the state has something to take back
+                    for (int i = gt; i < 7 * P.n_pose; i += GT) P.pose[i] = P.pose_bk[i];
+                    for (int i = gt; i < 3 * P.n_point; i += GT) P.point[i] = P.point_bk[i];
+                }
                 team_sync(P);
                 if (!isfinite(lambda)) break;
             }
