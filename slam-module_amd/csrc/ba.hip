@@ -4742,8 +4742,8 @@ static int ba_relaunch_single(ms_ba *B) {
 // read by one lane of the first workgroup while the others may still be storing), and a launch with one set is repeated with one workgroup per problem before
 // anything of it is handed on -- to the caller (ms_ba_download) or to another handle (ms_ba_copy_state).
 static int ba_team_verdict(ms_ba *B) {
+    if (B->team_checked) return MS_OK;          // (a launch without teams has no verdict to wait for: what follows it on the stream is ordered behind it anyway)
     MS_TRY_BA(ba_wait_pending(B));
-    if (B->team_checked) return MS_OK;
     ms_ctx *c = B->ctx;
     int any = 0;
     hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
