@@ -34,7 +34,7 @@ for _p in ("slam-module_amd", "tools", "tests"):
 W, H, LEVELS, SCALE, MAX_KPTS, FAST_THR, BATCH = 1280, 720, 8, 1.2, 2000, 20, 256
 LOWE_RATIO = 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")      # HBM bytes / instruction counts per launch of the committed kernel sources
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")      # HBM bytes / instruction counts per launch of the committed kernel sources
 N_SEQ = 8                      # C5: independent sequences of the whole job
 
 

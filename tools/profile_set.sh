@@ -87,6 +87,6 @@ print("merged k_ba_lm into", sys.argv[1])
 PY
 # the bench line once more, now that the counters of THESE sources exist: the line of the set quotes them (roofline.traffic, valu_issue_frac) instead of withholding
 # the numbers of an older tree (bench.py compares src_sha256); the snapshot's own copy of the summary is replaced, nothing outside the scratch tree is touched
-cp "$O/pmc_traffic.json" "$R/profiles/r03_pmc_traffic.json"
+cp "$O/pmc_traffic.json" "$R/$(grep -o '"profiles", "r[0-9]*_pmc_traffic.json"' "$R/bench.py" | head -1 | sed 's/"profiles", "/profiles\//; s/"$//')"      # (the file bench.py's PMC_FILE names)
 python3 "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err"
 echo "bench line with this set's counters done"
