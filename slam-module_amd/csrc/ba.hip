@@ -23,6 +23,7 @@
 // dense Cholesky panel update uses the f64 MFMA.  The Schur sums have a fixed order; the few SE3-edge atomics do not,
 // so results may differ in the last bits run-to-run; parity is judged at 1e-5 on the residuals.
 #include "ms_internal.h"
+#include <sys/prctl.h>
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -298,6 +299,16 @@ __device__ __forceinline__ void huber(double chi2, double delta, double &rho0, d
     const double dsqr = delta * delta;
     if (delta <= 0 || chi2 <= dsqr) { rho0 = chi2; w = 1; }
     else { const double s = sqrt(chi2); rho0 = 2 * s * delta - dsqr; w = delta / s; }
+}
+
+// 1 / sqrt(d) for the pivots of the small Cholesky factorisations: v_rsq_f64 and two Newton steps (one cubic, one quadratic: full double precision) -- ~10
+// instructions where sqrt and a division are ~60 on the solver's critical path
+__device__ __forceinline__ double rsqrt_d(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    e = fma(-d * y, y, 1.0);
+    return fma(y * e, 0.5, y);
 }
 
 // 144-byte (18 double) per-observation records are moved as nine 16-byte pieces: a lane's record sits in its own cache
@@ -1452,9 +1463,9 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
             load6(P.Hll + 6 * (size_t)l, H);
             const double b0 = P.bl[3 * (size_t)l], b1 = P.bl[3 * (size_t)l + 1], b2 = P.bl[3 * (size_t)l + 2];
             const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
-            const double l11 = sqrt(a), i11 = 1.0 / l11, l21 = H[1] * i11, l31 = H[2] * i11;
-            const double d2 = d - l21 * l21, l22 = sqrt(d2), i22 = 1.0 / l22, l32 = (H[4] - l31 * l21) * i22;
-            const double d3 = f - l31 * l31 - l32 * l32, l33 = sqrt(d3), i33 = 1.0 / l33;
+            const double i11 = rsqrt_d(a), l21 = H[1] * i11, l31 = H[2] * i11;
+            const double d2 = d - l21 * l21, i22 = rsqrt_d(d2), l32 = (H[4] - l31 * l21) * i22;
+            const double d3 = f - l31 * l31 - l32 * l32, i33 = rsqrt_d(d3);
             if (!(a > 0) || !(d2 > 0) || !(d3 > 0) || !isfinite(i11 * i22 * i33)) P.flag[0] = 0;
             const double u0 = b0 * i11, u1 = (b1 - l21 * u0) * i22, u2 = (b2 - l31 * u0 - l32 * u1) * i33;
             const double Li[6] = {i11, l21, l31, i22, l32, i33};
@@ -1498,7 +1509,7 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
         // run at the same speed: the older one has priority, 27 against 19 batches of a C4 pass), so the owner's run stays contiguous.  (Round 3 handed out runs of
         // three batches from one counter: a wave's consecutive runs were then far apart, every run started with a flush, and the flushes -- with two dependent global
         // loads for the row's tile offset in front of them -- were 3 k of the 8 k cycles a batch's products took.)
-        const int pb0 = F.batch_start[pass], pb1 = F.batch_start[pass + 1];
+        const int pb1 = F.batch_start[pass + 1];
         double acc[36];
 #pragma unroll
         for (int q = 0; q < 36; ++q) acc[q] = 0;
@@ -1587,12 +1598,11 @@ __device__ __noinline__ void schur_fused(const BaProb &P_, double lambda_, doubl
                 if (pre) { i11 = H[0]; l21 = H[1]; l31 = H[2]; i22 = H[3]; l32 = H[4]; i33 = H[5]; u0 = blv[0]; u1 = blv[1]; u2 = blv[2]; }
                 else {
                     const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
-                    const double l11 = sqrt(a);
-                    i11 = 1.0 / l11; l21 = H[1] * i11; l31 = H[2] * i11;
-                    const double d2 = d - l21 * l21, l22 = sqrt(d2);
-                    i22 = 1.0 / l22; l32 = (H[4] - l31 * l21) * i22;
-                    const double d3 = f - l31 * l31 - l32 * l32, l33 = sqrt(d3);
-                    i33 = 1.0 / l33;
+                    i11 = rsqrt_d(a); l21 = H[1] * i11; l31 = H[2] * i11;
+                    const double d2 = d - l21 * l21;
+                    i22 = rsqrt_d(d2); l32 = (H[4] - l31 * l21) * i22;
+                    const double d3 = f - l31 * l31 - l32 * l32;
+                    i33 = rsqrt_d(d3);
                     if (!(a > 0) || !(d2 > 0) || !(d3 > 0) || !isfinite(i11 * i22 * i33)) P.flag[0] = 0;
                     u0 = blv[0] * i11; u1 = (blv[1] - l21 * u0) * i22; u2 = (blv[2] - l31 * u0 - l32 * u1) * i33;      // L^-1 bl
                 }
@@ -3000,7 +3010,8 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
             rho = (current - temp) / scale;
             if (trials < P.debug_reject) rho = -1.0;                // (test hook: drives the ten-rejections Terminate path)
             if (rho > 0 && isfinite(temp)) {
-                double alpha = 1. - pow((2 * rho - 1), 3);
+                const double t3 = 2 * rho - 1;
+                double alpha = 1. - t3 * t3 * t3;                                          // (pow(x, 3) of the reference to an ulp or two)
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
                 ni = 2; current = temp; chi2_carried = temp;
@@ -3033,36 +3044,96 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
 // 12 iterations of a 6-dof problem -- and poseBundleAdjust runs on EVERY non-keyframe, mapper_helpers.cpp:1043-1050); here a 256-thread workgroup keeps
 // the trial in registers: one sweep over the observations accumulates H (21 entries), b and the robust chi2 per thread, one reduction, lane 0 factors the
 // 6 x 6 matrix, one more sweep gives the chi2 of the moved pose.  Same LM schedule, same arithmetic per edge as k_ba_lm.
-constexpr int PO_NT = 256, PO_K = 8, PO_MAXE = 8;       // threads; observations a thread keeps in registers; SE3 edges with constants in LDS
-__device__ __forceinline__ void po_block_sum(double v, double *s_w, int slot) {      // s_w: [4 waves][32 slots]
-    v = wave_sum_d(v);
-    if ((threadIdx.x & 63) == 0) s_w[(threadIdx.x >> 6) * 32 + slot] = v;
+// Round 4: the stamps showed 45 % of the kernel in its reductions (28 sums x 6 ds_bpermute steps, three barriers per sweep), 20 % in the observations and 18 % in
+// the one SE3 edge's logarithm on the thread that also had the most observations -- and two sweeps per iteration where one is enough:
+//   * every sweep linearises.  The trial's sweep at the moved pose already holds H and b of the NEXT iteration when the trial is accepted (g2o linearises the
+//     same state again, optimizable_graph / sparse_optimizer computeActiveErrors + linearizeSystem), and a rejected trial keeps the old H, b in registers: 1 + trials
+//     sweeps instead of 2 + iterations + trials, and the per-observation chi2 of the accepted state stays in registers, so the closing sweep goes too;
+//   * the 28 sums go through LDS transposed: every thread writes its 28 partial sums (value-major rows of PO_ROW doubles), 8 lanes per value add 32 entries each
+//     and meet over the DPP network (3 steps): two barriers, ~100 instructions;
+//   * waves 0-2 take the observations (PO_K per thread in registers), wave 3 takes the SE3 edges, so the logarithm runs beside the observations.  One wave per
+//     SIMD: the whole 512-register file is each wave's (a 512-thread version, two waves per SIMD, spilled ~200 dwords per trial and was no faster than round 3's).
+constexpr int PO_NT = 256, PO_OT = 192, PO_K = 8, PO_MAXE = 8, PO_NV = 28;       // threads; threads with observations; observations a thread keeps in registers; SE3 edges; sums per sweep
+constexpr int PO_ROW = PO_NT + 8;                            // row stride (doubles) of the transposed partial sums: 8 mod 32, so the 8 values x 8 parts a wave reads spread over all banks
+constexpr size_t kPoLdsBytes = (size_t)PO_NV * PO_ROW * sizeof(double);
+static_assert(8 * PO_NV <= PO_NT, "stage 2 of the reduction: 8 lanes per sum");
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {               // the double of the lane the DPP control names (all source lanes active)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 
+// an SE3 edge of a pose-only problem, once per solve (out of line: its two 6 x 6 Jacobians are not to cost the solver's loop registers): between fixed poses its
+// chi2 is a constant (returned); one that touches the free pose leaves its fixed side's transform, -J^T W and J^T W J in LDS
+__device__ __noinline__ double po_edge_setup(const BaProb &P, int k, int pi, int *s_ne, int *s_eSide, double *s_eC, double *s_eM, double *s_eG, double *s_eW, double *s_Hc) {
+    const int vi = P.edge_i[k], vj = P.edge_j[k];
+    const double *W = P.edge_info + 36 * (size_t)k;
+    double e[6], Ji[36], Jj[36], cacc = 0;
+    pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+    if (vi != pi && vj != pi) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j]; return cacc; }
+    const int sl = atomicAdd(s_ne, 1), side = vi == pi ? 0 : 1;
+    const double *J = side ? Jj : Ji;
+    s_eSide[sl] = side;
+    if (side == 0) { double Tjinv[7], A2[7]; se3_inv(P.pose0 + 7 * (size_t)vj, Tjinv); se3_mul(Tjinv, P.edge_meas + 7 * (size_t)k, A2); for (int i = 0; i < 7; ++i) s_eC[8 * sl + i] = A2[i]; }
+    else for (int i = 0; i < 7; ++i) { s_eC[8 * sl + i] = P.pose0[7 * (size_t)vi + i]; s_eM[8 * sl + i] = P.edge_meas[7 * (size_t)k + i]; }
+    for (int i = 0; i < 36; ++i) s_eW[36 * sl + i] = W[i];
+    for (int a = 0; a < 6; ++a)                                     // G = -J^T W
+        for (int c = 0; c < 6; ++c) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += J[6 * r2 + a] * W[6 * r2 + c]; s_eG[36 * sl + 6 * a + c] = -v; }
+    int kk = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b2 = a; b2 < 6; ++b2) {
+            double v = 0;
+            for (int r2 = 0; r2 < 6; ++r2) { double m = 0; for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * J[6 * c2 + b2]; v += J[6 * r2 + a] * m; }
+            atomicAdd(&s_Hc[kk++], v);
+        }
+    return 0.0;
+}
+
+#ifndef MS_PO_PROF
+#define MS_PO_PROF 0            // 1: cycle stamps per phase in stats[8 .. 12) (tools/pose_only_prof.py; each stamp is an s_memtime and a wait, ~10 % of the kernel together)
+#endif
+#if MS_PO_PROF
+#define PO_CLOCK() clock64()
+#else
+#define PO_CLOCK() 0ll
+#endif
 __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
-    __shared__ double s_w[4 * 32], s_sum[32];
+    extern __shared__ __attribute__((aligned(16))) double po_red[];         // [PO_NV][PO_ROW]
+    __shared__ __attribute__((aligned(16))) double s_sum[2][32];       // the sums of the last two sweeps: [cur] belongs to the accepted state (its H and b), the other to the trial
     __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
-    __shared__ int s_eSide[PO_MAXE], s_ne;
+    __shared__ int s_eSide[PO_MAXE], s_ne, s_any;
     const BaProb &P = probs[blockIdx.x];
     const int tid = threadIdx.x, pi = P.free2pose[0];
     for (int i = tid; i < 7 * P.n_pose; i += PO_NT) P.pose[i] = P.pose0[i];
     for (int i = tid; i < 3 * P.n_point; i += PO_NT) P.point[i] = P.point0[i];
     if (tid < 24) s_Hc[tid] = 0;
-    if (tid == 0) { s_ne = 0; s_const = 0; }
+    if (tid == 0) { s_ne = 0; s_const = 0; s_any = P.n_obs; }
+    __syncthreads();
+    {   // the first observation of the free pose
+        int mine = P.n_obs;
+        for (int o = tid; o < P.n_obs; o += PO_NT) if (P.obs_pose[o] == pi) { mine = o; break; }
+        if (mine < P.n_obs) atomicMin(&s_any, mine);
+    }
     __syncthreads();
     double pose[7];
 #pragma unroll
     for (int a = 0; a < 7; ++a) pose[a] = P.pose0[7 * (size_t)pi + a];
-    // ---- what never changes: the observations of the free pose go into registers (PO_K per thread), the others' chi2 and the edges between fixed poses
-    //      into one constant; an edge that touches the free pose leaves its fixed side's transform, -J^T W and J^T W J in LDS (its Jacobian does not depend
+    // ---- what never changes: the observations of the free pose go into registers (PO_K per thread of waves 0-2), the others' chi2 and the edges between fixed
+    //      poses into one constant; an edge that touches the free pose leaves its fixed side's transform, -J^T W and J^T W J in LDS (its Jacobian does not depend
     //      on the free pose: Ji = adj(Tj^-1 M), Jj = -adj(Ti^-1 M^-1)), so a sweep only takes its logarithm
-    double X[PO_K][3], uv[PO_K][2], info[PO_K], cacc = 0;
+    double X[PO_K][3], uv[PO_K][2], info[PO_K], c2[PO_K], c2t[PO_K], cacc = 0;
     unsigned have = 0;
+    const int o_any = s_any;                                                // an observation of the free pose (n_obs: there is none)
+    double Xd[3] = {0, 0, 1}, uvd[2] = {0, 0};
+    if (o_any < P.n_obs) {
+        const int l = P.obs_point[o_any];
+        Xd[0] = P.point0[3 * (size_t)l]; Xd[1] = P.point0[3 * (size_t)l + 1]; Xd[2] = P.point0[3 * (size_t)l + 2];
+        uvd[0] = P.obs_uv[2 * (size_t)o_any]; uvd[1] = P.obs_uv[2 * (size_t)o_any + 1];
+    }
 #pragma unroll
     for (int j = 0; j < PO_K; ++j) {
-        const int o = tid + PO_NT * j;
-        X[j][0] = X[j][1] = X[j][2] = uv[j][0] = uv[j][1] = info[j] = 0;
-        if (o < P.n_obs) {
+        const int o = tid + PO_OT * j;
+        X[j][0] = Xd[0]; X[j][1] = Xd[1]; X[j][2] = Xd[2]; uv[j][0] = uvd[0]; uv[j][1] = uvd[1]; info[j] = c2[j] = c2t[j] = 0;
+        if (tid < PO_OT && o < P.n_obs) {
             const int po = P.obs_pose[o], l = P.obs_point[o];
             if (po == pi) {
                 have |= 1u << j;
@@ -3071,6 +3142,10 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
             }
         }
     }
+    // slots this wave sweeps: observation tid + PO_OT j exists for j < (n_obs - tid) / PO_OT, most for the wave's first lane (wave 3, the edges' wave, and a problem
+    // without observations of the free pose: none)
+    const int w0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int jn = (w0 < PO_OT && o_any < P.n_obs && P.n_obs > w0) ? min(PO_K, (P.n_obs - w0 + PO_OT - 1) / PO_OT) : 0;
     for (int o = tid; o < P.n_obs; o += PO_NT) {                            // observations from FIXED poses: constant
         const int po = P.obs_pose[o];
         if (po == pi) continue;
@@ -3081,103 +3156,106 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
         P.chi2_obs[o] = chi2;
         cacc += r;
     }
-    if (tid < P.n_edge) {
-        const int k = tid, vi = P.edge_i[k], vj = P.edge_j[k];
-        const double *W = P.edge_info + 36 * (size_t)k;
-        double e[6], Ji[36], Jj[36];
-        pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
-        if (vi != pi && vj != pi) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j]; }
-        else {
-            const int sl = atomicAdd(&s_ne, 1), side = vi == pi ? 0 : 1;
-            const double *J = side ? Jj : Ji;
-            s_eSide[sl] = side;
-            if (side == 0) { double Tjinv[7], A2[7]; se3_inv(P.pose0 + 7 * (size_t)vj, Tjinv); se3_mul(Tjinv, P.edge_meas + 7 * (size_t)k, A2); for (int i = 0; i < 7; ++i) s_eC[sl][i] = A2[i]; }
-            else for (int i = 0; i < 7; ++i) { s_eC[sl][i] = P.pose0[7 * (size_t)vi + i]; s_eM[sl][i] = P.edge_meas[7 * (size_t)k + i]; }
-            for (int i = 0; i < 36; ++i) s_eW[sl][i] = W[i];
-            for (int a = 0; a < 6; ++a)                                     // G = -J^T W
-                for (int c = 0; c < 6; ++c) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += J[6 * r2 + a] * W[6 * r2 + c]; s_eG[sl][6 * a + c] = -v; }
-            int kk = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int b2 = a; b2 < 6; ++b2) {
-                    double v = 0;
-                    for (int r2 = 0; r2 < 6; ++r2) { double m = 0; for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * J[6 * c2 + b2]; v += J[6 * r2 + a] * m; }
-                    lds_addd((MS_LDS double *)&s_Hc[kk++], v);
-                }
-        }
-    }
+    if (tid < P.n_edge) cacc += po_edge_setup(P, tid, pi, &s_ne, s_eSide, &s_eC[0][0], &s_eM[0][0], &s_eG[0][0], &s_eW[0][0], s_Hc);
     cacc = wave_sum_d(cacc);
     if ((tid & 63) == 0) lds_addd((MS_LDS double *)&s_const, cacc);
     __syncthreads();
     const int ne = s_ne;
-    // ---- one sweep over the free pose's edges: robust chi2, and (lin) the upper triangle of H and b
-    auto sweep = [&](bool lin, bool store) {
+    const bool overflow = P.n_obs > PO_OT * PO_K;                           // more observations than the registers take: those come from memory in every sweep
+    long long pc[4] = {0, 0, 0, 0};                                         // cycles of thread 0: a sweep's observations, (thread PO_OT:) its SE3 edges, its reduction, the 6 x 6 solve + exp
+    const long long t_begin = clock64();
+    int cur = 1;                                                            // which half of s_sum belongs to the accepted state
+    // ---- one sweep over the free pose's edges at `pose`: the robust chi2 (returned), the upper triangle of H and b (left in s_sum[1 - cur][0 .. 27)), the chi2 per observation in c2t
+    auto sweep = [&]() {
         double A[21], g[6], acc = 0;
+        long long ts = PO_CLOCK();
 #pragma unroll
         for (int a = 0; a < 21; ++a) A[a] = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) g[a] = 0;
-        auto one = [&](const double *Xo, const double *uvo, double inf, int o) {
+        auto one = [&](const double *Xo, const double *uvo, double inf) {
             double e[2], Jp[12], Jl[6];
-            if (lin) proj_edge<true>(pose, Xo, uvo, e, Jp, Jl); else proj_edge<false>(pose, Xo, uvo, e, nullptr, nullptr);
+            proj_edge<true>(pose, Xo, uvo, e, Jp, Jl);
             const double chi2 = inf * (e[0] * e[0] + e[1] * e[1]);
             double r, w;
             huber(chi2, P.huber, r, w);
-            if (store) P.chi2_obs[o] = chi2;
             acc += r;
-            if (lin) {
-                const double wi = w * inf;
-                int k = 0;
+            const double wi = w * inf;
+            int k = 0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    g[a] += -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi;
+            for (int a = 0; a < 6; ++a) {
+                g[a] += -(Jp[a] * e[0] + Jp[6 + a] * e[1]) * wi;
 #pragma unroll
-                    for (int b2 = a; b2 < 6; ++b2) A[k++] += wi * (Jp[a] * Jp[b2] + Jp[6 + a] * Jp[6 + b2]);
-                }
+                for (int b2 = a; b2 < 6; ++b2) A[k++] += wi * (Jp[a] * Jp[b2] + Jp[6 + a] * Jp[6 + b2]);
             }
+            return chi2;
         };
+        // slots in pairs, both evaluations in one basic block so that the scheduler interleaves their chains (a lone wave per SIMD has nothing else to hide the
+        // fp64 latency with); a slot without an observation holds a copy of a real one with information 0: finite arithmetic, nothing added
 #pragma unroll
-        for (int j = 0; j < PO_K; ++j) if ((have >> j) & 1u) one(X[j], uv[j], info[j], tid + PO_NT * j);
-        for (int o = tid + PO_NT * PO_K; o < P.n_obs; o += PO_NT) {          // more observations than the registers take: from memory
-            if (P.obs_pose[o] != pi) continue;
-            const double Xo[3] = {P.point0[3 * (size_t)P.obs_point[o]], P.point0[3 * (size_t)P.obs_point[o] + 1], P.point0[3 * (size_t)P.obs_point[o] + 2]};
-            const double uvo[2] = {P.obs_uv[2 * (size_t)o], P.obs_uv[2 * (size_t)o + 1]};
-            one(Xo, uvo, P.obs_info[o], o);
+        for (int j = 0; j < PO_K; j += 2) {
+            if (j + 1 < jn) { c2t[j] = one(X[j], uv[j], info[j]); c2t[j + 1] = one(X[j + 1], uv[j + 1], info[j + 1]); }
+            else if (j < jn) c2t[j] = one(X[j], uv[j], info[j]);
         }
-        if (tid < ne) {
+        if (overflow && tid < PO_OT)
+            for (int o = tid + PO_OT * PO_K; o < P.n_obs; o += PO_OT) {
+                if (P.obs_pose[o] != pi) continue;
+                const double Xo[3] = {P.point0[3 * (size_t)P.obs_point[o]], P.point0[3 * (size_t)P.obs_point[o] + 1], P.point0[3 * (size_t)P.obs_point[o] + 2]};
+                const double uvo[2] = {P.obs_uv[2 * (size_t)o], P.obs_uv[2 * (size_t)o + 1]};
+                (void)one(Xo, uvo, P.obs_info[o]);
+            }
+        if (MS_PO_PROF && tid == 0) { const long long t1 = PO_CLOCK(); pc[0] += t1 - ts; }
+        if (tid >= PO_OT && tid - PO_OT < ne) {                             // wave 3: the SE3 edges of the free pose
+            const int k = tid - PO_OT;
             double Bm[7], e[6], We[6];
-            if (s_eSide[tid] == 0) se3_mul(s_eC[tid], pose, Bm);                                    // (Tj^-1 M) Ti
-            else { double Tjinv[7], A2[7]; se3_inv(pose, Tjinv); se3_mul(Tjinv, s_eM[tid], A2); se3_mul(A2, s_eC[tid], Bm); }
+            if (s_eSide[k] == 0) se3_mul(s_eC[k], pose, Bm);                                      // (Tj^-1 M) Ti
+            else { double Tjinv[7], A2[7]; se3_inv(pose, Tjinv); se3_mul(Tjinv, s_eM[k], A2); se3_mul(A2, s_eC[k], Bm); }
             se3_log(Bm, e);
-            for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[tid][6 * i + j] * e[j]; We[i] = v; }
+            for (int i = 0; i < 6; ++i) { double v = 0; for (int j = 0; j < 6; ++j) v += s_eW[k][6 * i + j] * e[j]; We[i] = v; }
             for (int i = 0; i < 6; ++i) acc += e[i] * We[i];
-            if (lin) for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[tid][6 * a + c] * e[c]; g[a] += v; }
+            for (int a = 0; a < 6; ++a) { double v = 0; for (int c = 0; c < 6; ++c) v += s_eG[k][6 * a + c] * e[c]; g[a] += v; }
+            if (MS_PO_PROF && k == 0) pc[1] += PO_CLOCK() - ts;
         }
-        __syncthreads();                                                    // (s_w / s_sum of the previous reduction have been read)
-        po_block_sum(acc, s_w, 27);
-        if (lin) {
+        ts = PO_CLOCK();
+        {
+            MS_LDS double *row = (MS_LDS double *)po_red + tid;
 #pragma unroll
-            for (int a = 0; a < 21; ++a) po_block_sum(A[a], s_w, a);
+            for (int a = 0; a < 21; ++a) row[a * PO_ROW] = A[a];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) po_block_sum(g[a], s_w, 21 + a);
+            for (int a = 0; a < 6; ++a) row[(21 + a) * PO_ROW] = g[a];
+            row[27 * PO_ROW] = acc;
         }
         __syncthreads();
-        if (tid < 28) s_sum[tid] = s_w[tid] + s_w[32 + tid] + s_w[64 + tid] + s_w[96 + tid] + (tid < 21 ? s_Hc[tid] : (tid == 27 ? s_const : 0.0));
+        if (tid < 8 * PO_NV) {                                              // lanes 8 v .. 8 v + 7 add row v up, each 32 entries, then among themselves
+            const int v = tid >> 3, part = tid & 7;
+            const MS_LDS double *row = (const MS_LDS double *)po_red + v * PO_ROW + part;
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int k = 0; k < PO_NT / 8; k += 2) { s0 += row[8 * k]; s1 += row[8 * k + 8]; }
+            double s = s0 + s1;
+            s += dpp_d<0xB1>(s);                                            // quad_perm [1 0 3 2]
+            s += dpp_d<0x4E>(s);                                            // quad_perm [2 3 0 1]
+            s += dpp_d<0x141>(s);                                           // row_half_mirror
+            if (part == 0) s_sum[1 - cur][v] = s + (v < 21 ? s_Hc[v] : (v == 27 ? s_const : 0.0));
+        }
         __syncthreads();
-        return s_sum[27];
+        if (MS_PO_PROF && tid == 0) pc[2] += PO_CLOCK() - ts;
+        return s_sum[1 - cur][27];
     };
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, stop = 0;
-    const double chi2_init = sweep(false, false);
+    auto accept = [&]() {                                                   // the swept state becomes the current one: its H, b (the other half of s_sum) and per-observation chi2
+        cur = 1 - cur;
+#pragma unroll
+        for (int j = 0; j < PO_K; ++j) c2[j] = c2t[j];
+    };
+    const double chi2_init = sweep();
+    accept();
     double chi2_carried = chi2_init;
     for (it = 0; it < P.max_iters; ++it) {
         double current = chi2_carried, temp = current;
-        (void)sweep(true, false);
-        double H[21], b[6];
-#pragma unroll
-        for (int a = 0; a < 21; ++a) H[a] = s_sum[a];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) b[a] = s_sum[21 + a];
         if (it == 0) {                                                       // computeLambdaInit: 1e-5 x the largest diagonal entry
+            const double *H = s_sum[cur];
             const double md = fmax(fmax(fmax(fabs(H[0]), fabs(H[6])), fmax(fabs(H[11]), fabs(H[15]))), fmax(fabs(H[18]), fabs(H[20])));
             lambda = 1e-5 * md; ni = 2;
         }
@@ -3186,8 +3264,12 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
         do {
             // (H + lambda I) dp = b: Cholesky of the 6 x 6 matrix, by every thread for itself (fully unrolled: 21 + 6 registers, ~150 dependent operations --
             // cheaper than one thread doing it behind a barrier and a trip through LDS)
-            double Lm[21], dpv[6];                                           // lower triangle, row-major: Lm[i (i + 1) / 2 + j]
+            double Lm[21], dpv[6], b[6];                                     // lower triangle, row-major: Lm[i (i + 1) / 2 + j]
             bool ok2 = true;
+            const long long tc = PO_CLOCK();
+            const double *H = s_sum[cur];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) b[a] = H[21 + a];
             {
                 int k = 0;
 #pragma unroll
@@ -3201,7 +3283,7 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
 #pragma unroll
                 for (int k = 0; k < j; ++k) d -= Lm[j * (j + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
                 if (!(d > 0) || !isfinite(d)) ok2 = false;
-                const double lj = sqrt(d), inv = 1.0 / lj;
+                const double inv = rsqrt_d(d);
                 Lm[j * (j + 1) / 2 + j] = inv;                               // the reciprocal pivot is what the substitutions use
 #pragma unroll
                 for (int i = j + 1; i < 6; ++i) {
@@ -3237,16 +3319,19 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
                 for (int a = 0; a < 6; ++a) { dp[a] = dpv[a]; sc += dp[a] * (lambda * dp[a] + b[a]); }
                 se3_exp(dp, ex);
                 se3_mul(ex, bk, pose);                                                      // every thread moves its own copy of the pose: the same arithmetic, the same result
-                temp = sweep(false, false);
+                if (MS_PO_PROF && tid == 0) pc[3] += PO_CLOCK() - tc;
+                temp = sweep();
             } else temp = DBL_MAX;
             const double scale = sc + 1e-3;
             rho = (current - temp) / scale;
             if (trials < P.debug_reject) rho = -1.0;                // (test hook: drives the ten-rejections Terminate path)
             if (rho > 0 && isfinite(temp)) {
-                double alpha = 1. - pow((2 * rho - 1), 3);
+                const double t3 = 2 * rho - 1;
+                double alpha = 1. - t3 * t3 * t3;                                          // (pow(x, 3) of the reference to an ulp or two, without the ~300 instructions of pow)
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
                 ni = 2; current = temp; chi2_carried = temp;
+                accept();                                                                   // (the trial's half of s_sum becomes the current one; the next sweep writes the other, behind its first barrier)
             } else {
                 lambda *= ni; ni *= 2;
 #pragma unroll
@@ -3257,12 +3342,24 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
         } while (rho < 0 && qmax < 10);
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) { stop = 1; ++it; break; }
     }
-    const double chi2_final = sweep(false, true);
+    // the chi2 per observation of the accepted state: from the registers; the observations beyond them are evaluated once more
+#pragma unroll
+    for (int j = 0; j < PO_K; ++j) if ((have >> j) & 1u) P.chi2_obs[tid + PO_OT * j] = c2[j];
+    if (overflow && tid < PO_OT)
+        for (int o = tid + PO_OT * PO_K; o < P.n_obs; o += PO_OT) {
+            if (P.obs_pose[o] != pi) continue;
+            double e[2], Jp[12], Jl[6];
+            proj_edge<true>(pose, P.point0 + 3 * (size_t)P.obs_point[o], P.obs_uv + 2 * (size_t)o, e, Jp, Jl);     // (the arithmetic of the sweeps)
+            P.chi2_obs[o] = P.obs_info[o] * (e[0] * e[0] + e[1] * e[1]);
+        }
+    const double chi2_final = chi2_carried;                                 // the sweep that was accepted last evaluated exactly this state
+    if (tid == PO_OT) P.stats[9] = (double)pc[1];
     if (tid == 0) {
         for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = chi2_final;
         P.stats[6] = isfinite(chi2_final) ? 1 : 0; P.stats[7] = 0;
-        for (int k = 8; k < 16; ++k) P.stats[k] = 0;
+        P.stats[8] = (double)pc[0]; P.stats[10] = (double)pc[2]; P.stats[11] = (double)pc[3]; P.stats[12] = 0;
+        P.stats[13] = (double)(clock64() - t_begin);       // (MS_PO_PROF off: cycles since the kernel started, nothing per phase) P.stats[14] = 0; P.stats[15] = 0;
     }
 }
 
@@ -3314,12 +3411,11 @@ __device__ __forceinline__ int group_sum_i(int v, int lg) {
 struct Chol3 { double i11, l21, l31, i22, l32, i33; };
 __device__ __forceinline__ bool chol3(const double *H, double lambda, Chol3 &c) {
     const double a = H[0] + lambda, d = H[3] + lambda, f = H[5] + lambda;
-    const double l11 = sqrt(a);
-    c.i11 = 1.0 / l11; c.l21 = H[1] * c.i11; c.l31 = H[2] * c.i11;
-    const double d2 = d - c.l21 * c.l21, l22 = sqrt(d2);
-    c.i22 = 1.0 / l22; c.l32 = (H[4] - c.l31 * c.l21) * c.i22;
-    const double d3 = f - c.l31 * c.l31 - c.l32 * c.l32, l33 = sqrt(d3);
-    c.i33 = 1.0 / l33;
+    c.i11 = rsqrt_d(a); c.l21 = H[1] * c.i11; c.l31 = H[2] * c.i11;
+    const double d2 = d - c.l21 * c.l21;
+    c.i22 = rsqrt_d(d2); c.l32 = (H[4] - c.l31 * c.l21) * c.i22;
+    const double d3 = f - c.l31 * c.l31 - c.l32 * c.l32;
+    c.i33 = rsqrt_d(d3);
     return a > 0 && d2 > 0 && d3 > 0 && isfinite(c.i11 * c.i22 * c.i33);
 }
 
@@ -3759,7 +3855,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
 #pragma unroll
                 for (int k = 0; k < j; ++k) d -= Lm[j * (j + 1) / 2 + k] * Lm[j * (j + 1) / 2 + k];
                 if (!(d > 0) || !isfinite(d)) ok2 = false;
-                const double lj = sqrt(d), inv = 1.0 / lj;
+                const double inv = rsqrt_d(d);
                 Lm[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
                 for (int i = j + 1; i < 6; ++i) {
@@ -3828,7 +3924,8 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
             rho = (current - temp) / scale;
             if (trials < P.debug_reject) rho = -1.0;                // (test hook: drives the ten-rejections Terminate path)
             if (rho > 0 && isfinite(temp)) {
-                double alpha = 1. - pow((2 * rho - 1), 3);
+                const double t3 = 2 * rho - 1;
+                double alpha = 1. - t3 * t3 * t3;                                          // (pow(x, 3) of the reference to an ulp or two)
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
                 ni = 2; current = temp; chi2_carried = temp;
@@ -3894,6 +3991,13 @@ struct ms_ba {
     int debug_fail_barriers = 0;       // test hook: team barriers give up at once (ms_ba_debug_fail_team_barriers)
     int team_fallbacks = 0;            // launches repeated with one workgroup per problem after a team barrier gave up
     int solves = 0;                    // launches so far (ms_ba_copy_state refuses a source that has never been solved)
+    // a single small problem (poseBundleAdjust): its results are packed and copied into h_result right behind the solver launch, so that ms_ba_download only
+    // waits for ev_done and reads them -- no pack launch and device-to-host round trip after the wait (0.03 ms of a 0.08 ms solve)
+    void *h_result = nullptr;          // page-locked, stays with the handle OBJECT (pooled per context)
+    size_t h_result_bytes = 0, pack_doubles = 0;
+    double *d_pack = nullptr;          // in the arena; nullptr: no eager results for this handle
+    bool eager = false;                // h_result holds the last launch's results
+    bool quiet = false;                // everything this handle put on the stream is known to have finished (ev_done was seen, nothing enqueued since): ms_ba_destroy need not wait
     hipEvent_t ev_done = nullptr;      // the end of this handle's last launch (what reads its results waits for it ON THE HOST, politely: ba_wait_event)
     bool pending = false;
 };
@@ -3910,27 +4014,44 @@ static int g_team_query_errors = 0;        // hipEventQuery answers other than s
 // enqueues anything -- not with hipStreamSynchronize, and not with a wait packet behind the launch (round 4, tools/hog_probe.py: a stream with packets queued behind
 // a 2 ms kernel slowed the front end of ANOTHER sequence 10 ... 90 x, one that holds one launch at a time 3 ... 15 x).
 static int ba_launch_done(ms_ctx *c, ms_ba *B) {
+    B->quiet = false;
     if (!B->ev_done) { MS_HIP(c, hipEventCreateWithFlags(&B->ev_done, hipEventDisableTiming)); ++g_ba_host_allocs; }
     MS_HIP(c, hipEventRecord(B->ev_done, c->stream));
     B->pending = true;
     return MS_OK;
 }
+static void ba_delete_object(ms_ba *B) {
+    if (B->ev_done) (void)hipEventDestroy(B->ev_done);
+    if (B->h_result) (void)hipHostFree(B->h_result);
+    delete B;
+}
 // A host wait for a solver launch (milliseconds) that leaves the processor to the other sequences' threads: hipStreamSynchronize / hipEventSynchronize spin, and
 // seven threads spinning in them made the thread that drives another sequence's front end 3 ... 15 x slower (tools/hog_probe.py: x 3.3 beside two streams whose
 // threads wait in hipStreamSynchronize, x 1.09 beside the same streams with the threads asleep) -- on this runtime a waiting thread is not free for the others.
+// Two phases: for the first ~120 us the event is polled with a yield in between (poseBundleAdjust's launch is 0.08 ms: a frame must not pay a timer's granularity
+// for it), after that the thread sleeps 20 us at a time, with its timer slack set to 1 us once (the default 50 us slack turned every 25 us sleep into ~75 us:
+// 0.18 ms in ms_ba_download for a 0.08 ms kernel, tools/pose_path_probe.py).
 static int ba_wait_event(ms_ctx *c, hipEvent_t ev) {
-    for (int i = 0;; ++i) {
+    thread_local bool slack_set = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (bool spinning = true;;) {
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) return MS_OK;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); return ms_fail(c, MS_ERR_HIP, "waiting for a solver launch failed: %s", hipGetErrorString(q)); }
-        if (i < 4) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(25));
+        if (spinning) {
+            std::this_thread::yield();
+            spinning = std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(120);
+        } else {
+            if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }      // (nanoseconds; the calling thread only)
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
     }
 }
 static int ba_wait_pending(ms_ba *B) {
     if (!B->pending) return MS_OK;
     MS_TRY_BA(ba_wait_event(B->ctx, B->ev_done));
     B->pending = false;
+    B->quiet = true;
     return MS_OK;
 }
 
@@ -3999,8 +4120,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     bvec<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
-    struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red; };
+    constexpr size_t kBaEagerMax = (size_t)64 << 10;       // results of a single problem up to this size are packed and copied behind every launch (ms_ba struct: h_result)
+constexpr size_t kBaStageMax = (size_t)4 << 20;        // creates whose inputs fit are uploaded from the context's page-locked staging block without a wait
+struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red, pack; };
     bvec<Off> off(n);
     bvec<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -4424,6 +4547,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
         O.bar = bump(256); O.red = bump(4 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
         O.op_rec = bump(R.one_pose ? 28 * (size_t)Q.n_point * D : 8); O.op_red = bump(R.one_pose ? 2 * (size_t)kMaxTeam * OP_NV * D : 8);
+        // a single small problem gets its results packed behind every launch (ba_after_launch): status, poses, points, chi2 per observation
+        const size_t pack_doubles = 16 + 7 * (size_t)Q.n_pose + 3 * (size_t)Q.n_point + (size_t)Q.n_obs;
+        O.pack = bump(n == 1 && pack_doubles * D <= kBaEagerMax ? pack_doubles * D : 8);
     }
     const double tm1 = tm_now();
     ms_ba *B = nullptr;
@@ -4448,10 +4574,39 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                 for (auto &b : c->ba_cache) if (b.p) { (void)hipFree(b.p); b = {}; }
                 e = hipMalloc(reinterpret_cast<void **>(&B->d_arena), need);
             }
-            if (e != hipSuccess) { (void)hipGetLastError(); delete B; return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes: %s", need, hipGetErrorString(e)); }
+            if (e != hipSuccess) { (void)hipGetLastError(); ba_delete_object(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes: %s", need, hipGetErrorString(e)); }
             B->arena_bytes = need;
         }
         B->d_probs = reinterpret_cast<BaProb *>(B->d_arena + probs_at);
+    }
+    // small creates (a pose-only problem per frame, a window per keyframe) stage all their inputs in the context's own page-locked block and do not wait for the copies
+    size_t stage_need = sizeof(BaProb) * n, stage_at = 0;
+    for (int p = 0; p < n; ++p) stage_need += ms_align_up(in_hi[p] - in_lo[p], (size_t)256);
+    const bool staged = stage_need <= kBaStageMax;
+    if (staged) {
+        if (c->ba_stage_busy) { (void)hipEventSynchronize(c->ba_stage_ev); c->ba_stage_busy = false; }      // (the previous create's upload: long done)
+        hipError_t e = hipSuccess;
+        if (!c->ba_stage_ev) { e = hipEventCreateWithFlags(&c->ba_stage_ev, hipEventDisableTiming); ++g_ba_host_allocs; }
+        if (e == hipSuccess && c->ba_stage_bytes < stage_need) {
+            if (c->ba_stage) (void)hipHostFree(c->ba_stage);
+            c->ba_stage = nullptr; c->ba_stage_bytes = 0;
+            const size_t want = std::min(kBaStageMax, ms_align_up(stage_need + stage_need / 4, (size_t)1 << 16));
+            e = hipHostMalloc(&c->ba_stage, want, hipHostMallocDefault); ++g_ba_host_allocs;
+            if (e == hipSuccess) c->ba_stage_bytes = want;
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: staging block: %s", hipGetErrorString(e)); }
+    }
+    {   // the eager results of a single small problem: a page-locked block that stays with the handle object
+        const size_t pack_doubles = n == 1 ? 16 + 7 * (size_t)problems[0].n_pose + 3 * (size_t)problems[0].n_point + (size_t)problems[0].n_obs : 0;
+        B->pack_doubles = pack_doubles * sizeof(double) <= kBaEagerMax ? pack_doubles : 0;
+        if (B->pack_doubles * sizeof(double) > B->h_result_bytes) {
+            if (B->h_result) (void)hipHostFree(B->h_result);
+            B->h_result = nullptr; B->h_result_bytes = 0;
+            const size_t want = ms_align_up(B->pack_doubles * sizeof(double) * 2, (size_t)4096);
+            const hipError_t e = hipHostMalloc(&B->h_result, want, hipHostMallocDefault); ++g_ba_host_allocs;
+            if (e != hipSuccess) { (void)hipGetLastError(); ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: result block: %s", hipGetErrorString(e)); }
+            B->h_result_bytes = want;
+        }
     }
     {
         const hipError_t e = hipMemsetAsync(B->d_arena, 0, total, c->stream);
@@ -4462,8 +4617,12 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         const ms_ba_problem &Q = problems[p]; const Prep &R = prep[p]; const Off &O = off[p]; const size_t D = sizeof(double);
         // the problem's input block is assembled in the context's page-locked staging and goes up in ONE copy the copy engine reads directly
         const size_t stage_bytes = in_hi[p] - in_lo[p];
-        if (ms_pinned(c, stage_bytes) != MS_OK) { ms_ba_destroy(B); return MS_ERR_HIP; }
-        char *stage = static_cast<char *>(c->pinned);
+        char *stage = nullptr;
+        if (staged) { stage = static_cast<char *>(c->ba_stage) + stage_at; stage_at += ms_align_up(stage_bytes, (size_t)256); }
+        else {
+            if (ms_pinned(c, stage_bytes) != MS_OK) { ms_ba_destroy(B); return MS_ERR_HIP; }
+            stage = static_cast<char *>(c->pinned);
+        }
         std::memset(stage, 0, stage_bytes);
         auto up = [&](size_t o, const void *src, size_t bytes) { if (bytes) std::memcpy(stage + (o - in_lo[p]), src, bytes); };
         up(O.pose0, Q.pose, 7 * Q.n_pose * D); up(O.point0, Q.point, 3 * Q.n_point * D);
@@ -4486,8 +4645,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
         up(O.op_pose, R.op_pose.data(), 4 * R.op_pose.size()); up(O.op_o, R.op_o.data(), 4 * R.op_o.size()); up(O.op_uvi, R.op_uvi.data(), sizeof(double) * R.op_uvi.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
+        // (the shared staging block is written again for the next problem: wait; the context's own block holds every problem's inputs side by side: no wait)
         if (hipMemcpyAsync(B->d_arena + in_lo[p], stage, stage_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
+            (!staged && hipStreamSynchronize(c->stream) != hipSuccess)) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
         BaProb &H = B->host[p];
         char *a = B->d_arena;
         H.n_pose = Q.n_pose; H.n_point = Q.n_point; H.n_obs = Q.n_obs; H.n_edge = Q.n_pose_edge; H.np_free = R.np_free; H.n6 = 6 * R.np_free;
@@ -4526,6 +4686,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.op_pose = R.one_pose ? PTR(int32_t, op_pose) : nullptr; H.op_o = R.one_pose ? PTR(int32_t, op_o) : nullptr; H.op_uvi = R.one_pose ? PTR(double, op_uvi) : nullptr;
         H.op_rec = R.one_pose ? PTR(double, op_rec) : nullptr; H.op_red = R.one_pose ? PTR(double, op_red) : nullptr;
         if (p == 0) B->one_pose = R.one_pose; else B->one_pose = B->one_pose && R.one_pose;
+        if (n == 1 && B->pack_doubles) B->d_pack = PTR(double, pack);
         B->chol_tiles.push_back(R.chol_tiles);
         {   // poseBundleAdjust-shaped: one free pose, no free point
             bool po = R.np_free == 1 && problems[p].n_pose_edge <= PO_MAXE;
@@ -4534,12 +4695,28 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
 #undef PTR
     }
-    if (hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOpLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOpLdsBytes) != hipSuccess) {
-        ms_ba_destroy(B);
-        return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
+    {
+        hipError_t e;
+        if (staged) {                                       // the descriptors follow the inputs out of the same block; its next user waits for ba_stage_ev
+            std::memcpy(static_cast<char *>(c->ba_stage) + stage_at, B->host.data(), sizeof(BaProb) * n);
+            e = hipMemcpyAsync(B->d_probs, static_cast<char *>(c->ba_stage) + stage_at, sizeof(BaProb) * n, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ba_stage_ev, c->stream);
+            c->ba_stage_busy = e == hipSuccess;
+        } else e = hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice);
+        // the solvers' dynamic LDS sizes: once per device and process
+        static std::atomic<unsigned long long> attr_done{0};
+        if (e == hipSuccess && !((attr_done.load() >> (c->device & 63)) & 1ull)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_pose_only), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOpLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(k_ba_one_pose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOpLdsBytes) != hipSuccess) e = hipErrorUnknown;
+            else attr_done.fetch_or(1ull << (c->device & 63));
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ms_ba_destroy(B);
+            return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
+        }
     }
     if (tm_on) std::fprintf(stderr, "ms_ba_create: prep %.3f ms (CSR + envelope %.3f, record lists + panel lists %.3f, fused-pass batches %.3f, rest %.3f), alloc+upload %.3f ms, arena %.1f MB\n",
                             tm1 - tm0, tm_part[0], tm_part[2], tm_part[3], tm1 - tm0 - tm_part[0] - tm_part[2] - tm_part[3], tm_now() - tm1, total / 1e6);
@@ -4551,8 +4728,11 @@ void ms_ba_destroy(ms_ba *B) {
     if (!B) return;
     (void)hipSetDevice(B->ctx->device);
     if (B->pending) (void)ba_wait_event(B->ctx, B->ev_done);
-    (void)hipStreamSynchronize(B->ctx->stream);
-    {   // every team launch of this stream has finished: its entries leave the admission list now, before the stream itself can go away (an event
+    // (a handle whose last launch has been waited for and that enqueued nothing since leaves the stream alone: hipStreamSynchronize on a stream the runtime has
+    //  not itself seen idle costs ~15 us, per frame for poseBundleAdjust)
+    const bool synced = !B->quiet || B->pending;
+    if (synced) (void)hipStreamSynchronize(B->ctx->stream);
+    if (synced) {   // every team launch of this stream has finished: its entries leave the admission list now, before the stream itself can go away (an event
         // queried after its stream was destroyed answered "operation not permitted on an event last recorded in a capturing stream" once in ~20 runs)
         std::lock_guard<std::mutex> lk(g_team_mu);
         for (TeamLaunch &t : g_team_live[B->ctx->device & 63]) if (t.live && t.stream == B->ctx->stream) t.live = false;
@@ -4578,16 +4758,17 @@ void ms_ba_destroy(ms_ba *B) {
         for (void *&sl : c->ba_handle_pool) if (!sl) { slot = &sl; break; }
         if (slot) {
             const hipEvent_t ev = B->ev_done;
+            void *const hres = B->h_result; const size_t hres_bytes = B->h_result_bytes;
             std::vector<BaProb> host = std::move(B->host); std::vector<ms_ba_problem> dims = std::move(B->dims); std::vector<double> tiles = std::move(B->chol_tiles);
             host.clear(); dims.clear(); tiles.clear();
             *B = ms_ba();
             B->host = std::move(host); B->dims = std::move(dims); B->chol_tiles = std::move(tiles); B->ev_done = ev;
+            B->h_result = hres; B->h_result_bytes = hres_bytes;
             *slot = B;
             return;
         }
-        if (B->ev_done) (void)hipEventDestroy(B->ev_done);
     }
-    delete B;
+    ba_delete_object(B);
 }
 
 int ms_ba_set_team(ms_ba *B, int workgroups_per_problem) {
@@ -4602,6 +4783,18 @@ int ms_ba_set_factor_team(ms_ba *B, int workgroups) {
     return MS_OK;
 }
 
+// what follows every solver launch of ms_ba_solve: the eager results of a small single problem, then the handle's completion event
+static int ba_after_launch(ms_ctx *c, ms_ba *B) {
+    B->eager = false;
+    if (B->d_pack) {
+        hipLaunchKernelGGL(k_ba_pack_result, dim3((unsigned)std::min<size_t>(ms_div_up((int)B->pack_doubles, 256), 256)), dim3(256), 0, c->stream, B->d_probs, 0, B->d_pack, 1);
+        MS_KERNEL_CHECK(c, "k_ba_pack_result");
+        MS_HIP(c, hipMemcpyAsync(B->h_result, B->d_pack, B->pack_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        B->eager = true;
+    }
+    return ba_launch_done(c, B);
+}
+
 int ms_ba_solve(ms_ba *B) {
     MsRange range("ms_ba_solve");
     if (!B) return MS_ERR_INVALID;
@@ -4613,10 +4806,10 @@ int ms_ba_solve(ms_ba *B) {
     // (all its workgroups must be resident for the barriers), hence the cooperative launch below.  Automatic choice: as many
     // workgroups per problem as fit, at most 32 (beyond that the single-workgroup Cholesky dominates).
     if (B->pose_only && B->team <= 1 && !std::getenv("MS_BA_NO_POSE_KERNEL")) {      // (an explicit team request keeps the general kernel: tests compare the two)
-        hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), 0, ls, B->d_probs);
+        hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), kPoLdsBytes, ls, B->d_probs);
         MS_KERNEL_CHECK(c, "k_ba_pose_only");
         B->launched_team = 1; B->team_checked = true; B->last_one_pose = false; ++B->solves;
-        return ba_launch_done(c, B);
+        return ba_after_launch(c, B);
     }
     int most_obs = 0, most_points = 0, most_poses = 0;
     for (const auto &h : B->host) { most_obs = std::max(most_obs, h.n_obs); most_points = std::max(most_points, h.n_point); most_poses = std::max(most_poses, h.n_pose); }
@@ -4710,7 +4903,7 @@ int ms_ba_solve(ms_ba *B) {
     B->launched_team = team;
     B->team_checked = team == 1;
     ++B->solves;
-    return ba_launch_done(c, B);
+    return ba_after_launch(c, B);
 }
 
 // one workgroup per problem, no team barriers: the fallback after a team barrier gave up
@@ -4718,6 +4911,7 @@ static int ba_relaunch_single(ms_ba *B) {
     ms_ctx *c = B->ctx;
     const hipStream_t ls = c->stream;
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
+    B->eager = false;                                              // (what h_result holds belongs to the void launch)
     MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, ls));
     if (B->last_one_pose) {
         int most_poses = 0, most_points = 0;
@@ -4772,15 +4966,21 @@ int ms_ba_download(ms_ba *B, int i, double *pose, double *point, double *chi2_pe
     const bool want_chi2 = chi2_per_obs && H.n_obs;
     const size_t n_st = 16, n_pose7 = 7 * (size_t)H.n_pose, n_pt3 = 3 * (size_t)H.n_point, n_all = n_st + n_pose7 + n_pt3 + (want_chi2 ? (size_t)H.n_obs : 0);
     void *scr = nullptr;
-    MS_TRY_BA(ms_scratch(c, n_all * sizeof(double), &scr));
-    MS_TRY_BA(ms_pinned(c, n_all * sizeof(double)));
+    if (!B->eager) {
+        MS_TRY_BA(ms_scratch(c, n_all * sizeof(double), &scr));
+        MS_TRY_BA(ms_pinned(c, n_all * sizeof(double)));
+    }
     const double *st = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        hipLaunchKernelGGL(k_ba_pack_result, dim3((unsigned)std::min<size_t>(ms_div_up((int)std::min<size_t>(n_all, 1u << 30), 256), 256)), dim3(256), 0, c->stream, B->d_probs, i, static_cast<double *>(scr), want_chi2 ? 1 : 0);
-        MS_KERNEL_CHECK(c, "k_ba_pack_result");
-        MS_HIP(c, hipMemcpyAsync(c->pinned, scr, n_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        MS_HIP(c, hipStreamSynchronize(c->stream));
-        st = static_cast<const double *>(c->pinned);
+        if (B->eager) st = static_cast<const double *>(B->h_result);       // packed and copied behind the launch: the wait above covered it (chi2 always included)
+        else {
+            if (!scr) { MS_TRY_BA(ms_scratch(c, n_all * sizeof(double), &scr)); MS_TRY_BA(ms_pinned(c, n_all * sizeof(double))); }
+            hipLaunchKernelGGL(k_ba_pack_result, dim3((unsigned)std::min<size_t>(ms_div_up((int)std::min<size_t>(n_all, 1u << 30), 256), 256)), dim3(256), 0, c->stream, B->d_probs, i, static_cast<double *>(scr), want_chi2 ? 1 : 0);
+            MS_KERNEL_CHECK(c, "k_ba_pack_result");
+            MS_HIP(c, hipMemcpyAsync(c->pinned, scr, n_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            MS_HIP(c, hipStreamSynchronize(c->stream));
+            st = static_cast<const double *>(c->pinned);
+        }
         if (B->team_checked || st[7] == 0) break;            // a team barrier gave up: solve again without a team, then fetch again
         MS_TRY_BA(ba_relaunch_single(B));
     }
@@ -4820,6 +5020,7 @@ int ms_ba_copy_state(ms_ba *dst, const ms_ba *src, const int32_t *extra_pose_src
         d_extra = static_cast<int32_t *>(scr);
         MS_HIP(c, hipMemcpyAsync(d_extra, extra_pose_src, sizeof(int32_t) * (size_t)dst->n, hipMemcpyHostToDevice, c->stream));
     }
+    dst->quiet = false; const_cast<ms_ba *>(src)->quiet = false;          // (both arenas are in use on the stream again)
     hipLaunchKernelGGL(k_ba_copy_state, dim3(dst->n), dim3(256), 0, c->stream, dst->d_probs, src->d_probs, d_extra);
     MS_KERNEL_CHECK(c, "k_ba_copy_state");
     return MS_OK;
@@ -4850,5 +5051,7 @@ int ms_ba_solve_host(ms_ctx *c, const ms_ba_problem *problem, double *pose_out, 
 }  // extern "C"
 
 void ms_ba_release_pool(ms_ctx *c) {
-    for (void *&sl : c->ba_handle_pool) if (sl) { ms_ba *B = static_cast<ms_ba *>(sl); if (B->ev_done) (void)hipEventDestroy(B->ev_done); delete B; sl = nullptr; }
+    for (void *&sl : c->ba_handle_pool) if (sl) { ba_delete_object(static_cast<ms_ba *>(sl)); sl = nullptr; }
+    if (c->ba_stage) { if (c->ba_stage_busy) (void)hipEventSynchronize(c->ba_stage_ev); (void)hipHostFree(c->ba_stage); c->ba_stage = nullptr; c->ba_stage_bytes = 0; }
+    if (c->ba_stage_ev) { (void)hipEventDestroy(c->ba_stage_ev); c->ba_stage_ev = nullptr; }
 }

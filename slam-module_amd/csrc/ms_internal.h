@@ -29,6 +29,12 @@ struct ms_ctx {
     bool d2h_pending = false;
     void *pinned = nullptr;       // page-locked host staging of small result blocks (ms_pinned), grow-only
     size_t pinned_bytes = 0;
+    // page-locked staging of ms_ba_create's small uploads (the inputs of all its problems and their descriptors, copied asynchronously: the solver launch follows
+    // in stream order, nobody waits); ba_stage_ev = the end of the last upload from it, waited for before the block is written again
+    void *ba_stage = nullptr;
+    size_t ba_stage_bytes = 0;
+    hipEvent_t ba_stage_ev = nullptr;
+    bool ba_stage_busy = false;
     void *ba_handle_pool[4] = {nullptr, nullptr, nullptr, nullptr};      // destroyed bundle-adjustment handle OBJECTS (their vectors keep their capacity, their event stays): ms_ba_create takes one back
     char err[512] = {0};
 };
