@@ -4033,17 +4033,20 @@ static void ba_delete_object(ms_ba *B) {
 // 0.18 ms in ms_ba_download for a 0.08 ms kernel, tools/pose_path_probe.py).
 static int ba_wait_event(ms_ctx *c, hipEvent_t ev) {
     thread_local bool slack_set = false;
+    static const int spin_us = std::getenv("MS_WAIT_SPIN_US") ? std::atoi(std::getenv("MS_WAIT_SPIN_US")) : 120;          // (experiment knobs)
+    static const int sleep_us = std::getenv("MS_WAIT_SLEEP_US") ? std::atoi(std::getenv("MS_WAIT_SLEEP_US")) : 20;
+    static const bool fine_slack = !std::getenv("MS_WAIT_COARSE");
     const auto t0 = std::chrono::steady_clock::now();
-    for (bool spinning = true;;) {
+    for (bool spinning = spin_us > 0;;) {
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) return MS_OK;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); return ms_fail(c, MS_ERR_HIP, "waiting for a solver launch failed: %s", hipGetErrorString(q)); }
         if (spinning) {
             std::this_thread::yield();
-            spinning = std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(120);
+            spinning = std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us);
         } else {
-            if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }      // (nanoseconds; the calling thread only)
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if (!slack_set && fine_slack) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }      // (nanoseconds; the calling thread only)
+            std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
         }
     }
 }
