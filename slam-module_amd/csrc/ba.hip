@@ -3062,30 +3062,64 @@ template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {         
     return __hiloint2double(hi, lo);
 }
 
-// an SE3 edge of a pose-only problem, once per solve (out of line: its two 6 x 6 Jacobians are not to cost the solver's loop registers): between fixed poses its
-// chi2 is a constant (returned); one that touches the free pose leaves its fixed side's transform, -J^T W and J^T W J in LDS
-__device__ __noinline__ double po_edge_setup(const BaProb &P, int k, int pi, int *s_ne, int *s_eSide, double *s_eC, double *s_eM, double *s_eG, double *s_eW, double *s_Hc) {
-    const int vi = P.edge_i[k], vj = P.edge_j[k];
-    const double *W = P.edge_info + 36 * (size_t)k;
-    double e[6], Ji[36], Jj[36], cacc = 0;
-    pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
-    if (vi != pi && vj != pi) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j]; return cacc; }
-    const int sl = atomicAdd(s_ne, 1), side = vi == pi ? 0 : 1;
-    const double *J = side ? Jj : Ji;
-    s_eSide[sl] = side;
-    if (side == 0) { double Tjinv[7], A2[7]; se3_inv(P.pose0 + 7 * (size_t)vj, Tjinv); se3_mul(Tjinv, P.edge_meas + 7 * (size_t)k, A2); for (int i = 0; i < 7; ++i) s_eC[8 * sl + i] = A2[i]; }
-    else for (int i = 0; i < 7; ++i) { s_eC[8 * sl + i] = P.pose0[7 * (size_t)vi + i]; s_eM[8 * sl + i] = P.edge_meas[7 * (size_t)k + i]; }
-    for (int i = 0; i < 36; ++i) s_eW[36 * sl + i] = W[i];
-    for (int a = 0; a < 6; ++a)                                     // G = -J^T W
-        for (int c = 0; c < 6; ++c) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += J[6 * r2 + a] * W[6 * r2 + c]; s_eG[36 * sl + 6 * a + c] = -v; }
-    int kk = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int b2 = a; b2 < 6; ++b2) {
-            double v = 0;
-            for (int r2 = 0; r2 < 6; ++r2) { double m = 0; for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * J[6 * c2 + b2]; v += J[6 * r2 + a] * m; }
-            atomicAdd(&s_Hc[kk++], v);
+// The SE3 edges of a problem with ONE free pose (k_ba_pose_only, k_ba_one_pose), once per solve, by ONE wave (all its lanes): an edge between fixed poses is a constant chi2
+// (returned: every lane's share); one that touches
+// the free pose leaves its fixed side's transform, G = -J^T W and J^T W J = -G J in LDS.  Only the free side's Jacobian is formed (Ji = adj(Tj^-1 M) or
+// Jj = -adj(Ti^-1 M^-1): no logarithm), and the two 6 x 6 products are spread over the lanes -- as the work of one thread (two Jacobians in scratch, 970 dependent
+// multiply-adds) this was 44 k cycles, a third of the whole kernel.
+__device__ __noinline__ double po_edges_setup(const BaProb &P, int pi, int lane, int *s_ne, int *s_eSide, double *s_eC, double *s_eM, double *s_eG, double *s_eW, double *s_Hc, double *s_J) {
+    double cacc = 0;
+    int ne = 0;
+    for (int k = lane; k < P.n_edge; k += 64) {                             // the edges between fixed poses (a window's stage 1 has ~50): one per lane
+        const int vi = P.edge_i[k], vj = P.edge_j[k];
+        if (vi == pi || vj == pi) continue;
+        const double *W = P.edge_info + 36 * (size_t)k;
+        double e[6];
+        pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, nullptr, nullptr, false);
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j];
+    }
+    // the edges of the free pose: found 64 at a time (a ballot over the lanes' edges -- a scan with one dependent load per edge was 35 us for a window's 50 edges), then
+    // taken by the wave together
+    for (int k0 = 0; k0 < P.n_edge; k0 += 64) {
+      const int kl = k0 + lane;
+      unsigned long long touching = __ballot(kl < P.n_edge && (P.edge_i[kl] == pi || P.edge_j[kl] == pi));
+      while (touching) {
+        const int k = k0 + __builtin_ctzll(touching);
+        touching &= touching - 1;
+        const int vi = P.edge_i[k], vj = P.edge_j[k];
+        const double *W = P.edge_info + 36 * (size_t)k, *M = P.edge_meas + 7 * (size_t)k, *Ti = P.pose0 + 7 * (size_t)vi, *Tj = P.pose0 + 7 * (size_t)vj;
+        const int sl = ne++, side = vi == pi ? 0 : 1;
+        double C7[7], J[36];
+        if (side == 0) { double Tjinv[7]; se3_inv(Tj, Tjinv); se3_mul(Tjinv, M, C7); se3_adj(C7, J); }
+        else { double Tiinv[7], Minv[7]; se3_inv(Ti, Tiinv); se3_inv(M, Minv); se3_mul(Tiinv, Minv, C7); se3_adj(C7, J); for (int i = 0; i < 36; ++i) J[i] = -J[i]; }
+        if (lane == 0) {
+            s_eSide[sl] = side;
+            if (side == 0) for (int i = 0; i < 7; ++i) s_eC[8 * sl + i] = C7[i];
+            else for (int i = 0; i < 7; ++i) { s_eC[8 * sl + i] = Ti[i]; s_eM[8 * sl + i] = M[i]; }
+            for (int i = 0; i < 36; ++i) s_J[i] = J[i];
         }
-    return 0.0;
+        if (lane < 36) s_eW[36 * sl + lane] = W[lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (lane < 36) {                                                    // G = -J^T W
+            const int a2 = lane / 6, c = lane % 6;
+            double v = 0;
+            for (int r2 = 0; r2 < 6; ++r2) v += s_J[6 * r2 + a2] * s_eW[36 * sl + 6 * r2 + c];
+            s_eG[36 * sl + lane] = -v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (lane < 21) {                                                    // upper triangle of J^T W J = -G J, entry (a, b) at a (11 - a) / 2 + b
+            int a2 = 0, rest = lane;
+            while (rest >= 6 - a2) { rest -= 6 - a2; ++a2; }
+            const int b2 = a2 + rest;
+            double v = 0;
+            for (int c = 0; c < 6; ++c) v += s_eG[36 * sl + 6 * a2 + c] * s_J[6 * c + b2];
+            s_Hc[lane] -= v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (lane == 0) *s_ne = ne;
+    return cacc;
 }
 
 #ifndef MS_PO_PROF
@@ -3101,6 +3135,8 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
     __shared__ __attribute__((aligned(16))) double s_sum[2][32];       // the sums of the last two sweeps: [cur] belongs to the accepted state (its H and b), the other to the trial
     __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
     __shared__ int s_eSide[PO_MAXE], s_ne, s_any;
+    __shared__ double s_J[36];
+    const long long t_kernel = clock64();
     const BaProb &P = probs[blockIdx.x];
     const int tid = threadIdx.x, pi = P.free2pose[0];
     for (int i = tid; i < 7 * P.n_pose; i += PO_NT) P.pose[i] = P.pose0[i];
@@ -3156,7 +3192,7 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
         P.chi2_obs[o] = chi2;
         cacc += r;
     }
-    if (tid < P.n_edge) cacc += po_edge_setup(P, tid, pi, &s_ne, s_eSide, &s_eC[0][0], &s_eM[0][0], &s_eG[0][0], &s_eW[0][0], s_Hc);
+    if (tid >= PO_OT) cacc += po_edges_setup(P, pi, tid - PO_OT, &s_ne, s_eSide, &s_eC[0][0], &s_eM[0][0], &s_eG[0][0], &s_eW[0][0], s_Hc, s_J);   // (wave 3, beside the observation loads)
     cacc = wave_sum_d(cacc);
     if ((tid & 63) == 0) lds_addd((MS_LDS double *)&s_const, cacc);
     __syncthreads();
@@ -3359,7 +3395,8 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
         P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = chi2_final;
         P.stats[6] = isfinite(chi2_final) ? 1 : 0; P.stats[7] = 0;
         P.stats[8] = (double)pc[0]; P.stats[10] = (double)pc[2]; P.stats[11] = (double)pc[3]; P.stats[12] = 0;
-        P.stats[13] = (double)(clock64() - t_begin);       // (MS_PO_PROF off: cycles since the kernel started, nothing per phase) P.stats[14] = 0; P.stats[15] = 0;
+        P.stats[13] = (double)(clock64() - t_begin);       // (MS_PO_PROF off: only this and the next: cycles of the iterations, cycles of what came before them)
+        P.stats[14] = (double)(t_begin - t_kernel); P.stats[15] = 0;
     }
 }
 
@@ -3457,6 +3494,8 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     __shared__ double s_acc[OP_NV], s_sum[OP_NV], s_w[OP_NW * 2], s_part[OP_NW * OP_NV];
     __shared__ double s_eC[PO_MAXE][8], s_eM[PO_MAXE][8], s_eG[PO_MAXE][36], s_eW[PO_MAXE][36], s_Hc[24], s_const;
     __shared__ int s_eSide[PO_MAXE], s_ne;
+    __shared__ double s_J[36];
+    const long long t_kernel = clock64();
     const BaProb &P = probs[blockIdx.x / (unsigned)team];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rank = team > 1 ? (int)(blockIdx.x % (unsigned)team) : 0;
     const int G = 1 << lgG, gl = rank * OP_NT + tid, sub = gl & (G - 1), slot = gl >> lgG, nslot = (team * OP_NT) >> lgG;
@@ -3499,29 +3538,10 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     //      an edge is ~1 700 dependent instructions (quaternion products, the SE3 logarithm) in one lane, 17 k cycles per sweep, and on the team's first wave
     //      it sat in front of that wave's points -- the last lanes of a launch have the fewest points (none when the lanes outnumber them)
     const bool edge_wg = rank == team - 1;
-    if (edge_wg && tid < P.n_edge) {
-        const int k = tid, vi = P.edge_i[k], vj = P.edge_j[k];
-        const double *W = P.edge_info + 36 * (size_t)k;
-        double e[6], Ji[36], Jj[36];
-        pose_edge(P.pose0 + 7 * (size_t)vi, P.pose0 + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
-        if (vi != pi && vj != pi) { double cacc = 0; for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) cacc += e[i] * W[6 * i + j] * e[j]; lds_addd((MS_LDS double *)&s_const, cacc); }
-        else {
-            const int sl = atomicAdd(&s_ne, 1), side = vi == pi ? 0 : 1;
-            const double *J = side ? Jj : Ji;
-            s_eSide[sl] = side;
-            if (side == 0) { double Tjinv[7], A2[7]; se3_inv(P.pose0 + 7 * (size_t)vj, Tjinv); se3_mul(Tjinv, P.edge_meas + 7 * (size_t)k, A2); for (int i = 0; i < 7; ++i) s_eC[sl][i] = A2[i]; }
-            else for (int i = 0; i < 7; ++i) { s_eC[sl][i] = P.pose0[7 * (size_t)vi + i]; s_eM[sl][i] = P.edge_meas[7 * (size_t)k + i]; }
-            for (int i = 0; i < 36; ++i) s_eW[sl][i] = W[i];
-            for (int a = 0; a < 6; ++a)
-                for (int c = 0; c < 6; ++c) { double v = 0; for (int r2 = 0; r2 < 6; ++r2) v += J[6 * r2 + a] * W[6 * r2 + c]; s_eG[sl][6 * a + c] = -v; }
-            int kk = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int b2 = a; b2 < 6; ++b2) {
-                    double v = 0;
-                    for (int r2 = 0; r2 < 6; ++r2) { double m = 0; for (int c2 = 0; c2 < 6; ++c2) m += W[6 * r2 + c2] * J[6 * c2 + b2]; v += J[6 * r2 + a] * m; }
-                    lds_addd((MS_LDS double *)&s_Hc[kk++], v);
-                }
-        }
+    if (edge_wg && tid >= OP_NT - 64) {                                     // (the last wave: the one that takes the edges in every sweep)
+        double cc = po_edges_setup(P, pi, tid - (OP_NT - 64), &s_ne, s_eSide, &s_eC[0][0], &s_eM[0][0], &s_eG[0][0], &s_eW[0][0], s_Hc, s_J);
+        cc = wave_sum_d(cc);
+        if (tid == OP_NT - 64) lds_addd((MS_LDS double *)&s_const, cc);
     }
     __syncthreads();
     const int ne = edge_wg ? s_ne : 0, et = tid - (OP_NT - 64);             // lane et of the last wave takes edge et
@@ -3961,6 +3981,7 @@ __global__ __launch_bounds__(OP_NT) void k_ba_one_pose(const BaProb *probs, int 
     if (gl == (OP_PROF_GL < team * OP_NT ? OP_PROF_GL : 0)) {              // the phase stamps of one wave (-DOP_PROF_GL=<global lane>: another wave than the first)
         P.stats[8] = (double)cyc[0]; P.stats[9] = (double)cyc[1]; P.stats[10] = (double)cyc[2]; P.stats[11] = (double)cyc[3]; P.stats[12] = (double)cyc[4];
         P.stats[13] = (double)(clock64() - t_begin); P.stats[14] = (double)cyc[5];
+        P.stats[15] = (double)(t_begin - t_kernel);                           // what comes before the first sweep (not part of [13])
     }
 #undef OP_LAP
 }
@@ -3996,6 +4017,8 @@ struct ms_ba {
     void *h_result = nullptr;          // page-locked, stays with the handle OBJECT (pooled per context)
     size_t h_result_bytes = 0, pack_doubles = 0;
     double *d_pack = nullptr;          // in the arena; nullptr: no eager results for this handle
+    int32_t *h_verdict = nullptr;      // page-locked word, stays with the handle object: "a team barrier gave up somewhere in the last launch", collected behind every team launch
+    bool verdict_eager = false;        // h_verdict belongs to the last launch
     bool eager = false;                // h_result holds the last launch's results
     bool quiet = false;                // everything this handle put on the stream is known to have finished (ev_done was seen, nothing enqueued since): ms_ba_destroy need not wait
     hipEvent_t ev_done = nullptr;      // the end of this handle's last launch (what reads its results waits for it ON THE HOST, politely: ba_wait_event)
@@ -4010,6 +4033,11 @@ static std::vector<TeamLaunch> g_team_live[64];
 static int g_team_query_errors = 0;        // hipEventQuery answers other than success / not-ready seen by the admission list (guarded by g_team_mu)
 #define MS_TRY_BA(x) do { int rc__ = (x); if (rc__ != MS_OK) return rc__; } while (0)
 
+constexpr size_t kBaEagerMax = (size_t)64 << 10;        // results of a single problem up to this size are packed and copied behind every launch (ms_ba struct: h_result).
+                                                        // (Tried at 512 KB, i.e. for a whole C4 window too: -0.025 ms for the window alone, but the front end of the same
+                                                        //  sequence, running beside it, fell from 2.7-3.0 k to 2.0-2.2 k frames/s -- tools/together_ab.sh; kept for small problems)
+constexpr size_t kBaStageMax = (size_t)4 << 20;        // creates whose inputs fit are uploaded from the context's page-locked staging block without a wait
+static size_t ba_eager_max() { static const size_t v = std::getenv("MS_BA_EAGER_MAX") ? (size_t)std::atoll(std::getenv("MS_BA_EAGER_MAX")) : kBaEagerMax; return v; }     // (experiment knob)
 // The end of a handle's last launch, as an event the handle owns: whatever reads the launch's results waits for it ON THE HOST, politely (ba_wait_event), before it
 // enqueues anything -- not with hipStreamSynchronize, and not with a wait packet behind the launch (round 4, tools/hog_probe.py: a stream with packets queued behind
 // a 2 ms kernel slowed the front end of ANOTHER sequence 10 ... 90 x, one that holds one launch at a time 3 ... 15 x).
@@ -4023,6 +4051,7 @@ static int ba_launch_done(ms_ctx *c, ms_ba *B) {
 static void ba_delete_object(ms_ba *B) {
     if (B->ev_done) (void)hipEventDestroy(B->ev_done);
     if (B->h_result) (void)hipHostFree(B->h_result);
+    if (B->h_verdict) (void)hipHostFree(B->h_verdict);
     delete B;
 }
 // A host wait for a solver launch (milliseconds) that leaves the processor to the other sequences' threads: hipStreamSynchronize / hipEventSynchronize spin, and
@@ -4123,9 +4152,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     bvec<Prep> prep(n);
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
-    constexpr size_t kBaEagerMax = (size_t)64 << 10;       // results of a single problem up to this size are packed and copied behind every launch (ms_ba struct: h_result)
-constexpr size_t kBaStageMax = (size_t)4 << 20;        // creates whose inputs fit are uploaded from the context's page-locked staging block without a wait
-struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
+    struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
                  free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red, pack; };
     bvec<Off> off(n);
     bvec<size_t> in_lo(n), in_hi(n);
@@ -4552,7 +4579,7 @@ struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, o
         O.op_rec = bump(R.one_pose ? 28 * (size_t)Q.n_point * D : 8); O.op_red = bump(R.one_pose ? 2 * (size_t)kMaxTeam * OP_NV * D : 8);
         // a single small problem gets its results packed behind every launch (ba_after_launch): status, poses, points, chi2 per observation
         const size_t pack_doubles = 16 + 7 * (size_t)Q.n_pose + 3 * (size_t)Q.n_point + (size_t)Q.n_obs;
-        O.pack = bump(n == 1 && pack_doubles * D <= kBaEagerMax ? pack_doubles * D : 8);
+        O.pack = bump(n == 1 && pack_doubles * D <= ba_eager_max() ? pack_doubles * D : 8);
     }
     const double tm1 = tm_now();
     ms_ba *B = nullptr;
@@ -4601,7 +4628,7 @@ struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, o
     }
     {   // the eager results of a single small problem: a page-locked block that stays with the handle object
         const size_t pack_doubles = n == 1 ? 16 + 7 * (size_t)problems[0].n_pose + 3 * (size_t)problems[0].n_point + (size_t)problems[0].n_obs : 0;
-        B->pack_doubles = pack_doubles * sizeof(double) <= kBaEagerMax ? pack_doubles : 0;
+        B->pack_doubles = pack_doubles * sizeof(double) <= ba_eager_max() ? pack_doubles : 0;
         if (B->pack_doubles * sizeof(double) > B->h_result_bytes) {
             if (B->h_result) (void)hipHostFree(B->h_result);
             B->h_result = nullptr; B->h_result_bytes = 0;
@@ -4762,11 +4789,12 @@ void ms_ba_destroy(ms_ba *B) {
         if (slot) {
             const hipEvent_t ev = B->ev_done;
             void *const hres = B->h_result; const size_t hres_bytes = B->h_result_bytes;
+            int32_t *const hver = B->h_verdict;
             std::vector<BaProb> host = std::move(B->host); std::vector<ms_ba_problem> dims = std::move(B->dims); std::vector<double> tiles = std::move(B->chol_tiles);
             host.clear(); dims.clear(); tiles.clear();
             *B = ms_ba();
             B->host = std::move(host); B->dims = std::move(dims); B->chol_tiles = std::move(tiles); B->ev_done = ev;
-            B->h_result = hres; B->h_result_bytes = hres_bytes;
+            B->h_result = hres; B->h_result_bytes = hres_bytes; B->h_verdict = hver;
             *slot = B;
             return;
         }
@@ -4788,8 +4816,19 @@ int ms_ba_set_factor_team(ms_ba *B, int workgroups) {
 
 // what follows every solver launch of ms_ba_solve: the eager results of a small single problem, then the handle's completion event
 static int ba_after_launch(ms_ctx *c, ms_ba *B) {
-    B->eager = false;
-    if (B->d_pack) {
+    B->eager = false; B->verdict_eager = false;
+    static const bool no_eager_verdict = std::getenv("MS_BA_NO_EAGER_VERDICT") != nullptr;                       // (experiment knob)
+    if (!B->team_checked && (B->n > 1 || B->last_one_pose) && !no_eager_verdict) {      // a team launch: its verdict travels behind it, so that whoever needs it (ms_ba_copy_state between the
+        if (!B->h_verdict) {                                       // two stages, ms_ba_download of a batch) finds it on the host once the launch's event has been seen
+                                                                   // (a single window's stage 2 is read by ms_ba_download, whose packed results carry the marker: nothing extra)
+            MS_HIP(c, hipHostMalloc(reinterpret_cast<void **>(&B->h_verdict), 64, hipHostMallocDefault)); ++g_ba_host_allocs;
+        }
+        hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
+        MS_KERNEL_CHECK(c, "k_ba_collect_gave_up");
+        MS_HIP(c, hipMemcpyAsync(B->h_verdict, B->host[0].flag + 2, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        B->verdict_eager = true;
+    }
+    if (B->d_pack && !B->last_one_pose) {                          // (stage 1 of a window is handed on by ms_ba_copy_state, not downloaded: nothing to pack)
         hipLaunchKernelGGL(k_ba_pack_result, dim3((unsigned)std::min<size_t>(ms_div_up((int)B->pack_doubles, 256), 256)), dim3(256), 0, c->stream, B->d_probs, 0, B->d_pack, 1);
         MS_KERNEL_CHECK(c, "k_ba_pack_result");
         MS_HIP(c, hipMemcpyAsync(B->h_result, B->d_pack, B->pack_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -4914,7 +4953,7 @@ static int ba_relaunch_single(ms_ba *B) {
     ms_ctx *c = B->ctx;
     const hipStream_t ls = c->stream;
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
-    B->eager = false;                                              // (what h_result holds belongs to the void launch)
+    B->eager = false; B->verdict_eager = false;                     // (what h_result / h_verdict hold belongs to the void launch)
     MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, ls));
     if (B->last_one_pose) {
         int most_poses = 0, most_points = 0;
@@ -4943,10 +4982,13 @@ static int ba_team_verdict(ms_ba *B) {
     MS_TRY_BA(ba_wait_pending(B));
     ms_ctx *c = B->ctx;
     int any = 0;
-    hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
-    MS_KERNEL_CHECK(c, "k_ba_collect_gave_up");
-    MS_HIP(c, hipMemcpyAsync(&any, B->host[0].flag + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    MS_HIP(c, hipStreamSynchronize(c->stream));
+    if (B->verdict_eager) any = *B->h_verdict;                    // collected and copied behind the launch: the wait above covered it
+    else {
+        hipLaunchKernelGGL(k_ba_collect_gave_up, dim3(1), dim3(64), 0, c->stream, B->d_probs, B->n);
+        MS_KERNEL_CHECK(c, "k_ba_collect_gave_up");
+        MS_HIP(c, hipMemcpyAsync(&any, B->host[0].flag + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        MS_HIP(c, hipStreamSynchronize(c->stream));
+    }
     if (any) MS_TRY_BA(ba_relaunch_single(B));
     B->team_checked = true;
     return MS_OK;

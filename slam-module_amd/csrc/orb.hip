@@ -223,111 +223,6 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs R, ResizeTab T) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two levels per launch (round 4): level l+1 AND level l+2 from level l.  The chain of k_resize launches reads every level it has just written back from
-// memory -- 5.1 level-0 images of traffic per frame for 3.1 of output; here a workgroup takes a tile of level l+2, stages the part of level l that tile
-// depends on (through the part of level l+1 it depends on) in LDS with plain coalesced dword loads, computes that part of level l+1 into LDS -- writing
-// the rows and dword columns it OWNS to memory on the way -- and then the tile of level l+2 from LDS.  Every second level is never read back (-23 % of
-// the chain's traffic), the per-lane 12-byte window loads (k_resize is bound by their number) become LDS reads, and the chain has half the launches.
-//   Ownership: a tile's level-(l+1) part starts at the first tap of its first level-(l+2) pixel (rows: Y2[y2a].sy0, columns: X2[x2a].sx rounded down to a
-//   dword) and the next tile's start ends it; taps are monotone, so the owned ranges partition the level, and a tile computes what it owns because its
-//   last pixel's second tap reaches at least up to the next tile's first (scale factors up to 2).  The arithmetic per pixel is k_resize's, bit for bit.
-struct PairArgs {
-    const uint8_t *src; uint64_t src_frame_stride; int32_t src_pitch, w0;                          // level l
-    uint8_t *d1; uint64_t d1_frame_stride; int32_t d1_pitch;                                       // level l+1
-    uint8_t *d2; uint64_t d2_frame_stride; int32_t d2_pitch;                                       // level l+2
-    const int16_t *xtab1, *ytab1, *xtab2, *ytab2;                                                  // [.][4] as ResizeTab, padded to whole groups
-    const int32_t *tile_x, *tile_y;                                                                // per tile column / row: the ranges below (PairTile), 8 ints each
-    int32_t lds_y2, lds_l0, lds_l1;                                                                // byte offsets in LDS: level l+2's row table, the level-l part, the level-(l+1) part (level l+1's row table sits at 0)
-};
-// a tile column's (row's) ranges: the level-(l+2) tile [a2, b2), the part of level l+1 it needs [a1, b1) and owns [a1, own1), the part of level l that needs [a0, b0)
-struct PairTile { int32_t a2, b2, a1, b1, own1, a0, b0, pad; };
-
-// A level's rows [ya, yb) x dword columns [xa, xb) from a source part held in LDS (origin xs0 / ys0, pitch srcP bytes): wave `wave` takes rows ya + wave, + 4, ...; a lane
-// takes four pixels.  ytab: the rows' table entries in LDS (entry 0 = row ya); xt0: the lane's column entries for the first 256 columns (fetched before the barrier).
-// store(y, x, packed dword).
-template <class Store>
-__device__ __forceinline__ void resize_rows_lds(const uint8_t *src, int srcP, int xs0, int ys0, const int16_t *xtab, const short4 *ytab, const uint4 (&xt0)[2],
-                                                int xa, int xb, int ya, int yb, int lane, int wave, Store &&store) {
-    for (int x = xa + 4 * lane; x < xb; x += 256) {
-        uint4 ta = xt0[0], tb = xt0[1];
-        if (x >= xa + 256) { ta = reinterpret_cast<const uint4 *>(xtab)[x >> 1]; tb = reinterpret_cast<const uint4 *>(xtab)[(x >> 1) + 1]; }
-        const short4 xt[4] = {__builtin_bit_cast(short4, make_uint2(ta.x, ta.y)), __builtin_bit_cast(short4, make_uint2(ta.z, ta.w)),
-                              __builtin_bit_cast(short4, make_uint2(tb.x, tb.y)), __builtin_bit_cast(short4, make_uint2(tb.z, tb.w))};
-        const int sx0 = xt[0].x, col = (sx0 & ~3) - xs0;
-        uint32_t A[4], sel[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            A[i] = (uint32_t)(uint16_t)xt[i].y | ((uint32_t)(uint16_t)xt[i].z << 16);
-            sel[i] = 0x0C010C00u + (uint32_t)(xt[i].x - sx0) * 0x00010001u;
-        }
-#pragma unroll 2
-        for (int y = ya + wave; y < yb; y += 4) {
-            const short4 yt = ytab[y - ya];                                                        // (LDS, the same entry in every lane)
-            const uint32_t *r0 = reinterpret_cast<const uint32_t *>(src + (yt.x - ys0) * srcP + col), *r1 = reinterpret_cast<const uint32_t *>(src + (yt.y - ys0) * srcP + col);
-            const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], c0 = r1[0], c1 = r1[1], c2 = r1[2];
-            const uint32_t lo0 = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)sx0), hi0 = __builtin_amdgcn_alignbyte(a2, a1, (uint32_t)sx0);
-            const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, (uint32_t)sx0), hi1 = __builtin_amdgcn_alignbyte(c2, c1, (uint32_t)sx0);
-            const uint32_t b0 = (uint32_t)yt.z, b1 = (uint32_t)yt.w;
-            uint32_t v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t q0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi0, lo0, sel[i])), __builtin_bit_cast(us2_t, A[i]), 0u, false);
-                const uint32_t q1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi1, lo1, sel[i])), __builtin_bit_cast(us2_t, A[i]), 0u, false);
-                v[i] = ((__umul24(b0, q0 >> 4) >> 16) + (__umul24(b1, q1 >> 4) >> 16) + 2) >> 2;
-            }
-            store(y, x, v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24));
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_resize_pair(PairArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t rp_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = blockIdx.z;
-    // the tile's ranges, worked out by ms_orb_create (a chain of three dependent table lookups per axis otherwise -- with the row tables fetched per row that was 12 us of
-    // exposed latency per workgroup and the fused chain TWICE as slow as the plain one)
-    const int4 ux0 = reinterpret_cast<const int4 *>(A.tile_x)[2 * blockIdx.x], ux1 = reinterpret_cast<const int4 *>(A.tile_x)[2 * blockIdx.x + 1];
-    const int4 uy0 = reinterpret_cast<const int4 *>(A.tile_y)[2 * blockIdx.y], uy1 = reinterpret_cast<const int4 *>(A.tile_y)[2 * blockIdx.y + 1];
-#define RFL(v) __builtin_amdgcn_readfirstlane(v)
-    const int x2a = RFL(ux0.x), x2b = RFL(ux0.y), x1a = RFL(ux0.z), x1b = RFL(ux0.w), c1b = RFL(ux1.x), x0a = RFL(ux1.y), x0b = RFL(ux1.z);
-    const int y2a = RFL(uy0.x), y2b = RFL(uy0.y), y1a = RFL(uy0.z), y1b = RFL(uy0.w), o1b = RFL(uy1.x), y0a = RFL(uy1.y), y0b = RFL(uy1.z);
-#undef RFL
-    // ---- everything that comes from memory is requested first: the level-l part, the two row tables (into LDS), the lane's column entries of both levels
-    const int dw0 = (x0b - x0a) >> 2, n0 = dw0 * (y0b - y0a), P0 = 4 * dw0, last = (A.w0 - 1) & ~3;
-    const uint32_t inv0 = (uint32_t)(((1ull << 32) + (uint32_t)dw0 - 1) / (uint32_t)dw0);
-    const uint8_t *S = A.src + (uint64_t)f * A.src_frame_stride + (uint64_t)y0a * A.src_pitch;
-    uint32_t *L0 = reinterpret_cast<uint32_t *>(rp_lds + A.lds_l0);
-    uint2 *T1 = reinterpret_cast<uint2 *>(rp_lds), *T2 = reinterpret_cast<uint2 *>(rp_lds + A.lds_y2);
-    if (tid < y1b - y1a) T1[tid] = reinterpret_cast<const uint2 *>(A.ytab1)[y1a + tid];
-    if (tid >= 128 && tid - 128 < y2b - y2a) T2[tid - 128] = reinterpret_cast<const uint2 *>(A.ytab2)[y2a + tid - 128];
-    uint4 xt1[2], xt2[2];
-    {
-        const int x1 = min(x1a + 4 * lane, x1b - 4), x2 = min(x2a + 4 * lane, x2b - 4);             // (lanes beyond the part: a valid entry nobody uses)
-        xt1[0] = reinterpret_cast<const uint4 *>(A.xtab1)[x1 >> 1]; xt1[1] = reinterpret_cast<const uint4 *>(A.xtab1)[(x1 >> 1) + 1];
-        xt2[0] = reinterpret_cast<const uint4 *>(A.xtab2)[x2 >> 1]; xt2[1] = reinterpret_cast<const uint4 *>(A.xtab2)[(x2 >> 1) + 1];
-    }
-    for (int i = tid; i < n0; i += 256) {
-        const int r = (int)__umulhi((uint32_t)i, inv0), j = i - r * dw0;
-        L0[i] = ((const __attribute__((address_space(1))) U32u *)(S + (uint64_t)r * A.src_pitch + min(x0a + 4 * j, last)))->v;
-    }
-    __syncthreads();
-    // ---- level l+1: the needed part into LDS, the owned part to memory as well
-    uint8_t *L1 = rp_lds + A.lds_l1;
-    const int P1 = x1b - x1a;
-    uint8_t *D1 = A.d1 + (uint64_t)f * A.d1_frame_stride;
-    resize_rows_lds(rp_lds + A.lds_l0, P0, x0a, y0a, A.xtab1, reinterpret_cast<const short4 *>(T1), xt1, x1a, x1b, y1a, y1b, lane, wave, [&](int y, int x, uint32_t px) {
-        *reinterpret_cast<uint32_t *>(L1 + (y - y1a) * P1 + (x - x1a)) = px;
-        if (y < o1b && x < c1b) *reinterpret_cast<uint32_t *>(D1 + (uint64_t)y * A.d1_pitch + x) = px;      // (the part starts where the ownership starts: y >= y1a, x >= x1a)
-    });
-    __syncthreads();
-    // ---- level l+2: the tile, from LDS
-    uint8_t *D2 = A.d2 + (uint64_t)f * A.d2_frame_stride;
-    resize_rows_lds(L1, P1, x1a, y1a, A.xtab2, reinterpret_cast<const short4 *>(T2), xt2, x2a, x2b, y2a, y2b, lane, wave, [&](int y, int x, uint32_t px) {
-        *reinterpret_cast<uint32_t *>(D2 + (uint64_t)y * A.d2_pitch + x) = px;
-    });
-}
-
-// ------------------------------------------------------------------------------------------------
 // P2: cv::GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101, 8U fixed point (image_pyramid.cpp:84).
 // One launch covers every level of every frame (tile table in PyrGeom).  No LDS: a lane owns one dword
 // (4 pixels) of a row; a wave owns a 256-pixel row segment and walks 8 output rows.
@@ -1238,9 +1133,6 @@ struct ms_orb {
     // resize tables per level (device)
     int16_t *d_xtab[MS_MAX_LEVELS] = {nullptr}, *d_ytab[MS_MAX_LEVELS] = {nullptr};
     bool wide[MS_MAX_LEVELS] = {false};
-    // k_resize_pair: levels l and l + 1 from level l - 1 in one launch (plan[l].on; l odd)
-    struct PairPlan { bool on = false; int tiles_x = 0, tiles_y = 0, lds_y2 = 0, lds_l0 = 0, lds_l1 = 0; size_t lds_bytes = 0; } pair[MS_MAX_LEVELS];
-    int32_t *d_pair_x[MS_MAX_LEVELS] = {nullptr}, *d_pair_y[MS_MAX_LEVELS] = {nullptr};      // PairTile per tile column / row
     uint4 *d_moment_tab = nullptr;            // k_describe: disc mask of the orientation patch, four dwords per lane
     float4 *d_pattern_f = nullptr;            // k_describe: the 256 BRIEF point pairs as floats
     // optional per-stage HIP events (ms_orb_set_profiling)
@@ -1378,7 +1270,6 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
     A(dev_calloc(ctx, &o->d_octave, B * cap)); A(dev_calloc(ctx, &o->d_track, B * cap)); A(dev_calloc(ctx, &o->d_count, B)); A(dev_calloc(ctx, &o->d_slot_tab, B * cap));
     A(dev_calloc(ctx, &o->d_desc, B * cap * 8));
     if (rc == MS_OK && hipMemcpyAsync(o->d_geom, &o->geom, sizeof(PyrGeom), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = MS_ERR_HIP;
-    std::vector<int16_t> hx[MS_MAX_LEVELS], hy[MS_MAX_LEVELS];      // the padded tables, kept for the pair plans below
     for (int l = 1; l < cfg->levels && rc == MS_OK; ++l) {
         std::vector<int16_t> xo, xc, yo, yc;
         msgeo::resize_tables(w[l - 1], w[l], true, xo, xc);
@@ -1400,60 +1291,6 @@ int ms_orb_create(ms_ctx *ctx, const ms_orb_config *cfg, ms_orb **out) {
                 hipMemcpy(*d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = MS_ERR_HIP;
         };
         up(&o->d_xtab[l], xt); up(&o->d_ytab[l], yt);
-        hx[l] = std::move(xt); hy[l] = std::move(yt);
-    }
-    // pair plans: the tile of level l + 1 whose level-l part is at most ~256 pixels wide (one pass of a wave's lanes), 32 rows unless LDS says less.  The ranges of every
-    // tile column and row (PairTile) are worked out here, from the same tables the kernel interpolates with; a plan whose tiles do not own what they compute is dropped
-    for (int l = 1; l + 1 < cfg->levels && rc == MS_OK && std::getenv("MS_RESIZE_PAIR"); l += 2) {   // (measured slower than the chain: opt-in)
-        if (o->wide[l] || o->wide[l + 1]) continue;
-        ms_orb::PairPlan P;
-        const int w1pad = ms_div_up(w[l], 4) * 4, w2pad = ms_div_up(w[l + 1], 4) * 4;
-        if (w1pad > G.L[l].pitch || w2pad > G.L[l + 1].pitch) continue;
-        const int16_t *X1 = hx[l].data(), *Y1 = hy[l].data(), *X2 = hx[l + 1].data(), *Y2 = hy[l + 1].data();
-        const int T2W = std::max(16, ((int)(240.0 * w[l + 1] / w[l])) & ~3);
-        std::vector<PairTile> tx, ty;
-        for (int T2H = 32; T2H >= 8 && !P.on; T2H /= 2) {
-            P.tiles_x = ms_div_up(w[l + 1], T2W); P.tiles_y = ms_div_up(h[l + 1], T2H);
-            tx.assign(P.tiles_x, PairTile{}); ty.assign(P.tiles_y, PairTile{});
-            int dw0_max = 0, p1_max = 0, r0_max = 0, r1_max = 0;
-            bool good = (X2[0] & ~3) == 0 && Y2[0] == 0;
-            for (int bx = 0; bx < P.tiles_x && good; ++bx) {
-                const bool lastx = bx == P.tiles_x - 1;
-                PairTile &t = tx[bx];
-                t.a2 = bx * T2W; t.b2 = std::min(t.a2 + T2W, w2pad);
-                t.a1 = bx == 0 ? 0 : (X2[4 * t.a2] & ~3); t.b1 = lastx ? w1pad : std::min(w1pad, (X2[4 * (t.b2 - 1)] + 2 + 3) & ~3);
-                t.own1 = lastx ? w1pad : (X2[4 * t.b2] & ~3);
-                good = t.b2 - t.a2 >= 4 && t.b1 - t.a1 >= 4 && t.own1 <= t.b1 && t.own1 >= t.a1;
-                if (!good) break;
-                t.a0 = X1[4 * t.a1] & ~3; t.b0 = (X1[4 * (t.b1 - 1)] + 2 + 3) & ~3;
-                dw0_max = std::max(dw0_max, (t.b0 - t.a0) / 4); p1_max = std::max(p1_max, t.b1 - t.a1);
-            }
-            for (int by = 0; by < P.tiles_y && good; ++by) {
-                const bool lasty = by == P.tiles_y - 1;
-                PairTile &t = ty[by];
-                t.a2 = by * T2H; t.b2 = std::min(t.a2 + T2H, h[l + 1]);
-                t.a1 = by == 0 ? 0 : Y2[4 * t.a2]; t.b1 = lasty ? h[l] : std::min(h[l], Y2[4 * (t.b2 - 1) + 1] + 1);
-                t.own1 = lasty ? h[l] : Y2[4 * t.b2];
-                good = t.b2 > t.a2 && t.b1 > t.a1 && t.own1 <= t.b1 && t.own1 >= t.a1;
-                if (!good) break;
-                t.a0 = Y1[4 * t.a1]; t.b0 = Y1[4 * (t.b1 - 1) + 1] + 1;
-                r0_max = std::max(r0_max, t.b0 - t.a0); r1_max = std::max(r1_max, t.b1 - t.a1);
-            }
-            if (!good || r1_max > 128 || T2H > 128) break;               // (the row tables are staged by 128 threads each)
-            P.lds_y2 = (int)ms_align_up((size_t)8 * r1_max, 16);
-            P.lds_l0 = P.lds_y2 + (int)ms_align_up((size_t)8 * T2H, 16);
-            P.lds_l1 = P.lds_l0 + (int)ms_align_up((size_t)4 * dw0_max * r0_max + 16, 16);
-            P.lds_bytes = (size_t)P.lds_l1 + (size_t)p1_max * r1_max + 16;
-            P.on = P.lds_bytes <= (size_t)48 << 10;
-        }
-        if (!P.on) continue;
-        auto upt = [&](int32_t **d, const std::vector<PairTile> &v) {
-            if (rc != MS_OK) return;
-            if (hipMalloc(reinterpret_cast<void **>(d), v.size() * sizeof(PairTile)) != hipSuccess ||
-                hipMemcpy(*d, v.data(), v.size() * sizeof(PairTile), hipMemcpyHostToDevice) != hipSuccess) rc = MS_ERR_HIP;
-        };
-        upt(&o->d_pair_x[l], tx); upt(&o->d_pair_y[l], ty);
-        o->pair[l] = P;
     }
     if (rc == MS_OK) {                                   // k_fast's tile table: level | column << 4 | row << 16
         std::vector<uint32_t> tt;
@@ -1534,8 +1371,6 @@ void ms_orb_destroy(ms_orb *o) {
     if (o->ev_end) (void)hipEventDestroy(o->ev_end);
 
     for (int l = 0; l < MS_MAX_LEVELS; ++l) {
-        if (o->d_pair_x[l]) (void)hipFree(o->d_pair_x[l]);
-        if (o->d_pair_y[l]) (void)hipFree(o->d_pair_y[l]);
         if (o->d_xtab[l]) (void)hipFree(o->d_xtab[l]);
         if (o->d_ytab[l]) (void)hipFree(o->d_ytab[l]);
     }
@@ -1614,26 +1449,11 @@ static int orb_enqueue_kernels(ms_orb *o, FrameSrc src, int f0, int nf, bool hav
     MS_STAGE_MARK();
     MsRange pyramid_range("pyramid");
     for (int l = 1; l < G.levels; ++l) {
-        const uint8_t *lsrc = l == 1 ? src.lvl0 : src.slab + G.L[l - 1].img_off;
-        const uint64_t lsrc_stride = l == 1 ? src.lvl0_frame_stride : G.slab_stride;
-        const int lsrc_pitch = l == 1 ? src.lvl0_pitch : G.L[l - 1].pitch;
-        if (o->pair[l].on) {                            // levels l and l + 1 from level l - 1 in one launch
-            const ms_orb::PairPlan &P = o->pair[l];
-            PairArgs PA{};
-            PA.src = lsrc; PA.src_frame_stride = lsrc_stride; PA.src_pitch = lsrc_pitch; PA.w0 = G.L[l - 1].w;
-            PA.d1 = src.slab + G.L[l].img_off; PA.d1_frame_stride = G.slab_stride; PA.d1_pitch = G.L[l].pitch;
-            PA.d2 = src.slab + G.L[l + 1].img_off; PA.d2_frame_stride = G.slab_stride; PA.d2_pitch = G.L[l + 1].pitch;
-            PA.xtab1 = o->d_xtab[l]; PA.ytab1 = o->d_ytab[l]; PA.xtab2 = o->d_xtab[l + 1]; PA.ytab2 = o->d_ytab[l + 1];
-            PA.tile_x = o->d_pair_x[l]; PA.tile_y = o->d_pair_y[l]; PA.lds_y2 = P.lds_y2; PA.lds_l0 = P.lds_l0; PA.lds_l1 = P.lds_l1;
-            hipLaunchKernelGGL(k_resize_pair, dim3(P.tiles_x, P.tiles_y, nf), dim3(256), P.lds_bytes, st, PA);
-            MS_KERNEL_CHECK(c, "k_resize_pair");
-            ++l;
-            continue;
-        }
         dim3 grid(ms_div_up(G.L[l].w, 256), ms_div_up(G.L[l].h, 4 * kResizeRows), nf);
         const ResizeTab RT{o->d_xtab[l], o->d_ytab[l]};
         ResizeArgs RA{};
-        RA.src = lsrc; RA.src_frame_stride = lsrc_stride; RA.src_pitch = lsrc_pitch;
+        if (l == 1) { RA.src = src.lvl0; RA.src_frame_stride = src.lvl0_frame_stride; RA.src_pitch = src.lvl0_pitch; }
+        else { RA.src = src.slab + G.L[l - 1].img_off; RA.src_frame_stride = G.slab_stride; RA.src_pitch = G.L[l - 1].pitch; }
         RA.sw = G.L[l - 1].w;
         RA.dst = src.slab + G.L[l].img_off; RA.dst_frame_stride = G.slab_stride; RA.dst_pitch = G.L[l].pitch; RA.dw = G.L[l].w; RA.dh = G.L[l].h;
         if (o->wide[l]) hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, st, RA, RT);
