@@ -4142,7 +4142,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     const bool tm_on = std::getenv("MS_BA_TIMING") != nullptr;           // prints the host index build and the allocation + upload time of every create to stderr
     auto tm_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tm0 = tm_now();
-    double tm_part[5] = {0, 0, 0, 0, 0}, tm_mark = tm0;                  // CSR + envelope | record-based Schur lists | Cholesky panel lists | fused Schur batches | windowed Cholesky tables
+    double tm_part[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tm_mark = tm0;                  // CSR + envelope | record-based Schur lists | Cholesky panel lists | fused Schur batches | windowed Cholesky tables
     auto tm_lap = [&](int k) { if (tm_on) { const double t = tm_now(); tm_part[k] += t - tm_mark; tm_mark = t; } };
     // pass 1: sizes + host-side structure (free-pose index, CSR by point and by free pose)
     struct FsHost { bvec<int32_t> row0, row1, batch_start, b_obs_start, b_run_start, b_fmt, pobs, rowoff, yoff; bvec<uint16_t> pairs; bvec<double> puv; bool by_points = false; };
@@ -4328,7 +4328,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                     for (int f = r; f < r1; ++f) { F.rowoff.push_back(off2); off2 += 36 * (f - first[f] + 1); }
                     F.yoff[F.yoff.size() - 2] = off2;
                 };
-                auto tile_need = [&](int r, int r1) { int u = 0; for (int f = r; f < r1; ++f) u += 36 * (f - first[f] + 1) + 6; return u; };
+                bvec<int32_t> need_pre(np + 1, 0);                        // tile doubles of rows [0, f): a pass's need is a difference
+                for (int f = 0; f < np; ++f) need_pre[f + 1] = need_pre[f] + 36 * (f - first[f] + 1) + 6;
+                auto tile_need = [&](int r, int r1) { return r1 > r ? need_pre[r1] - need_pre[r] : 0; };
                 // set 1 (teams): the POINTS are dealt out, not the rows -- a pass is a run of points (in the order of their first pose) with about 1 / team of the
                 // block products; its rows are the poses those points see (they overlap with the neighbours': the sums meet in S through atomics).  Every
                 // observation is then linearised once per damped solve.  (Row passes made each of the 32 workgroups re-evaluate every point that touches its
@@ -4344,7 +4346,18 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                         order.emplace_back(((uint32_t)fp_f[fp_start[l]] << 16) | (uint32_t)fp_f[fp_start[l + 1] - 1], l);
                         total_cost += 8.0 * k + 0.5 * k * (k + 1);
                     }
-                    std::sort(order.begin(), order.end());
+                    {   // by (first pose, last pose), then point: a counting sort over the np x np key space (std::sort of 2000 keys was 0.05 ms of the 0.45 ms create)
+                        const size_t nk = (size_t)np * np;
+                        if (order.size() > 64 && nk <= 65536) {
+                            bvec<int32_t> cnt(nk + 1, 0);
+                            auto key_of = [&](const std::pair<uint32_t, int32_t> &e) { return (size_t)(e.first >> 16) * np + (e.first & 0xFFFF); };
+                            for (const auto &e : order) cnt[key_of(e) + 1]++;
+                            for (size_t q = 0; q < nk; ++q) cnt[q + 1] += cnt[q];
+                            bvec<std::pair<uint32_t, int32_t>> sorted(order.size());
+                            for (const auto &e : order) sorted[cnt[key_of(e)]++] = e;      // (order is in point order: equal keys stay in it)
+                            order.swap(sorted);
+                        } else std::sort(order.begin(), order.end());
+                    }
                     double acc_cost = 0;
                     int g_lo = np, g_hi = 0;
                     group_pts.emplace_back();
@@ -4363,6 +4376,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                     for (size_t ps = 0; ps < F.row0.size(); ++ps) if (tile_need(F.row0[ps], F.row1[ps]) > kFsTileDoubles) F.by_points = false;
                     if (!F.by_points) { F.row0.clear(); F.row1.clear(); F.yoff.clear(); F.rowoff.clear(); group_pts.clear(); }
                 }
+                tm_lap(5);
                 if (!F.by_points) {
                     int r = 0;
                     while (r < np) {                                      // greedy row ranges under the tile budget
@@ -4400,7 +4414,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                             for (int jj = fp_start[l]; jj < fp_start[l + 1] && fp_f[jj] < r1; ++jj) { h = (h ^ (uint64_t)fp_f[jj]) * 1099511628211ull; fmin = std::min(fmin, (int)fp_f[jj]); fmax = fp_f[jj]; ++kk; }
                             pts.emplace_back(((uint64_t)fmin << 48) | ((uint64_t)fmax << 32) | ((uint64_t)(kk & 0xFF) << 24) | (h & 0xFFFFFFull), l);
                         }
+                    tm_lap(6);
                     std::sort(pts.begin(), pts.end());                    // points with the same set of poses next to each other: their pairs fall into the same blocks
+                    tm_lap(7);
                     int in_batch = 0;
                     bool uniform = true;                                  // every point of the open batch has the same pose set
                     uint64_t batch_key = 0;
@@ -4416,7 +4432,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                         while (F.pairs.size() % 8) F.pairs.push_back((uint16_t)0xFFFF);
                     };
                     auto pad_slots = [&]() {                              // a batch owns FS_OB lane slots (the kernel addresses batch b at slot FS_OB b): the rest hold "no observation"
-                        while ((F.pobs.size() / 4) % FS_OB) { F.pobs.push_back(-1); F.pobs.push_back(0); F.pobs.push_back(0); F.pobs.push_back(-1); }
+                        const size_t at = F.pobs.size(), slots = at / 4, padded = (slots + FS_OB - 1) / FS_OB * FS_OB;
+                        if (padded == slots) return;
+                        F.pobs.resize(4 * padded);
+                        for (size_t q = slots; q < padded; ++q) { F.pobs[4 * q] = -1; F.pobs[4 * q + 1] = 0; F.pobs[4 * q + 2] = 0; F.pobs[4 * q + 3] = -1; }
                     };
                     auto close_batch = [&](int pt_end) {
                         if (in_batch == 0) return;
@@ -4485,11 +4504,17 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                             const int jb = fp_start[pts[batch_first].second];
                             for (int a = 0; a < kk; ++a) if (fp_f[j0 + a] != fp_f[jb + a]) { uniform = false; break; }
                         }
-                        for (int a = 0; a < kk; ++a) { const int o = fp_o[j0 + a]; F.pobs.push_back(o); F.pobs.push_back(Q.obs_pose[o]); F.pobs.push_back(l); F.pobs.push_back(fp_f[j0 + a]); }
+                        {
+                            const size_t at = F.pobs.size();
+                            F.pobs.resize(at + 4 * (size_t)kk);
+                            int32_t *w = F.pobs.data() + at;
+                            for (int a = 0; a < kk; ++a, w += 4) { const int o = fp_o[j0 + a]; w[0] = o; w[1] = Q.obs_pose[o]; w[2] = l; w[3] = fp_f[j0 + a]; }
+                        }
                         in_batch += kk;
                     }
                     close_batch((int)pts.size());
                     F.batch_start.push_back((int32_t)F.b_obs_start.size() - 1);
+                    tm_lap(8);
                 }
                 F.b_obs_start.push_back(F.b_obs_start.back());
                 F.puv.assign(F.pobs.size(), 0.0);                         // per lane slot: u, v, information, 0
@@ -4497,8 +4522,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
                     const int o = F.pobs[4 * i];
                     if (o >= 0) { F.puv[4 * i] = Q.obs_uv[2 * (size_t)o]; F.puv[4 * i + 1] = Q.obs_uv[2 * (size_t)o + 1]; F.puv[4 * i + 2] = Q.obs_info[o]; }
                 }
+                tm_lap(9);
             }
         }
+        if (tm_on) { for (int k = 5; k <= 9; ++k) tm_part[3] += tm_part[k]; }
         tm_lap(3);
         {   // windowed Cholesky (cholesky_window): active 16-row blocks per panel, LDS slots, tiles entering per panel
             const int np = R.np_free, n6i = 6 * np, nblk = (n6i + 15) / 16;
@@ -4748,6 +4775,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             return ms_fail(c, MS_ERR_HIP, "ms_ba_create: device setup failed");
         }
     }
+    if (tm_on && std::getenv("MS_BA_TIMING")[0] == '2') std::fprintf(stderr, "  fused-pass batches: passes %.3f, point keys %.3f, sort %.3f, batches %.3f, values %.3f ms\n", tm_part[5], tm_part[6], tm_part[7], tm_part[8], tm_part[9]);
     if (tm_on) std::fprintf(stderr, "ms_ba_create: prep %.3f ms (CSR + envelope %.3f, record lists + panel lists %.3f, fused-pass batches %.3f, rest %.3f), alloc+upload %.3f ms, arena %.1f MB\n",
                             tm1 - tm0, tm_part[0], tm_part[2], tm_part[3], tm1 - tm0 - tm_part[0] - tm_part[2] - tm_part[3], tm_now() - tm1, total / 1e6);
     *out = B;
