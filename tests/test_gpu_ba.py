@@ -431,6 +431,29 @@ def test_pose_only_kernel_equals_the_general_solver_and_the_oracle(oracle, ctx, 
     ba.close()
 
 
+def test_per_frame_pose_problems_through_recycled_handles(oracle, ctx):
+    """The per-frame path (mapper_helpers.cpp:1043-1050: a NEW poseBundleAdjust problem per frame): handle objects, device blocks, the page-locked staging and result blocks
+    are recycled from problem to problem -- small, large, single and batched problems in turn, each checked against the oracle.  Covers: results packed behind the launch
+    (single problems up to 64 KB) and fetched the ordinary way (beyond, and batches); uploads staged without a wait (several problems side by side in the staging block) and
+    the per-problem path (a batch beyond the block); more observations than k_ba_pose_only keeps in registers (192 threads x 8) and none at all in the last slots; a second
+    solve of the same handle; a download without chi2."""
+    import mi355slam
+    small = _pose_ba_problem(31, 6, 60, 4, 3)
+    mid = _pose_ba_problem(32)
+    big = ba_synth.pose_only_from_window(ba_synth.make_problem(6, 4000, 6, seed=33), 3, use_gt_points=True)       # every point seen by every keyframe: 4000 observations of the free pose
+    assert len(big["obs_pose"]) > 192 * 8 and len(small["obs_pose"]) < 192 < len(mid["obs_pose"])
+    want = {id(q): oracle.ba_solve(q, 10, False) for q in (small, mid, big)}
+    for rep, batch in enumerate([[small], [big], [mid], [small, mid, small], [mid] * 20, [small], [big, small], [mid] * 300, [small], [mid]] * 2):
+        ba = mi355slam.BundleAdjuster(ctx, batch, max_iters=10)
+        ba.solve()
+        for i in (0, len(batch) - 1):
+            _check(batch[i], ba.download(i), want[id(batch[i])], strict_trajectory=False)
+        if rep % 3 == 0:                                                   # the same handle again: the eager results of the second launch, not the first's
+            ba.solve()
+            _check(batch[0], ba.download(0), want[id(batch[0])], strict_trajectory=False)
+        ba.close()
+
+
 def _stage1(p, cur):
     s = dict(p); s["pose_fixed"] = np.ones(len(p["pose"]), np.uint8); s["pose_fixed"][cur] = 0
     return s
