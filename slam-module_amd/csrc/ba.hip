@@ -539,7 +539,7 @@ __device__ __forceinline__ void poseobs_data(const BaProb &P, int o, int l, Pose
 // (point, observation) and (u, v, information) side by side: coalesced loads whose addresses depend on nothing, requested three and two steps ahead; only the
 // point's position is still a gather (one step ahead, from the 48 KB the window's points occupy).  Units of work are half poses, handed out from an LDS counter
 // (the waves of a SIMD do not run at the same speed); a unit's 27 sums leave with global atomics (Hpp's diagonal blocks and bp are zero at this point).
-__device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
+__device__ __noinline__ double linearise_stream(const BaProb &P_, double *lds_v) {      // returns this thread's share of the robust chi2 of the observations (the caller adds the shares up when it wants them)
     __shared__ int s_ls_next;
     const BaProb &P = *(const BaProb *)uglobal(&P_);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -551,6 +551,7 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
     const MS_GLOBAL int32_t *fstart = uglobal(P.fstart), *free2pose = uglobal(P.free2pose);
     MS_GLOBAL double *Hpp = (MS_GLOBAL double *)uglobal(P.Hpp), *bp = (MS_GLOBAL double *)uglobal(P.bp);
     const double hub = P.huber;
+    double chi2_share = 0;
     for (int i = tid; i < 9 * n_point; i += NT) ptab[i] = 0;
     if (tid == 0) s_ls_next = 0;
     __syncthreads();
@@ -587,6 +588,7 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
         proj_edge<true>(pose, X, uv, e, Jp, Jl);
         double rho, w;
         huber(info * (e[0] * e[0] + e[1] * e[1]), hub, rho, w);
+        chi2_share += rho;
         point_terms(r.x, r.y < 0, Jl, e, w * info);
     }
     // the free poses, a wave each (handed out from a counter: the waves of a SIMD do not run at the same speed)
@@ -635,6 +637,7 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
                     proj_edge<true>(pose, X0, uv, e, Jp, Jl);
                     double rho, w;
                     huber(o0.info * (e[0] * e[0] + e[1] * e[1]), hub, rho, w);
+                    chi2_share += rho;
                     const double wi = w * o0.info;
                     double Jw[12];
 #pragma unroll
@@ -672,6 +675,7 @@ __device__ __noinline__ void linearise_stream(const BaProb &P_, double *lds_v) {
         const int l = i / 9, c = i - 9 * l;
         if (c < 6) Hll[6 * l + c] = ptab[i]; else bl[3 * l + c - 6] = ptab[i];
     }
+    return chi2_share;
 }
 
 // robust chi2 of the current state for a window on ONE workgroup, from the same streams (eval_chi2 below walks observation -> pose / point index chains, per-lane
@@ -826,6 +830,9 @@ __device__ __noinline__ void backsub_stream(const BaProb &P_, double lambda_, do
 #ifndef MS_LIN_ABL
 #define MS_LIN_ABL 0
 #endif
+#ifndef MS_BA_NO_FUSED_TRIAL
+#define MS_BA_NO_FUSED_TRIAL 0  // 1: k_ba_lm never fuses a trial's chi2 with the next linearisation (A/B builds)
+#endif
 #ifndef MS_LIN_NO_STREAM
 #define MS_LIN_NO_STREAM 0          /* -DMS_LIN_NO_STREAM=1: round 3's per-pose pass over index chains (A/B runs) */
 #endif
@@ -836,7 +843,12 @@ extern "C" int ms_debug_linprof(long long *out) { return (int)hipMemcpyFromSymbo
 #else
 #define LINP(i) do { } while (0)
 #endif
-__device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
+// chi2_share (optional): the linearisation visits every edge at the current state anyway -- when the caller wants the robust chi2 of that state (a trial of the fused
+// schedule in k_ba_lm), every thread's share of it is added here (streamed, one-workgroup path only: the caller checks lin_streams())
+__device__ __forceinline__ bool lin_streams(const BaProb &P) {      // build_system takes the streamed path (linearise_stream) for this problem on ONE workgroup
+    return P.fused && 9 * (size_t)P.n_point + 64 <= kLdsBytes / 8 && P.fo_lo != nullptr && !MS_LIN_NO_STREAM;
+}
+__device__ __noinline__ void build_system(const BaProb &P_, double *lds_, double *chi2_share = nullptr) {
     const BaProb &P = P_;
     BA_IDS
     const int n6 = P.n6;
@@ -950,7 +962,7 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
     const bool one_pass = T_ == 1 && !obs_par && P.fused && 9 * (size_t)P.n_point + 64 <= kLdsBytes / 8;
     MS_LDS double *ptab1 = (MS_LDS double *)lds_;
     const bool stream = one_pass && P.fo_lo != nullptr && !MS_LIN_NO_STREAM;
-    if (stream) linearise_stream(P, lds_);
+    if (stream) { const double share = linearise_stream(P, lds_); if (chi2_share) *chi2_share += share; }
     if (one_pass && !stream) {
         for (int i = tid; i < 9 * P.n_point; i += NT) ptab1[i] = 0;
         __syncthreads();
@@ -1143,9 +1155,24 @@ __device__ __noinline__ void build_system(const BaProb &P_, double *lds_) {
             const int k0 = rd * EB, kn = min(EB, P.n_edge - k0);
             if (tid < kn) {
                 const int k = k0 + tid, vi = P.edge_i[k], vj = P.edge_j[k];
-                if (P.pidx[vi] >= 0 || P.pidx[vj] >= 0) {
+                const bool touches = P.pidx[vi] >= 0 || P.pidx[vj] >= 0;
+                if (!touches && chi2_share) {                                     // an edge between fixed poses: a constant, but part of the chi2
+                    double e[6];
+                    pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, nullptr, nullptr, false);
+                    const double *W = P.edge_info + 36 * (size_t)k;
+                    double c2 = 0;
+                    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) c2 += e[i] * W[6 * i + j] * e[j];
+                    *chi2_share += c2;
+                }
+                if (touches) {
                     double e[6], Ji[36], Jj[36];
                     pose_edge(P.pose + 7 * (size_t)vi, P.pose + 7 * (size_t)vj, P.edge_meas + 7 * (size_t)k, e, Ji, Jj, true);
+                    if (chi2_share) {
+                        const double *W = P.edge_info + 36 * (size_t)k;
+                        double c2 = 0;
+                        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) c2 += e[i] * W[6 * i + j] * e[j];
+                        *chi2_share += c2;
+                    }
                     MS_LDS double *d = eb + tid * ES;
 #pragma unroll
                     for (int q = 0; q < 6; ++q) d[q] = e[q];
@@ -2934,7 +2961,11 @@ __global__ __launch_bounds__(256) void k_ba_copy_state(const BaProb *dst, const 
 #else
 #define MS_BA_OCC
 #endif
-__global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int team) {
+// alt (one workgroup per problem, streamed phases; else nullptr): the same problems with the linearisation's outputs -- Hpp, bp, Hll, bl -- pointing at a SECOND set of
+// arrays.  The chi2 of a trial state and the linearisation of the next iteration walk the same observations at the same state when the trial is accepted: a trial
+// then linearises into the set that is not in use and takes its chi2 from the same pass (build_system's chi2_share); accepted, the two descriptors change roles,
+// rejected, the old set is still there.  One pass over the observations per trial instead of two per iteration.
+__global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int team, const BaProb *alt) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double s_red[NW];
     const BaProb &P = probs[blockIdx.x / (unsigned)team];      // fields stay in constant memory: uniform scalar loads, no private copy
@@ -2952,20 +2983,30 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
     const long long t_begin = clock64();
     // one workgroup per window, streams built, pose table in LDS: the streamed phases (eval_stream, backsub_stream)
     const bool ev_stream = P.team == 1 && P.fo_lo != nullptr && 7 * (size_t)P.n_pose <= kLdsBytes / 8 && !MS_LIN_NO_STREAM;
-    const double chi2_init = ev_stream ? eval_stream(P, lds, s_red, false, 0.0, nullptr) : eval_chi2(P, s_red, false, seq);
+    const bool fuse = ev_stream && alt != nullptr && lin_streams(P) && !MS_BA_NO_FUSED_TRIAL;
+    const BaProb *Pc = &P, *Pa = fuse ? &alt[blockIdx.x] : &P;            // the descriptor whose linearisation belongs to the accepted state / the other one
+    // chi2 of the state as it stands + its linearisation into *Q, one pass (fused schedule); extra / extra_sum as in eval_stream
+    auto linearise_and_chi2 = [&](const BaProb &Q, double extra, double *extra_sum) {
+        double share = 0;
+        build_system(Q, lds, &share);
+        const double total = block_sum(share, s_red);
+        if (extra_sum) *extra_sum = block_sum(extra, s_red);
+        return total;
+    };
+    const double chi2_init = fuse ? linearise_and_chi2(*Pc, 0.0, nullptr) : ev_stream ? eval_stream(P, lds, s_red, false, 0.0, nullptr) : eval_chi2(P, s_red, false, seq);
     double chi2_carried = chi2_init;
     for (it = 0; it < P.max_iters; ++it) {
         long long tt = clock64();
         // g2o evaluates activeRobustChi2 again here; the state is the one the last accepted (or restored) trial left, so it is the same number
         double current = chi2_carried, temp = current;
         { const long long t1 = clock64(); cyc[0] += t1 - tt; tt = t1; }
-        build_system(P, lds);
+        if (!fuse) build_system(P, lds);                 // (fused schedule: the state's linearisation exists already -- the initial pass, or the trial that was accepted)
         cyc[1] += clock64() - tt;
         if (it == 0) {                                   // computeLambdaInit
             double md = 0;
-            for (int i = gt; i < n6; i += GT) md = fmax(md, fabs(P.Hpp[(size_t)i * n6 + i]));
+            for (int i = gt; i < n6; i += GT) md = fmax(md, fabs(Pc->Hpp[(size_t)i * n6 + i]));
             for (int l = gt; l < P.n_point; l += GT)
-                if (!(P.point_fixed && P.point_fixed[l])) { const double *h = P.Hll + 6 * (size_t)l; md = fmax(md, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])))); }
+                if (!(P.point_fixed && P.point_fixed[l])) { const double *h = Pc->Hll + 6 * (size_t)l; md = fmax(md, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])))); }
             lambda = 1e-5 * team_reduce(P, md, s_red, true, seq); ni = 2;
         }
         double rho = 0;
@@ -2973,7 +3014,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
         do {
             // push() happens where the state is changed: the update below saves every value it overwrites (a trial whose system cannot be solved changes nothing
             // and needs neither the copy nor the restore) -- one walk over the state per trial instead of three (save, update, gain denominator)
-            const bool ok2 = solve_step(P, lambda, lds, cyc);
+            const bool ok2 = solve_step(*Pc, lambda, lds, cyc);
             tt = clock64();
             // re-arm the flag for the next damped solve: on the good path every workgroup has read it before point_backsub's barrier; on the
             // (rare) failed path an extra barrier separates the reads from the write.  The barriers that follow order it before the next solve's phases.
@@ -2990,7 +3031,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
                     for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = r[a];
                 }
                 {
-                    const MS_GLOBAL double *gdl = uglobal(P.dl), *gbl = uglobal(P.bl);
+                    const MS_GLOBAL double *gdl = uglobal(P.dl), *gbl = uglobal(Pc->bl);
                     MS_GLOBAL double *gpt = (MS_GLOBAL double *)uglobal(P.point), *gbk = (MS_GLOBAL double *)uglobal(P.point_bk);
                     const int n3 = 3 * P.n_point;
 #pragma unroll 4
@@ -3003,8 +3044,8 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
                 team_sync(P);
             }
             cyc[4] += clock64() - tt; tt = clock64();
-            if (ok2) for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + P.bp[i]);
-            temp = ok2 ? (ev_stream ? eval_stream(P, lds, s_red, false, sc, &scale) : eval_chi2(P, s_red, false, seq, sc, &scale)) : DBL_MAX;     // chi2 of the new state and the gain denominator behind one team barrier
+            if (ok2) for (int i = gt; i < n6; i += GT) sc += P.dp[i] * (lambda * P.dp[i] + Pc->bp[i]);
+            temp = ok2 ? (fuse ? linearise_and_chi2(*Pa, sc, &scale) : ev_stream ? eval_stream(P, lds, s_red, false, sc, &scale) : eval_chi2(P, s_red, false, seq, sc, &scale)) : DBL_MAX;     // chi2 of the new state and the gain denominator behind one team barrier
             scale += 1e-3;
             cyc[0] += clock64() - tt;
             rho = (current - temp) / scale;
@@ -3015,6 +3056,7 @@ __global__ __launch_bounds__(NT) MS_BA_OCC void k_ba_lm(const BaProb *probs, int
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
                 ni = 2; current = temp; chi2_carried = temp;
+                if (fuse) { const BaProb *t = Pc; Pc = Pa; Pa = t; }                      // the trial's linearisation is the accepted state's
             } else {
                 lambda *= ni; ni *= 2;
                 if (ok2) {                                                                  // pop(): only a trial that moved the state has something to take back
@@ -3997,6 +4039,13 @@ struct ms_ba {
     std::vector<BaProb> host;          // device pointers inside
     std::vector<ms_ba_problem> dims;   // sizes only
     BaProb *d_probs = nullptr;
+    // k_ba_lm's fused trial schedule: the same descriptors with Hpp / bp / Hll / bl pointing at a second set of arrays (behind d_probs on the device); alt_ptrs[i].Hpp == nullptr:
+    // problem i has no second set and the whole handle runs the plain schedule
+    struct AltPtrs { double *Hpp, *bp, *Hll, *bl; };
+    std::vector<AltPtrs> alt_ptrs;
+    std::vector<BaProb> host_alt;
+    BaProb *d_probs_alt = nullptr;
+    bool alt_ok = false;
     char *d_arena = nullptr;
     size_t arena_bytes = 0;
     int team = 0;                      // workgroups per problem of the next launch (ms_ba_set_team; 0 = automatic)
@@ -4038,6 +4087,25 @@ constexpr size_t kBaEagerMax = (size_t)64 << 10;        // results of a single p
                                                         //  sequence, running beside it, fell from 2.7-3.0 k to 2.0-2.2 k frames/s -- tools/together_ab.sh; kept for small problems)
 constexpr size_t kBaStageMax = (size_t)4 << 20;        // creates whose inputs fit are uploaded from the context's page-locked staging block without a wait
 static size_t ba_eager_max() { static const size_t v = std::getenv("MS_BA_EAGER_MAX") ? (size_t)std::atoll(std::getenv("MS_BA_EAGER_MAX")) : kBaEagerMax; return v; }     // (experiment knob)
+// the descriptors of the second linearisation set: host_alt[i] = host[i] with the four output arrays exchanged (rebuilt whenever host[] is about to be uploaded: the
+// two must agree in everything else -- team sizes included)
+static void ba_make_alt(ms_ba *B) {
+    B->host_alt.assign(B->host.begin(), B->host.end());
+    B->alt_ok = !B->host.empty() && B->alt_ptrs.size() == B->host.size();
+    for (size_t i = 0; i < B->host_alt.size() && B->alt_ok; ++i) {
+        const ms_ba::AltPtrs &a = B->alt_ptrs[i];
+        if (!a.Hpp) { B->alt_ok = false; break; }
+        BaProb &q = B->host_alt[i];
+        q.Hpp = a.Hpp; q.bp = a.bp; q.Hll = a.Hll; q.bl = a.bl;
+    }
+}
+// (both descriptor sets, in stream order)
+static hipError_t ba_upload_descriptors(ms_ba *B, hipStream_t st) {
+    ba_make_alt(B);
+    hipError_t e = hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(B->d_probs_alt, B->host_alt.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, st);
+    return e;
+}
 // The end of a handle's last launch, as an event the handle owns: whatever reads the launch's results waits for it ON THE HOST, politely (ba_wait_event), before it
 // enqueues anything -- not with hipStreamSynchronize, and not with a wait packet behind the launch (round 4, tools/hog_probe.py: a stream with packets queued behind
 // a 2 ms kernel slowed the front end of ANOTHER sequence 10 ... 90 x, one that holds one launch at a time 3 ... 15 x).
@@ -4153,7 +4221,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red, pack; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red, pack, Hpp2, bp2, Hll2, bl2; };
     bvec<Off> off(n);
     bvec<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -4604,6 +4672,9 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         O.panG = R.np_free > kMaxFreePoses ? bump((n6 + 17) * NB * D) : 0;
         O.bar = bump(256); O.red = bump(4 * kMaxTeam * D); O.flag = bump(256);     // team state on lines of their own (bump aligns to 256 B)
         O.op_rec = bump(R.one_pose ? 28 * (size_t)Q.n_point * D : 8); O.op_red = bump(R.one_pose ? 2 * (size_t)kMaxTeam * OP_NV * D : 8);
+        // the second set of the linearisation's outputs (k_ba_lm's fused trial schedule): only for handles whose launches run one workgroup per problem on the streams
+        const bool alt_set = !R.fo_lo.empty() && R.fused;
+        O.Hpp2 = bump(alt_set ? n6 * n6 * D : 8); O.bp2 = bump(alt_set ? n6 * D : 8); O.Hll2 = bump(alt_set ? 6 * Q.n_point * D : 8); O.bl2 = bump(alt_set ? 3 * Q.n_point * D : 8);
         // a single small problem gets its results packed behind every launch (ba_after_launch): status, poses, points, chi2 per observation
         const size_t pack_doubles = 16 + 7 * (size_t)Q.n_pose + 3 * (size_t)Q.n_point + (size_t)Q.n_obs;
         O.pack = bump(n == 1 && pack_doubles * D <= ba_eager_max() ? pack_doubles * D : 8);
@@ -4614,7 +4685,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     if (!B) { B = new ms_ba(); ++g_ba_host_allocs; }
     B->ctx = c; B->n = n;
     {   // ONE device block per handle (arena + the problem descriptors behind it), taken from the context's cache of destroyed handles when one is large enough
-        const size_t probs_at = ms_align_up(total, 256), need = probs_at + sizeof(BaProb) * n;
+        const size_t probs_at = ms_align_up(total, 256), need = probs_at + 2 * sizeof(BaProb) * n;
         // best fit among the kept blocks, but never one more than kBaCacheSlack times the request: a small window must not sit on the
         // gigabytes a global-BA handle left behind (that block waits for the next large request, or goes when the cache is trimmed)
         int best = -1;
@@ -4635,9 +4706,10 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             B->arena_bytes = need;
         }
         B->d_probs = reinterpret_cast<BaProb *>(B->d_arena + probs_at);
+        B->d_probs_alt = B->d_probs + n;
     }
     // small creates (a pose-only problem per frame, a window per keyframe) stage all their inputs in the context's own page-locked block and do not wait for the copies
-    size_t stage_need = sizeof(BaProb) * n, stage_at = 0;
+    size_t stage_need = 2 * sizeof(BaProb) * n, stage_at = 0;
     for (int p = 0; p < n; ++p) stage_need += ms_align_up(in_hi[p] - in_lo[p], (size_t)256);
     const bool staged = stage_need <= kBaStageMax;
     if (staged) {
@@ -4744,6 +4816,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.op_rec = R.one_pose ? PTR(double, op_rec) : nullptr; H.op_red = R.one_pose ? PTR(double, op_red) : nullptr;
         if (p == 0) B->one_pose = R.one_pose; else B->one_pose = B->one_pose && R.one_pose;
         if (n == 1 && B->pack_doubles) B->d_pack = PTR(double, pack);
+        B->alt_ptrs.push_back(!R.fo_lo.empty() && R.fused ? ms_ba::AltPtrs{PTR(double, Hpp2), PTR(double, bp2), PTR(double, Hll2), PTR(double, bl2)} : ms_ba::AltPtrs{nullptr, nullptr, nullptr, nullptr});
         B->chol_tiles.push_back(R.chol_tiles);
         {   // poseBundleAdjust-shaped: one free pose, no free point
             bool po = R.np_free == 1 && problems[p].n_pose_edge <= PO_MAXE;
@@ -4754,12 +4827,18 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     }
     {
         hipError_t e;
-        if (staged) {                                       // the descriptors follow the inputs out of the same block; its next user waits for ba_stage_ev
-            std::memcpy(static_cast<char *>(c->ba_stage) + stage_at, B->host.data(), sizeof(BaProb) * n);
-            e = hipMemcpyAsync(B->d_probs, static_cast<char *>(c->ba_stage) + stage_at, sizeof(BaProb) * n, hipMemcpyHostToDevice, c->stream);
+        ba_make_alt(B);
+        if (staged) {                                       // the descriptors (both sets, side by side like on the device) follow the inputs out of the same block; its next user waits for ba_stage_ev
+            char *at = static_cast<char *>(c->ba_stage) + stage_at;
+            std::memcpy(at, B->host.data(), sizeof(BaProb) * n);
+            std::memcpy(at + sizeof(BaProb) * n, B->host_alt.data(), sizeof(BaProb) * n);
+            e = hipMemcpyAsync(B->d_probs, at, 2 * sizeof(BaProb) * n, hipMemcpyHostToDevice, c->stream);
             if (e == hipSuccess) e = hipEventRecord(c->ba_stage_ev, c->stream);
             c->ba_stage_busy = e == hipSuccess;
-        } else e = hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice);
+        } else {
+            e = hipMemcpy(B->d_probs, B->host.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(B->d_probs_alt, B->host_alt.data(), sizeof(BaProb) * n, hipMemcpyHostToDevice);
+        }
         // the solvers' dynamic LDS sizes: once per device and process
         static std::atomic<unsigned long long> attr_done{0};
         if (e == hipSuccess && !((attr_done.load() >> (c->device & 63)) & 1ull)) {
@@ -4818,10 +4897,11 @@ void ms_ba_destroy(ms_ba *B) {
             const hipEvent_t ev = B->ev_done;
             void *const hres = B->h_result; const size_t hres_bytes = B->h_result_bytes;
             int32_t *const hver = B->h_verdict;
-            std::vector<BaProb> host = std::move(B->host); std::vector<ms_ba_problem> dims = std::move(B->dims); std::vector<double> tiles = std::move(B->chol_tiles);
-            host.clear(); dims.clear(); tiles.clear();
+            std::vector<BaProb> host = std::move(B->host), host_alt = std::move(B->host_alt); std::vector<ms_ba_problem> dims = std::move(B->dims); std::vector<double> tiles = std::move(B->chol_tiles);
+            std::vector<ms_ba::AltPtrs> alt_ptrs = std::move(B->alt_ptrs);
+            host.clear(); host_alt.clear(); dims.clear(); tiles.clear(); alt_ptrs.clear();
             *B = ms_ba();
-            B->host = std::move(host); B->dims = std::move(dims); B->chol_tiles = std::move(tiles); B->ev_done = ev;
+            B->host = std::move(host); B->host_alt = std::move(host_alt); B->alt_ptrs = std::move(alt_ptrs); B->dims = std::move(dims); B->chol_tiles = std::move(tiles); B->ev_done = ev;
             B->h_result = hres; B->h_result_bytes = hres_bytes; B->h_verdict = hver;
             *slot = B;
             return;
@@ -4898,7 +4978,7 @@ int ms_ba_solve(ms_ba *B) {
             const size_t lds = ((size_t)op_pose_doubles + (size_t)OP_NW * 27 * op_slab_cap(lgG)) * sizeof(double);
             if ((long long)(tm * OP_NT >> lgG) >= most_points) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n * tm), dim3(OP_NT), lds, ls, B->d_probs, tm, lgG, op_pose_doubles);
             else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n * tm), dim3(OP_NT), lds, ls, B->d_probs, tm, lgG, op_pose_doubles);
-        } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, ls, B->d_probs, tm);
+        } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n * tm), dim3(NT), kLdsBytes, ls, B->d_probs, tm, (tm == 1 && B->alt_ok) ? B->d_probs_alt : static_cast<const BaProb *>(nullptr));
     };
     B->last_one_pose = one_pose; B->one_pose_lg = lgG;
     // the distributed factorisation is barrier-bound on banded systems: it gets one workgroup per 16 row tiles a panel touches
@@ -4910,7 +4990,7 @@ int ms_ba_solve(ms_ba *B) {
     }
     if (changed) {
         for (auto &h : B->host) h.team = team;
-        MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, ls));
+        MS_HIP(c, ba_upload_descriptors(B, ls));
     }
     // A plain launch: every workgroup needs more than half a CU's LDS and problems x team <= CUs, so all of a team's workgroups
     // become resident as soon as CUs are free.  What the spin barriers additionally need is that no OTHER team launch holds CUs
@@ -4982,7 +5062,7 @@ static int ba_relaunch_single(ms_ba *B) {
     const hipStream_t ls = c->stream;
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
     B->eager = false; B->verdict_eager = false;                     // (what h_result / h_verdict hold belongs to the void launch)
-    MS_HIP(c, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, ls));
+    MS_HIP(c, ba_upload_descriptors(B, ls));
     if (B->last_one_pose) {
         int most_poses = 0, most_points = 0;
         for (const auto &h : B->host) { most_poses = std::max(most_poses, h.n_pose); most_points = std::max(most_points, h.n_point); }
@@ -4990,7 +5070,7 @@ static int ba_relaunch_single(ms_ba *B) {
         const size_t lds = ((size_t)pd + (size_t)OP_NW * 27 * op_slab_cap(0)) * sizeof(double);
         if (most_points <= OP_NT) hipLaunchKernelGGL(k_ba_one_pose<true>, dim3(B->n), dim3(OP_NT), lds, ls, B->d_probs, 1, 0, pd);
         else hipLaunchKernelGGL(k_ba_one_pose<false>, dim3(B->n), dim3(OP_NT), lds, ls, B->d_probs, 1, 0, pd);
-    } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, ls, B->d_probs, 1);
+    } else hipLaunchKernelGGL(k_ba_lm, dim3(B->n), dim3(NT), kLdsBytes, ls, B->d_probs, 1, B->alt_ok ? B->d_probs_alt : static_cast<const BaProb *>(nullptr));
     MS_KERNEL_CHECK(c, "k_ba_lm");
     MS_TRY_BA(ba_launch_done(c, B));
     MS_TRY_BA(ba_wait_pending(B));
