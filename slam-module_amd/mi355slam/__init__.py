@@ -167,6 +167,12 @@ class Context:
         self.check(lib().ms_dev_upload(self._h, C.c_void_p(b.ptr), _vp(arr), C.c_size_t(arr.nbytes)), "ms_dev_upload")
         return b
 
+    def _adopt(self, obj):
+        """obj must be destroyed before the context: kept as a weak reference (the list is pruned as it grows -- a problem per frame must not leave a reference per frame)."""
+        if len(self._children) > 1024:
+            self._children = [r for r in self._children if r() is not None]
+        self._children.append(weakref.ref(obj))
+
     def close(self):
         if self._h:
             for r in self._children:
@@ -193,9 +199,7 @@ class DevBuf:
         self.ctx, self.nbytes = ctx, int(nbytes)
         p = C.c_void_p()
         ctx.check(lib().ms_dev_alloc(ctx._h, C.c_size_t(self.nbytes), C.byref(p)), "ms_dev_alloc")
-        if len(ctx._children) > 4096:
-            ctx._children = [r for r in ctx._children if r() is not None]
-        ctx._children.append(weakref.ref(self))
+        ctx._adopt(self)
         self.ptr = p.value or 0
         self.shape, self.dtype = None, None
 
@@ -255,7 +259,7 @@ class OrbExtractor:
         self.cfg = OrbConfig(width, height, levels, scale_factor, max_kpts, lk_track_level, fast_threshold, max_tracks, max_batch, min_distance)
         self._h = C.c_void_p()
         ctx.check(lib().ms_orb_create(ctx._h, C.byref(self.cfg), C.byref(self._h)), "ms_orb_create")
-        ctx._children.append(weakref.ref(self))
+        ctx._adopt(self)
         self.capacity = lib().ms_orb_capacity(self._h)
 
     def set_valid_mask(self, mask):
@@ -506,7 +510,7 @@ class BowVocabulary:
         ctx.check(lib().ms_bow_vocab_create(ctx._h, len(par), par.ctypes.data_as(C.c_void_p), nd.ctypes.data_as(C.c_void_p),
                                             wt.ctypes.data_as(C.c_void_p), wd.ctypes.data_as(C.c_void_p), int(depth_levels), C.byref(h)), "ms_bow_vocab_create")
         self._h = h
-        ctx._children.append(weakref.ref(self))
+        ctx._adopt(self)
 
     def transform(self, desc, levels_up=4):
         """desc: host array [n, 8] u32 or a device buffer (then pass n via a tuple (buf, n)).  Returns word, weight, node (host arrays)."""
@@ -651,7 +655,7 @@ class BundleAdjuster:
         arr = (BaProblemC * self.n)(*structs)
         self._h = C.c_void_p()
         ctx.check(lib().ms_ba_create(ctx._h, arr, self.n, C.byref(self._h)), "ms_ba_create")
-        ctx._children.append(weakref.ref(self))
+        ctx._adopt(self)
 
     def set_team(self, workgroups_per_problem):
         self.ctx.check(lib().ms_ba_set_team(self._h, int(workgroups_per_problem)), "ms_ba_set_team")
