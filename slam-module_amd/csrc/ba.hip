@@ -5187,7 +5187,7 @@ int ms_ba_debug_force_reject(ms_ba *B, int first_trials) {
     if (B->pose_only || B->one_pose) return ms_fail(B->ctx, MS_ERR_INVALID, "ms_ba_debug_force_reject: only the general solver (k_ba_lm) has the hook");
     for (auto &h : B->host) h.debug_reject = first_trials;
     MS_HIP(B->ctx, hipSetDevice(B->ctx->device));
-    MS_HIP(B->ctx, hipMemcpyAsync(B->d_probs, B->host.data(), sizeof(BaProb) * B->n, hipMemcpyHostToDevice, B->ctx->stream));
+    MS_HIP(B->ctx, ba_upload_descriptors(B, B->ctx->stream));          // (both sets: the fused trial schedule reads whichever is in use)
     return MS_OK;
 }
 
