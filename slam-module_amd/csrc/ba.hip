@@ -130,6 +130,7 @@ struct BaProb {
     const double *op_uvi;
     double *op_rec, *op_red;
     // results
+    double *pack;                            // k_ba_pose_only: the block ms_ba_download reads ([16 stats][7 n_pose][3 n_point][n_obs chi2]) is written by the solver itself (null: k_ba_pack_result does it)
     double *stats;                           // [16]: iters, trials, stop, lambda, chi2_init, chi2_final, ok, -, then cycles per phase:
                                              //       8 eval, 9 linearise, 10 Schur, 11 Cholesky+backsub, 12 points+update, 13 total
 };
@@ -3181,8 +3182,11 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
     const long long t_kernel = clock64();
     const BaProb &P = probs[blockIdx.x];
     const int tid = threadIdx.x, pi = P.free2pose[0];
-    for (int i = tid; i < 7 * P.n_pose; i += PO_NT) P.pose[i] = P.pose0[i];
-    for (int i = tid; i < 3 * P.n_point; i += PO_NT) P.point[i] = P.point0[i];
+    // the block ms_ba_download fetches -- [16 stats][7 n_pose poses][3 n_point points][n_obs chi2] -- is filled as the values arise (a single problem: BaProb::pack)
+    MS_GLOBAL double *pk = (MS_GLOBAL double *)uglobal(P.pack);
+    MS_GLOBAL double *pk_pose = pk + 16, *pk_point = pk_pose + 7 * P.n_pose, *pk_chi2 = pk_point + 3 * P.n_point;
+    for (int i = tid; i < 7 * P.n_pose; i += PO_NT) { const double v = P.pose0[i]; P.pose[i] = v; if (pk) pk_pose[i] = v; }
+    for (int i = tid; i < 3 * P.n_point; i += PO_NT) { const double v = P.point0[i]; P.point[i] = v; if (pk) pk_point[i] = v; }
     if (tid < 24) s_Hc[tid] = 0;
     if (tid == 0) { s_ne = 0; s_const = 0; s_any = P.n_obs; }
     __syncthreads();
@@ -3232,6 +3236,7 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
         const double chi2 = P.obs_info[o] * (e[0] * e[0] + e[1] * e[1]);
         huber(chi2, P.huber, r, w);
         P.chi2_obs[o] = chi2;
+        if (pk) pk_chi2[o] = chi2;
         cacc += r;
     }
     if (tid >= PO_OT) cacc += po_edges_setup(P, pi, tid - PO_OT, &s_ne, s_eSide, &s_eC[0][0], &s_eM[0][0], &s_eG[0][0], &s_eW[0][0], s_Hc, s_J);   // (wave 3, beside the observation loads)
@@ -3422,23 +3427,24 @@ __global__ __launch_bounds__(PO_NT) void k_ba_pose_only(const BaProb *probs) {
     }
     // the chi2 per observation of the accepted state: from the registers; the observations beyond them are evaluated once more
 #pragma unroll
-    for (int j = 0; j < PO_K; ++j) if ((have >> j) & 1u) P.chi2_obs[tid + PO_OT * j] = c2[j];
+    for (int j = 0; j < PO_K; ++j) if ((have >> j) & 1u) { P.chi2_obs[tid + PO_OT * j] = c2[j]; if (pk) pk_chi2[tid + PO_OT * j] = c2[j]; }
     if (overflow && tid < PO_OT)
         for (int o = tid + PO_OT * PO_K; o < P.n_obs; o += PO_OT) {
             if (P.obs_pose[o] != pi) continue;
             double e[2], Jp[12], Jl[6];
             proj_edge<true>(pose, P.point0 + 3 * (size_t)P.obs_point[o], P.obs_uv + 2 * (size_t)o, e, Jp, Jl);     // (the arithmetic of the sweeps)
             P.chi2_obs[o] = P.obs_info[o] * (e[0] * e[0] + e[1] * e[1]);
+            if (pk) pk_chi2[o] = P.chi2_obs[o];
         }
     const double chi2_final = chi2_carried;                                 // the sweep that was accepted last evaluated exactly this state
-    if (tid == PO_OT) P.stats[9] = (double)pc[1];
+    if (tid == PO_OT) { P.stats[9] = (double)pc[1]; if (pk) pk[9] = (double)pc[1]; }
     if (tid == 0) {
-        for (int a = 0; a < 7; ++a) P.pose[7 * (size_t)pi + a] = pose[a];
-        P.stats[0] = it; P.stats[1] = trials; P.stats[2] = stop; P.stats[3] = lambda; P.stats[4] = chi2_init; P.stats[5] = chi2_final;
-        P.stats[6] = isfinite(chi2_final) ? 1 : 0; P.stats[7] = 0;
-        P.stats[8] = (double)pc[0]; P.stats[10] = (double)pc[2]; P.stats[11] = (double)pc[3]; P.stats[12] = 0;
-        P.stats[13] = (double)(clock64() - t_begin);       // (MS_PO_PROF off: only this and the next: cycles of the iterations, cycles of what came before them)
-        P.stats[14] = (double)(t_begin - t_kernel); P.stats[15] = 0;
+        // [13], [14]: cycles of the iterations and of what came before them (the only stamps with MS_PO_PROF off); [9] is the edge wave's (above)
+        const double st[16] = {(double)it, (double)trials, (double)stop, lambda, chi2_init, chi2_final, isfinite(chi2_final) ? 1.0 : 0.0, 0.0,
+                               (double)pc[0], 0.0, (double)pc[2], (double)pc[3], 0.0, (double)(clock64() - t_begin), (double)(t_begin - t_kernel), 0.0};
+        for (int a = 0; a < 7; ++a) { P.pose[7 * (size_t)pi + a] = pose[a]; if (pk) pk_pose[7 * (size_t)pi + a] = pose[a]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q != 9) { P.stats[q] = st[q]; if (pk) pk[q] = st[q]; }
     }
 }
 
@@ -4069,6 +4075,9 @@ struct ms_ba {
     int32_t *h_verdict = nullptr;      // page-locked word, stays with the handle object: "a team barrier gave up somewhere in the last launch", collected behind every team launch
     bool verdict_eager = false;        // h_verdict belongs to the last launch
     bool eager = false;                // h_result holds the last launch's results
+    bool self_packed = false;          // the last launch was k_ba_pose_only with BaProb::pack set: d_pack is already what k_ba_pack_result would write
+    bool work_dirty = false;           // a pose-only handle whose work areas [work_lo[p], work_hi[p]) were never cleared: the general kernel needs them zero (ms_ba_solve)
+    std::vector<size_t> work_lo, work_hi;
     bool quiet = false;                // everything this handle put on the stream is known to have finished (ev_done was seen, nothing enqueued since): ms_ba_destroy need not wait
     hipEvent_t ev_done = nullptr;      // the end of this handle's last launch (what reads its results waits for it ON THE HOST, politely: ba_wait_event)
     bool pending = false;
@@ -4221,7 +4230,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
     size_t total = 0;
     auto bump = [&](size_t bytes) { size_t o = total; total += ms_align_up(bytes ? bytes : 8, 256); return o; };
     struct Off { size_t pose, pose_bk, pose0, point, point_bk, point0, pidx, pfix, obs_pose, obs_point, obs_uv, obs_info, pt_start, pt_obs, fstart, fobs, fo_lo, fo_uvi,
-                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red, pack, Hpp2, bp2, Hll2, bl2; };
+                 free2pose, edge_i, edge_j, edge_meas, edge_info, Hpp, S, bp, dp, y, Hll, bl, Hinv, Hpl, dl, chi2, stats, chunk_items, seg_start, seg_pair, Y, zrow, bar, red, flag, dinv, env16, panG, act_start, act_blk, fs_cs, fs_row0[2], fs_row1[2], fs_batch[2], fs_bobs[2], fs_brun[2], fs_bfmt[2], fs_pobs[2], fs_puv[2], fs_pairs[2], fs_rowoff[2], fs_yoff[2], cw_slot, cw_act_start, cw_act, cw_load_start, cw_load, op_pose, op_o, op_uvi, op_rec, op_red, pack, Hpp2, bp2, Hll2, bl2, desc; };
     bvec<Off> off(n);
     bvec<size_t> in_lo(n), in_hi(n);
     for (int p = 0; p < n; ++p) {
@@ -4662,6 +4671,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             O.fs_pairs[set] = bump(2 * F.pairs.size() + 16); O.fs_rowoff[set] = bump(4 * F.rowoff.size()); O.fs_yoff[set] = bump(4 * F.yoff.size());
         }
         O.op_pose = bump(4 * R.op_pose.size()); O.op_o = bump(4 * R.op_o.size()); O.op_uvi = bump(sizeof(double) * R.op_uvi.size());
+        O.desc = n == 1 ? bump(2 * sizeof(BaProb)) : 0;             // a single problem's two descriptors travel with its inputs: ONE copy per create
         in_hi[p] = total;
         O.pose = bump(7 * Q.n_pose * D); O.pose_bk = bump(7 * Q.n_pose * D); O.point = bump(3 * Q.n_point * D); O.point_bk = bump(3 * Q.n_point * D);
         O.Hpp = bump(n6 * n6 * D); O.S = bump(n6 * n6 * D); O.bp = bump(n6 * D); O.dp = bump(n6 * D); O.y = bump(n6 * D);
@@ -4705,7 +4715,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             if (e != hipSuccess) { (void)hipGetLastError(); ba_delete_object(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: cannot allocate %zu bytes: %s", need, hipGetErrorString(e)); }
             B->arena_bytes = need;
         }
-        B->d_probs = reinterpret_cast<BaProb *>(B->d_arena + probs_at);
+        B->d_probs = reinterpret_cast<BaProb *>(B->d_arena + (n == 1 ? off[0].desc : probs_at));
         B->d_probs_alt = B->d_probs + n;
     }
     // small creates (a pose-only problem per frame, a window per keyframe) stage all their inputs in the context's own page-locked block and do not wait for the copies
@@ -4737,9 +4747,20 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             B->h_result_bytes = want;
         }
     }
-    {
-        const hipError_t e = hipMemsetAsync(B->d_arena, 0, total, c->stream);
-        if (e != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: clearing the arena failed: %s", hipGetErrorString(e)); }
+    {   // poseBundleAdjust-shaped handles (one free pose, no free point, <= PO_MAXE edges): k_ba_pose_only reads nothing it has not been given or written itself, so the
+        // arena is not cleared now -- ms_ba_solve clears the work areas (everything behind the inputs) should the general kernel ever run on the handle
+        bool all_po = true;
+        for (int p = 0; p < n && all_po; ++p) {
+            all_po = prep[p].np_free == 1 && problems[p].n_pose_edge <= PO_MAXE && problems[p].point_fixed != nullptr;
+            for (int l = 0; l < problems[p].n_point && all_po; ++l) all_po = problems[p].point_fixed[l] != 0;
+        }
+        B->work_dirty = all_po;
+        if (!all_po) {
+            const hipError_t e = hipMemsetAsync(B->d_arena, 0, total, c->stream);
+            if (e != hipSuccess) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: clearing the arena failed: %s", hipGetErrorString(e)); }
+        }
+        B->work_lo.assign(in_hi.begin(), in_hi.begin() + n); B->work_hi.resize(n);
+        for (int p = 0; p < n; ++p) B->work_hi[p] = p + 1 < n ? in_lo[p + 1] : total;
     }
     B->host.resize(n); B->dims.assign(problems, problems + n);
     for (int p = 0; p < n; ++p) {
@@ -4774,9 +4795,6 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         }
         up(O.op_pose, R.op_pose.data(), 4 * R.op_pose.size()); up(O.op_o, R.op_o.data(), 4 * R.op_o.size()); up(O.op_uvi, R.op_uvi.data(), sizeof(double) * R.op_uvi.size());
         up(O.edge_i, Q.edge_i, 4 * Q.n_pose_edge); up(O.edge_j, Q.edge_j, 4 * Q.n_pose_edge); up(O.edge_meas, Q.edge_meas, 7 * Q.n_pose_edge * D); up(O.edge_info, Q.edge_info, 36 * Q.n_pose_edge * D);
-        // (the shared staging block is written again for the next problem: wait; the context's own block holds every problem's inputs side by side: no wait)
-        if (hipMemcpyAsync(B->d_arena + in_lo[p], stage, stage_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            (!staged && hipStreamSynchronize(c->stream) != hipSuccess)) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
         BaProb &H = B->host[p];
         char *a = B->d_arena;
         H.n_pose = Q.n_pose; H.n_point = Q.n_point; H.n_obs = Q.n_obs; H.n_edge = Q.n_pose_edge; H.np_free = R.np_free; H.n6 = 6 * R.np_free;
@@ -4816,6 +4834,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         H.op_rec = R.one_pose ? PTR(double, op_rec) : nullptr; H.op_red = R.one_pose ? PTR(double, op_red) : nullptr;
         if (p == 0) B->one_pose = R.one_pose; else B->one_pose = B->one_pose && R.one_pose;
         if (n == 1 && B->pack_doubles) B->d_pack = PTR(double, pack);
+        H.pack = (n == 1 && B->pack_doubles) ? PTR(double, pack) : nullptr;
         B->alt_ptrs.push_back(!R.fo_lo.empty() && R.fused ? ms_ba::AltPtrs{PTR(double, Hpp2), PTR(double, bp2), PTR(double, Hll2), PTR(double, bl2)} : ms_ba::AltPtrs{nullptr, nullptr, nullptr, nullptr});
         B->chol_tiles.push_back(R.chol_tiles);
         {   // poseBundleAdjust-shaped: one free pose, no free point
@@ -4824,11 +4843,22 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
             if (p == 0) B->pose_only = po; else B->pose_only = B->pose_only && po;
         }
 #undef PTR
+        if (n == 1) {                                       // the two descriptors ride in the input range (O.desc)
+            ba_make_alt(B);
+            std::memcpy(stage + (O.desc - in_lo[p]), &B->host[0], sizeof(BaProb));
+            std::memcpy(stage + (O.desc - in_lo[p]) + sizeof(BaProb), &B->host_alt[0], sizeof(BaProb));
+        }
+        // (the shared staging block is written again for the next problem: wait; the context's own block holds every problem's inputs side by side: no wait)
+        if (hipMemcpyAsync(B->d_arena + in_lo[p], stage, stage_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            (!staged && hipStreamSynchronize(c->stream) != hipSuccess)) { ms_ba_destroy(B); return ms_fail(c, MS_ERR_HIP, "ms_ba_create: upload failed"); }
     }
     {
         hipError_t e;
         ba_make_alt(B);
-        if (staged) {                                       // the descriptors (both sets, side by side like on the device) follow the inputs out of the same block; its next user waits for ba_stage_ev
+        if (n == 1) {                                       // (went up with the inputs)
+            e = staged ? hipEventRecord(c->ba_stage_ev, c->stream) : hipSuccess;
+            if (staged) c->ba_stage_busy = e == hipSuccess;
+        } else if (staged) {                                // the descriptors (both sets, side by side like on the device) follow the inputs out of the same block; its next user waits for ba_stage_ev
             char *at = static_cast<char *>(c->ba_stage) + stage_at;
             std::memcpy(at, B->host.data(), sizeof(BaProb) * n);
             std::memcpy(at + sizeof(BaProb) * n, B->host_alt.data(), sizeof(BaProb) * n);
@@ -4899,8 +4929,10 @@ void ms_ba_destroy(ms_ba *B) {
             int32_t *const hver = B->h_verdict;
             std::vector<BaProb> host = std::move(B->host), host_alt = std::move(B->host_alt); std::vector<ms_ba_problem> dims = std::move(B->dims); std::vector<double> tiles = std::move(B->chol_tiles);
             std::vector<ms_ba::AltPtrs> alt_ptrs = std::move(B->alt_ptrs);
-            host.clear(); host_alt.clear(); dims.clear(); tiles.clear(); alt_ptrs.clear();
+            std::vector<size_t> wlo = std::move(B->work_lo), whi = std::move(B->work_hi);
+            host.clear(); host_alt.clear(); dims.clear(); tiles.clear(); alt_ptrs.clear(); wlo.clear(); whi.clear();
             *B = ms_ba();
+            B->work_lo = std::move(wlo); B->work_hi = std::move(whi);
             B->host = std::move(host); B->host_alt = std::move(host_alt); B->alt_ptrs = std::move(alt_ptrs); B->dims = std::move(dims); B->chol_tiles = std::move(tiles); B->ev_done = ev;
             B->h_result = hres; B->h_result_bytes = hres_bytes; B->h_verdict = hver;
             *slot = B;
@@ -4937,7 +4969,7 @@ static int ba_after_launch(ms_ctx *c, ms_ba *B) {
         B->verdict_eager = true;
     }
     if (B->d_pack && !B->last_one_pose) {                          // (stage 1 of a window is handed on by ms_ba_copy_state, not downloaded: nothing to pack)
-        hipLaunchKernelGGL(k_ba_pack_result, dim3((unsigned)std::min<size_t>(ms_div_up((int)B->pack_doubles, 256), 256)), dim3(256), 0, c->stream, B->d_probs, 0, B->d_pack, 1);
+        if (!B->self_packed) hipLaunchKernelGGL(k_ba_pack_result, dim3((unsigned)std::min<size_t>(ms_div_up((int)B->pack_doubles, 256), 256)), dim3(256), 0, c->stream, B->d_probs, 0, B->d_pack, 1);
         MS_KERNEL_CHECK(c, "k_ba_pack_result");
         MS_HIP(c, hipMemcpyAsync(B->h_result, B->d_pack, B->pack_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         B->eager = true;
@@ -4959,7 +4991,12 @@ int ms_ba_solve(ms_ba *B) {
         hipLaunchKernelGGL(k_ba_pose_only, dim3(B->n), dim3(PO_NT), kPoLdsBytes, ls, B->d_probs);
         MS_KERNEL_CHECK(c, "k_ba_pose_only");
         B->launched_team = 1; B->team_checked = true; B->last_one_pose = false; ++B->solves;
+        B->self_packed = B->d_pack != nullptr;
         return ba_after_launch(c, B);
+    }
+    if (B->work_dirty) {                                   // a pose-only handle on the general kernel (an explicit team, MS_BA_NO_POSE_KERNEL): its work areas were never cleared
+        for (size_t p = 0; p < B->work_lo.size(); ++p) MS_HIP(c, hipMemsetAsync(B->d_arena + B->work_lo[p], 0, B->work_hi[p] - B->work_lo[p], ls));
+        B->work_dirty = false;
     }
     int most_obs = 0, most_points = 0, most_poses = 0;
     for (const auto &h : B->host) { most_obs = std::max(most_obs, h.n_obs); most_points = std::max(most_points, h.n_point); most_poses = std::max(most_poses, h.n_pose); }
@@ -5052,6 +5089,7 @@ int ms_ba_solve(ms_ba *B) {
     }
     B->launched_team = team;
     B->team_checked = team == 1;
+    B->self_packed = false;
     ++B->solves;
     return ba_after_launch(c, B);
 }
@@ -5061,7 +5099,7 @@ static int ba_relaunch_single(ms_ba *B) {
     ms_ctx *c = B->ctx;
     const hipStream_t ls = c->stream;
     for (auto &h : B->host) { h.team = 1; h.chol_team = 1; }
-    B->eager = false; B->verdict_eager = false;                     // (what h_result / h_verdict hold belongs to the void launch)
+    B->eager = false; B->verdict_eager = false; B->self_packed = false;   // (what h_result / h_verdict hold belongs to the void launch)
     MS_HIP(c, ba_upload_descriptors(B, ls));
     if (B->last_one_pose) {
         int most_poses = 0, most_points = 0;
