@@ -407,7 +407,7 @@ typedef struct ms_ba ms_ba;
  * after warm-up, and a small window never sits on a large block.  If the device is out of memory the kept blocks are freed and the
  * allocation is tried once more.  Kept blocks are released by ms_ctx_destroy.
  * Two shapes are recognised here and solved by kernels of their own (same LM schedule, same arithmetic per edge; results agree with the general
- * kernel to rounding): every problem has ONE free pose and only fixed points, <= 8 SE3 edges -- poseBundleAdjust, bundle_adjuster.cpp:396-491;
+ * kernel to rounding): every problem has ONE free pose and only fixed points, <= 8 SE3 edges at the free pose -- poseBundleAdjust, bundle_adjuster.cpp:396-491;
  * every problem has ONE free pose and at least one free point, <= 8 SE3 edges at the free pose -- stage 1 of localBundleAdjust,
  * bundle_adjuster.cpp:251-252,:322-333 (for this one ms_ba_set_team picks the team of the special kernel: 0 = automatic, up to 8 workgroups).
  * Environment switches for comparisons: MS_BA_NO_POSE_KERNEL=1 / MS_BA_NO_ONE_POSE_KERNEL=1 keep the general kernel. */

@@ -4096,6 +4096,12 @@ constexpr size_t kBaEagerMax = (size_t)64 << 10;        // results of a single p
                                                         //  sequence, running beside it, fell from 2.7-3.0 k to 2.0-2.2 k frames/s -- tools/together_ab.sh; kept for small problems)
 constexpr size_t kBaStageMax = (size_t)4 << 20;        // creates whose inputs fit are uploaded from the context's page-locked staging block without a wait
 static size_t ba_eager_max() { static const size_t v = std::getenv("MS_BA_EAGER_MAX") ? (size_t)std::atoll(std::getenv("MS_BA_EAGER_MAX")) : kBaEagerMax; return v; }     // (experiment knob)
+// SE3 edges that touch pose `pi` (k_ba_pose_only / k_ba_one_pose keep their constants in PO_MAXE LDS slots; edges between fixed poses need none)
+static int ba_edges_at_free_pose(const ms_ba_problem &Q, int pi) {
+    int t = 0;
+    for (int k = 0; k < Q.n_pose_edge; ++k) t += Q.edge_i[k] == pi || Q.edge_j[k] == pi;
+    return t;
+}
 // the descriptors of the second linearisation set: host_alt[i] = host[i] with the four output arrays exchanged (rebuilt whenever host[] is about to be uploaded: the
 // two must agree in everything else -- team sizes included)
 static void ba_make_alt(ms_ba *B) {
@@ -4751,7 +4757,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         // arena is not cleared now -- ms_ba_solve clears the work areas (everything behind the inputs) should the general kernel ever run on the handle
         bool all_po = true;
         for (int p = 0; p < n && all_po; ++p) {
-            all_po = prep[p].np_free == 1 && problems[p].n_pose_edge <= PO_MAXE && problems[p].point_fixed != nullptr;
+            all_po = prep[p].np_free == 1 && problems[p].point_fixed != nullptr && ba_edges_at_free_pose(problems[p], prep[p].free2pose.empty() ? -1 : prep[p].free2pose[0]) <= PO_MAXE;
             for (int l = 0; l < problems[p].n_point && all_po; ++l) all_po = problems[p].point_fixed[l] != 0;
         }
         B->work_dirty = all_po;
@@ -4838,7 +4844,7 @@ int ms_ba_create(ms_ctx *c, const ms_ba_problem *problems, int n, ms_ba **out) {
         B->alt_ptrs.push_back(!R.fo_lo.empty() && R.fused ? ms_ba::AltPtrs{PTR(double, Hpp2), PTR(double, bp2), PTR(double, Hll2), PTR(double, bl2)} : ms_ba::AltPtrs{nullptr, nullptr, nullptr, nullptr});
         B->chol_tiles.push_back(R.chol_tiles);
         {   // poseBundleAdjust-shaped: one free pose, no free point
-            bool po = R.np_free == 1 && problems[p].n_pose_edge <= PO_MAXE;
+            bool po = R.np_free == 1 && ba_edges_at_free_pose(problems[p], R.free2pose[0]) <= PO_MAXE;      // (edges between fixed poses are constants: any number)
             for (int l = 0; l < problems[p].n_point && po; ++l) po = problems[p].point_fixed && problems[p].point_fixed[l];
             if (p == 0) B->pose_only = po; else B->pose_only = B->pose_only && po;
         }

@@ -421,6 +421,21 @@ int main(int argc, char **argv) {
         const long long after = ms_debug_host_allocs();
         std::printf("24 sliding windows: library allocations after warm-up %lld (total so far %lld), worst chi2 ratio %.3g\n", after - at_warm, after, worst);
         if (after != at_warm || !(worst < 1.0)) return 21;
+        // ... and the per-frame path beside it (mapper_helpers.cpp:1043-1050, :1079-1081): a poseBundleAdjust per frame, a window on every 5th -- the staging block, the
+        // handles' result blocks and their objects go round between the two kinds of problem; nothing new after the first keyframes
+        long long at_warm2 = 0;
+        for (int f = 0; f < 60; ++f) {
+            if (f == 20) at_warm2 = ms_debug_host_allocs();
+            BaWindow s = make(f);
+            BaWindow sp = s;                                              // the newest keyframe against the window's points (all fixed), knocked off its place
+            sp.poses[11][4] += 0.01; sp.poses[11][5] -= 0.01;
+            ms_ba_result pr{};
+            if (!poseBundleAdjust(ctx, sp, 10, &pr) || !(pr.chi2_final < pr.chi2_initial)) return 22;
+            if (f % 5 == 0) { const BaOutcome bo = localBundleAdjust(ctx, s, 12, params, true, nullptr); if (!(bo.stage2.chi2_final <= bo.stage1.chi2_initial)) return 23; }
+        }
+        const long long after2 = ms_debug_host_allocs();
+        std::printf("60 frames (a pose adjustment each, a window on every 5th): library allocations after warm-up %lld\n", after2 - at_warm2);
+        if (after2 != at_warm2) return 24;
     }
     // globalBundleAdjust-sized map: 200 keyframes on a line (the current one fixed), 1500 points each seen by 8 consecutive keyframes
     {
