@@ -35,7 +35,7 @@ W, H, LEVELS, SCALE, MAX_KPTS, FAST_THR, BATCH = 1280, 720, 8, 1.2, 2000, 20, 25
 LOWE_RATIO = 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")      # HBM bytes / instruction counts per launch of the committed kernel sources
-N_SEQ = 8                      # C5: independent sequences of the whole job
+N_SEQ = int(os.environ.get("BENCH_N_SEQ", "8"))      # C5: independent sequences of the whole job (8; the variable is for experiments)
 
 
 def parse_args(argv=None):
@@ -261,7 +261,10 @@ class Rank:
             # hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's default of 4 queues a sequence's 10 us
             # front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
             import mi355slam
-            self.queues_prepared = mi355slam.prepare_process(N_SEQ)   # False: the runtime was up already (a profiler's preloaded tool): the queues are what the environment said then
+            # (round 4: ms_prepare_process asks for TWO queues per context -- a context owns two streams --: the sequences of THIS rank, 16 queues for the 8 of one rank,
+            #  4 for one sequence per rank at N = 8 or for six ranks on one GPU; the pipelined leg's 2 x 8 contexts run on the same 16)
+            n_mine = len([q for q in range(N_SEQ) if q % max(self.world, 1) == self.rank])
+            self.queues_prepared = mi355slam.prepare_process(max(n_mine, 1))   # False: the runtime was up already (a profiler's preloaded tool): the queues are what the environment said then
             self.hw_queues = mi355slam.hw_queues()
             torch.cuda.set_device(self.gpu)
         self.backend = None
@@ -1235,6 +1238,8 @@ def bench_pipelined(R, args):
                     a, b = stages[k % len(stages)]
                     h1 = mi355slam.BundleAdjuster(ctx, [a], max_iters=iters); h1.solve()      # stage 1 runs while the host builds stage 2's index structures
                     h2 = mi355slam.BundleAdjuster(ctx, [b], max_iters=iters)
+                    if args.c5_team:
+                        h2.set_team(args.c5_team)
                     h2.copy_state_from(h1, extra); h2.solve(); h2.download(0); h1.close(); h2.close()
                 window(0); ctx.sync()
                 self.ready.set()
@@ -1282,7 +1287,38 @@ def bench_pipelined(R, args):
     _, b_alone = run_pair(False, "alone")
     f_both, b_both = run_pair(True, "fed")
     med = lambda v: round(float(np.median(v)), 3) if len(v) else None
-    return {"workload": "one 720p sequence x %d frames; front end per frame: extract -> match vs previous -> ratio test -> poseBundleAdjust (new problem: create + solve + download); "
+
+    def run_many(n_seq):
+        """n_seq sequences side by side, each with its front end and its back end (2 n_seq host threads and contexts): C5's sequences in the deployment shape."""
+        start = threading.Event()
+        backs = [Back(start) for _ in range(n_seq)]
+        fronts = [Front(start, b.keyframe) for b in backs]
+        for t in fronts + backs:
+            t.start()
+        for t in fronts + backs:
+            t.ready.wait()
+        start.set()
+        for t in fronts:
+            t.join()
+        for b in backs:
+            b.stop()
+        for b in backs:
+            b.join()
+        for t in fronts + backs:
+            if t.error:
+                raise t.error
+        return fronts, backs
+    from mi355slam import shard
+    n_mine = len([q for q in range(N_SEQ) if shard.sequence_of(q, R.world) == R.rank])
+    many = None
+    if n_mine > 1:
+        fs, bs = run_many(n_mine)
+        secs = max(f.seconds for f in fs)
+        lat = [x for b in bs for x in b.lat_ms]
+        many = {"sequences": n_mine, "frames_per_s": round(n_mine * F / secs, 1), "per_sequence_frames_per_s": [round(F / f.seconds, 1) for f in fs],
+                "pose_ba_ms_per_frame": round(float(np.mean([f.pose_ms for f in fs])), 4), "keyframes_handled": len(lat), "keyframes_per_s": round(len(lat) / secs, 1),
+                "two_stage_new_window_ms_median": med(lat), "keyframe_wait_ms_median": med([x for b in bs for x in b.wait_ms])}
+    return {"sequences_side_by_side": many, "workload": "one 720p sequence x %d frames; front end per frame: extract -> match vs previous -> ratio test -> poseBundleAdjust (new problem: create + solve + download); "
                         "back end per keyframe (every %d-th frame): localBundleAdjust of a NEW C4 window, two-stage, %d + %d iterations; two host threads, two contexts" % (F, KF, iters, iters),
             "reference": "mapper.cpp:356-393 beside mapper.cpp:229-279 (mapper_helpers.cpp:1043-1050, :1079-1081)",
             "front_end_alone": {"frames_per_s": round(F / f_alone.seconds, 1), "ms_per_frame": round(f_alone.seconds / F * 1e3, 4), "pose_ba_ms_per_frame": round(f_alone.pose_ms, 4),

@@ -5048,8 +5048,9 @@ int ms_ba_solve(ms_ba *B) {
         std::lock_guard<std::mutex> lk(g_team_mu);
         std::vector<TeamLaunch> &live = g_team_live[c->device & 63];
         const int need = B->n * team;
+        static const int cap_env = std::getenv("MS_BA_TEAM_CU_CAP") ? std::atoi(std::getenv("MS_BA_TEAM_CU_CAP")) : 0;      // (experiment knob: CUs the team launches of a device may hold together)
+        const int team_cap = cap_env > 0 ? std::max(need, std::min(B->cus, cap_env)) : B->cus;
         int in_use = 0;
-        in_use = 0;
         for (TeamLaunch &t : live) {                                   // retire what has finished; launches of this stream precede the new one anyway
             if (t.live) {                                              // anything but "not ready" retires the entry (an error: the stream it was recorded on is gone)
                 const hipError_t q = hipEventQuery(t.ev);
@@ -5065,7 +5066,7 @@ int ms_ba_solve(ms_ba *B) {
             if (t.live && t.stream != ls) in_use += t.wgs;
         }
         for (TeamLaunch &t : live) {                                   // oldest first: wait for as many as it takes to make room
-            if (in_use + need <= B->cus) break;
+            if (in_use + need <= team_cap) break;
             if (!t.live || t.stream == ls) continue;
             MS_HIP(c, hipStreamWaitEvent(ls, t.ev, 0));                // on the device
             in_use -= t.wgs;

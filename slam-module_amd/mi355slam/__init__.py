@@ -66,7 +66,7 @@ MS_ERR_TOO_LATE = -6
 
 
 def prepare_process(concurrent_contexts):
-    """ms_prepare_process: before the first HIP call of the process -- as many hardware queues as there will be contexts driving the GPU at once.
+    """ms_prepare_process: before the first HIP call of the process -- two hardware queues per context that will drive the GPU at once (at least 4, at most 32).
     Returns True when the setting is in place (made now, or already in the environment), False when the GPU runtime of this process was up already
     (MS_ERR_TOO_LATE: e.g. under a profiler whose preloaded tool initialises the GPU first) -- the process then runs on the queues it has."""
     rc = lib().ms_prepare_process(int(concurrent_contexts))

@@ -125,7 +125,7 @@ def test_keypoint_records_unpack_in_serialize_order():
 
 
 def test_prepare_process_sets_the_queue_count_once():
-    """ms_prepare_process: GPU_MAX_HW_QUEUES = clamp(contexts, 4, 16) unless the caller's environment already has a value; no HIP call involved."""
+    """ms_prepare_process: GPU_MAX_HW_QUEUES = clamp(2 x contexts, 4, 32) unless the caller's environment already has a value; no HIP call involved."""
     import ctypes as C
     import subprocess
     import sys
@@ -142,7 +142,7 @@ print(libc.getenv(b"GPU_MAX_HW_QUEUES").decode())
 ''' % ROOT
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     run = lambda n, e: subprocess.run([sys.executable, "-c", code, str(n)], env=e, capture_output=True, text=True, check=True).stdout.strip()
-    assert run(8, env) == "8" and run(2, env) == "4" and run(40, env) == "16"
+    assert run(8, env) == "16" and run(2, env) == "4" and run(1, env) == "4" and run(40, env) == "32"
     assert run(8, dict(env, GPU_MAX_HW_QUEUES="2")) == "2"               # the caller's own setting wins
 
 

@@ -2,7 +2,7 @@
 # PMC passes over the local-BA leg of bench.py (k_ba_lm, 256 distinct C4 windows per launch): usage  bash tools/pmc_ba.sh <out.json>
 # One counter group per run, --kernel-trace only.  Writes the per-launch averages of the 256-workgroup launches.
 cd /tmp && export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=8      # as in tools/profile_set.sh: under the profiler ms_prepare_process comes too late
+export GPU_MAX_HW_QUEUES=16      # as in tools/profile_set.sh: under the profiler ms_prepare_process comes too late
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the snapshot root)}"
 R=$GRAFT_REPO_ROOT
 OUT=${1:-$R/gpurun_out/pmc_ba.json}; case "$OUT" in /*) ;; *) OUT="$R/$OUT";; esac

@@ -10,8 +10,8 @@ O=$R/gpurun_out/prof_$tag
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # the profiler's preloaded tool initialises the GPU before bench.py runs, so ms_prepare_process comes too late there: give the profiled runs the queue count the
-# unprofiled bench line gets from the library (8 sequences on one GPU in its C5 leg), and the bench line says which applied (c5.hw_queues)
-export GPU_MAX_HW_QUEUES=8
+# unprofiled bench line gets from the library (two per context: 16 for the 8 sequences of its C5 leg), and the bench line says which applied (c5.hw_queues)
+export GPU_MAX_HW_QUEUES=16
 if [ -z "$SKIP_HEAD" ]; then      # SKIP_HEAD=1: the bench line, the kernel stats and the front-end counter passes are already in $O; do the calibration and the BA passes
 python3 "$R/bench.py" > "$O/bench_default.json" 2> "$O/bench_default.err"
 echo "bench done"
