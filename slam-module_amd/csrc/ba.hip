@@ -5048,8 +5048,7 @@ int ms_ba_solve(ms_ba *B) {
         std::lock_guard<std::mutex> lk(g_team_mu);
         std::vector<TeamLaunch> &live = g_team_live[c->device & 63];
         const int need = B->n * team;
-        static const int cap_env = std::getenv("MS_BA_TEAM_CU_CAP") ? std::atoi(std::getenv("MS_BA_TEAM_CU_CAP")) : 0;      // (experiment knob: CUs the team launches of a device may hold together)
-        const int team_cap = cap_env > 0 ? std::max(need, std::min(B->cus, cap_env)) : B->cus;
+        const int team_cap = B->cus;                                   // (a lower cap -- 224, 192, 128 of the 256 CUs left to the team launches of a device -- changed nothing for 8 sequences, round 4)
         int in_use = 0;
         for (TeamLaunch &t : live) {                                   // retire what has finished; launches of this stream precede the new one anyway
             if (t.live) {                                              // anything but "not ready" retires the entry (an error: the stream it was recorded on is gone)
