@@ -1318,7 +1318,31 @@ def bench_pipelined(R, args):
         many = {"sequences": n_mine, "frames_per_s": round(n_mine * F / secs, 1), "per_sequence_frames_per_s": [round(F / f.seconds, 1) for f in fs],
                 "pose_ba_ms_per_frame": round(float(np.mean([f.pose_ms for f in fs])), 4), "keyframes_handled": len(lat), "keyframes_per_s": round(len(lat) / secs, 1),
                 "two_stage_new_window_ms_median": med(lat), "keyframe_wait_ms_median": med([x for b in bs for x in b.wait_ms])}
-    return {"sequences_side_by_side": many, "workload": "one 720p sequence x %d frames; front end per frame: extract -> match vs previous -> ratio test -> poseBundleAdjust (new problem: create + solve + download); "
+    # ... and the same with C++ threads on the C ABI (tools/c5_native.cpp: c5p_prepare / c5p_go), so that the interpreter's share of the figure above is known
+    native, many_native = _c5_native_lib(), None
+    if n_mine > 1 and native is not None and hasattr(native, "c5p_prepare"):
+        import ctypes as C
+        keep = []
+        def structs(probs, it):
+            st, kp = zip(*[mi355slam._ba_struct(q, it) for q in probs]); keep.append(kp)
+            return (mi355slam.BaProblemC * len(st))(*st)
+        parr, s1arr, s2arr = structs(pose_probs, 10), structs([a for a, _ in stages], iters), structs([b for _, b in stages], iters)
+        fptr = (C.c_void_p * n_mine)(*[frames.ctypes.data for _ in range(n_mine)])
+        native.c5p_prepare.restype = C.c_void_p
+        job = native.c5p_prepare(R.gpu, n_mine, F, FD, W, H, fptr, parr, len(pose_probs), s1arr, s2arr, len(stages), cur, KF, LEVELS, C.c_float(SCALE), MAX_KPTS, FAST_THR, C.c_float(LOWE_RATIO))
+        if not job:
+            raise RuntimeError("c5p_prepare failed")
+        secs, seq_s, pose_ms, handled, win_ms, wait_ms = C.c_double(), (C.c_double * n_mine)(), C.c_double(), C.c_int32(), C.c_double(), C.c_double()
+        err = C.create_string_buffer(512)
+        rc = native.c5p_go(C.c_void_p(job), C.byref(secs), seq_s, C.byref(pose_ms), C.byref(handled), C.byref(win_ms), C.byref(wait_ms), err, 512)
+        if rc != 0:
+            raise RuntimeError("c5p native driver: %s (status %d)" % (err.value.decode(), rc))
+        smax = max(seq_s)
+        many_native = {"sequences": n_mine, "driver": "tools/c5_native.cpp (a front-end and a back-end C++ thread per sequence on the C ABI)", "frames_per_s": round(n_mine * F / smax, 1),
+                       "per_sequence_frames_per_s": [round(F / x, 1) for x in seq_s], "pose_ba_ms_per_frame": round(pose_ms.value, 4), "keyframes_handled": handled.value,
+                       "keyframes_per_s": round(handled.value / smax, 1), "two_stage_new_window_ms_median": round(win_ms.value, 3), "keyframe_wait_ms_median": round(wait_ms.value, 3)}
+        del keep
+    return {"sequences_side_by_side": many, "sequences_side_by_side_native": many_native, "workload": "one 720p sequence x %d frames; front end per frame: extract -> match vs previous -> ratio test -> poseBundleAdjust (new problem: create + solve + download); "
                         "back end per keyframe (every %d-th frame): localBundleAdjust of a NEW C4 window, two-stage, %d + %d iterations; two host threads, two contexts" % (F, KF, iters, iters),
             "reference": "mapper.cpp:356-393 beside mapper.cpp:229-279 (mapper_helpers.cpp:1043-1050, :1079-1081)",
             "front_end_alone": {"frames_per_s": round(F / f_alone.seconds, 1), "ms_per_frame": round(f_alone.seconds / F * 1e3, 4), "pose_ba_ms_per_frame": round(f_alone.pose_ms, 4),
