@@ -261,7 +261,7 @@ class Rank:
             # hardware queue per sequence that will share the GPU (C5: up to 8 contexts on one device; with the runtime's default of 4 queues a sequence's 10 us
             # front-end kernels wait behind another sequence's 1.8 ms BA launch -- 4 300 against 6 100 frames/s)
             import mi355slam
-            # (round 4: ms_prepare_process asks for TWO queues per context -- a context owns two streams --: the sequences of THIS rank, 16 queues for the 8 of one rank,
+            # (round 4: ms_prepare_process asks for TWO queues per context: the sequences of THIS rank, 16 queues for the 8 of one rank,
             #  plus the rank's own: 18 queues for the 8 sequences of one rank, 4 - 6 at N = 8 or for six ranks on one GPU; the pipelined leg's 2 x 8 contexts run on the same 18)
             n_mine = len([q for q in range(N_SEQ) if q % max(self.world, 1) == self.rank])
             self.queues_prepared = mi355slam.prepare_process(n_mine + 1)       # (+ the rank's own context)  False: the runtime was up already (a profiler's preloaded tool): the queues are what the environment said then

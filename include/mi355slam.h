@@ -52,8 +52,8 @@ typedef struct ms_orb ms_orb;
 /* Optional, once per process, BEFORE the first HIP call of the process (ms_ctx_create included): tells the runtime how many contexts (= sequences, each
  * with its own stream) will drive the same GPU at the same time.  The HIP runtime maps streams onto a handful of hardware queues (4 by default), and kernels
  * of streams that share a queue run one after the other -- a 1.8 ms local-BA launch of one sequence then holds up the 10 us front-end kernels of another:
- * eight sequences on one GPU measured 4 300 frames/s with 4 queues, 5 600 with 8 and 8 400 - 8 700 with 12 ... 32 (a context owns TWO streams: its own and the one
- * its asynchronous downloads run on; tools/hw_queue_sweep.sh).  Sets GPU_MAX_HW_QUEUES to max(4, min(2 * concurrent_contexts, 32)) unless the variable is already set (the caller's own setting wins: MS_OK, nothing changed).  Once the runtime is
+ * eight sequences on one GPU measured 4 300 frames/s with 4 queues, 5 600 with 8 and 8 400 - 8 700 with 12 ... 32 (the process holds more streams than its sequences' -- a context's
+ * download stream, the application's own --, and with exactly one queue per context two sequences share one; tools/hw_queue_sweep.sh).  Sets GPU_MAX_HW_QUEUES to max(4, min(2 * concurrent_contexts, 32)) unless the variable is already set (the caller's own setting wins: MS_OK, nothing changed).  Once the runtime is
  * initialised -- by this library or by anybody else in the process: the kernel driver's device node is open -- the variable has been read and the call returns
  * MS_ERR_TOO_LATE without touching the environment, so a host that calls it late learns that it runs on the default number of queues.  (The reference has no
  * counterpart: its back end is one CPU thread per sequence, mapper.cpp:268-269.) */

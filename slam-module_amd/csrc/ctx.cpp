@@ -103,8 +103,8 @@ int ms_prepare_process(int concurrent_contexts) {
     if (concurrent_contexts < 1) return MS_ERR_INVALID;
     if (std::getenv("GPU_MAX_HW_QUEUES")) return MS_OK;              // the caller's own setting wins (and was there when the runtime came up, if it has)
     if (gpu_runtime_is_up()) return MS_ERR_TOO_LATE;                 // the variable has been read: setting it now would only pretend
-    // TWO queues per context: a context owns two streams (its own and the one its asynchronous downloads run on), and streams that share a hardware queue wait for
-    // each other's kernels -- with one queue per context eight sequences on one GPU made 5.6 k frames/s, with 12 ... 32 queues 8.4-8.7 k (tools/hw_queue_sweep.sh, round 4)
+    // TWO queues per context: the runtime deals its queues to streams in turn and the process holds more streams than its sequences' (a context's download stream, the
+    // application's own), and streams that share a hardware queue wait for each other's kernels -- with one queue per context eight sequences on one GPU made 5.6 k frames/s, with 12 ... 32 queues 8.4-8.7 k (tools/hw_queue_sweep.sh, round 4)
     const int q = std::max(4, std::min(2 * concurrent_contexts, 32));
     return setenv("GPU_MAX_HW_QUEUES", std::to_string(q).c_str(), 0) == 0 ? MS_OK : MS_ERR_INVALID;
 }
